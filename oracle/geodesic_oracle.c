@@ -1,0 +1,667 @@
+/*
+ * geodesic_oracle.c -- CPU restatement (plain C) of the reference's per-ray null-geodesic solve.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the *checker*: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call it.  The product path
+ * (blackhole_geodesic_calculator_amd/) never links or imports it and has no CPU fallback.
+ *
+ * PARITY UNPINNED.  The reference tree holds no solver arithmetic, no tests and no golden
+ * vectors for this path: the arithmetic is in the un-vendored, un-pinned third-party package
+ * `curvedpy` (reference README.md:23-24, :93; raytracer/RelativisticRenderEngine.py:7), which
+ * cannot be installed here.  This restatement therefore follows
+ *   - the ODE and metric stated in the reference README            (README.md:162-174, :198-209)
+ *   - the call-site contract of calc_trajectory                    (raytracer/RelativisticRenderEngine.py:134, :281, :293-313)
+ *   - the sphere-exit semantics of the Limited engine's ray_trace  (raytracer/LimitedRelativisticRenderEngine.py:273-278)
+ *   - scipy 1.15.3's RK45 (the integrator README.md:196 names):    scipy/integrate/_ivp/rk.py:14-71 (rk_step),
+ *     :111-176 (_step_impl), :377-404 (tableau, dense output P), common.py:63-134 (norm,
+ *     select_initial_step), ivp.py:51-76 (brentq event root), :109-126 (find_active_events),
+ *     :673-694 (event handling), base.py:175-206 (step / finished test)
+ * and it is pinned against scipy.integrate.solve_ivp itself (run in the build container, fixtures
+ * committed under tests/golden/ with the generating script) and against physics known answers.
+ *
+ * Arithmetic mirrors scipy's order of operations (no FMA contraction: build with
+ * -ffp-contract=off) so that accept/reject decisions and step counts agree with solve_ivp.
+ *
+ * State layout on the boundary: x0[3], k0[3] in; end[6] = {x, y, z, k_x, k_y, k_z} out
+ * (the Cam edition's ray_end[..., 0:3] = position, [..., 3:6] = direction,
+ *  raytracer/RelativisticRenderEngineCamEdition.py:225-228).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BHGO_FLAG_HIT_HORIZON 1u
+#define BHGO_FLAG_START_INSIDE 2u
+#define BHGO_FLAG_REACHED_END 4u
+#define BHGO_FLAG_EXITED_SPHERE 8u
+#define BHGO_FLAG_MAX_STEPS 16u
+#define BHGO_FLAG_STEP_TOO_SMALL 32u
+#define BHGO_FLAG_NAN 64u
+
+#define BHGO_METHOD_DP54 0
+#define BHGO_METHOD_RK4 1
+#define BHGO_RHS_CHRISTOFFEL 0
+#define BHGO_RHS_REDUCED 1
+
+typedef struct {
+    double r_s;        /* horizon radius = 2*mass (RelativisticRenderEngine.py:95) */
+    double lambda_end; /* curve_end (RelativisticRenderEngine.py:62, :294) */
+    double max_step;   /* max_step; +inf when the scene property is -1 (:59-60) */
+    double rtol;       /* scipy default 1e-3 (rk.py:86) */
+    double atol;       /* scipy default 1e-6 (rk.py:86) */
+    double h_fixed;    /* RK4 only */
+    double r_exit;     /* 0 = off; outward sphere exit radius (Limited engine) */
+    int32_t method;    /* BHGO_METHOD_* */
+    int32_t rhs_form;  /* BHGO_RHS_* */
+    uint32_t max_steps; /* cap on attempted steps per ray, 0 = no cap */
+    uint32_t reserved;
+} bhgo_params;
+
+/* ---------------------------------------------------------------------------------------
+ * RHS: the spatial acceleration -Gamma^i_{mu nu} k^mu k^nu with k^t from the null condition
+ * (README.md:198-209; time_like=False at RelativisticRenderEngine.py:134).
+ * ------------------------------------------------------------------------------------- */
+static void acc_christoffel(const double x[3], const double k[3], double r_s, double a[3])
+{
+    /* a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ],
+       f = 1 - r_s/r, f' = r_s/r^2, h = r_s/(r - r_s), h' = -r_s/(r - r_s)^2,
+       (k^t)^2 = (|k|^2 + h (n.k)^2)/f.  Singular at r = r_s, like the lambdified contraction. */
+    double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    double r = sqrt(r2);
+    double nk = (x[0] * k[0] + x[1] * k[1] + x[2] * k[2]) / r;
+    double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    double f = 1.0 - r_s / r;
+    double fp = r_s / r2;
+    double h = r_s / (r - r_s);
+    double hp = -r_s / ((r - r_s) * (r - r_s));
+    double kt2 = (kk + h * nk * nk) / f;
+    double s = 0.5 * f * fp * kt2 + 0.5 * f * hp * nk * nk + (r_s / r2) * (kk - nk * nk);
+    double c = -s / r;
+    a[0] = c * x[0];
+    a[1] = c * x[1];
+    a[2] = c * x[2];
+}
+
+static void acc_reduced(const double x[3], const double k[3], double r_s, double a[3])
+{
+    /* algebraically identical for null rays: a = -(3/2) r_s |x cross k|^2 x / r^5 */
+    double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    double xk = x[0] * k[0] + x[1] * k[1] + x[2] * k[2];
+    double L2 = r2 * kk - xk * xk;
+    double c = -1.5 * r_s * L2 / (r2 * r2 * sqrt(r2));
+    a[0] = c * x[0];
+    a[1] = c * x[1];
+    a[2] = c * x[2];
+}
+
+/* y = [k_x, x, k_y, y, k_z, z]  (RelativisticRenderEngine.py:301) */
+static void rhs(const bhgo_params *p, const double y[6], double dy[6])
+{
+    double x[3] = {y[1], y[3], y[5]};
+    double k[3] = {y[0], y[2], y[4]};
+    double a[3];
+    if (p->rhs_form == BHGO_RHS_REDUCED)
+        acc_reduced(x, k, p->r_s, a);
+    else
+        acc_christoffel(x, k, p->r_s, a);
+    dy[0] = a[0];
+    dy[1] = k[0];
+    dy[2] = a[1];
+    dy[3] = k[1];
+    dy[4] = a[2];
+    dy[5] = k[2];
+}
+
+static double radius(const double y[6])
+{
+    return sqrt(y[1] * y[1] + y[3] * y[3] + y[5] * y[5]);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Dormand-Prince 5(4) tableau -- scipy rk.py:377-404
+ * ------------------------------------------------------------------------------------- */
+/* C (stage abscissae) is not needed: the RHS is autonomous */
+static const double A_[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+static const double B_[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+static const double E_[7] = {-71.0 / 57600, 0,           71.0 / 16695, -71.0 / 1920,
+                             17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+static const double P_[7][4] = {
+    {1, -8048581381.0 / 2820520608.0, 8663915743.0 / 2820520608.0, -12715105075.0 / 11282082432.0},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799.0, -68118460800.0 / 10900136933.0, 87487479700.0 / 32700410799.0},
+    {0, -1754552775.0 / 470086768.0, 14199869525.0 / 1410260304.0, -10690763975.0 / 1880347072.0},
+    {0, 127303824393.0 / 49829197408.0, -318862633887.0 / 49829197408.0, 701980252875.0 / 199316789632.0},
+    {0, -282668133.0 / 205662961.0, 2019193451.0 / 616988883.0, -1453857185.0 / 822651844.0},
+    {0, 40617522.0 / 29380423.0, -110615467.0 / 29380423.0, 69997945.0 / 29380423.0}};
+
+#define SAFETY 0.9
+#define MIN_FACTOR 0.2
+#define MAX_FACTOR 10.0
+
+/* RMS norm -- common.py:63-65 */
+static double rms6(const double v[6])
+{
+    double s = 0.0;
+    for (int i = 0; i < 6; i++) s += v[i] * v[i];
+    return sqrt(s) / sqrt(6.0);
+}
+
+/* common.py:68-134 */
+static double select_initial_step(const bhgo_params *p, const double y0[6], const double f0[6],
+                                  double t0, double t_bound, uint32_t *nfev)
+{
+    const int order = 4; /* error_estimator_order, rk.py:96-98 */
+    double interval_length = fabs(t_bound - t0);
+    if (interval_length == 0.0) return 0.0;
+    double scale[6], v[6];
+    for (int i = 0; i < 6; i++) scale[i] = p->atol + fabs(y0[i]) * p->rtol;
+    for (int i = 0; i < 6; i++) v[i] = y0[i] / scale[i];
+    double d0 = rms6(v);
+    for (int i = 0; i < 6; i++) v[i] = f0[i] / scale[i];
+    double d1 = rms6(v);
+    double h0;
+    if (d0 < 1e-5 || d1 < 1e-5)
+        h0 = 1e-6;
+    else
+        h0 = 0.01 * d0 / d1;
+    if (interval_length < h0) h0 = interval_length;
+    double y1[6], f1[6];
+    for (int i = 0; i < 6; i++) y1[i] = y0[i] + h0 * f0[i];
+    rhs(p, y1, f1);
+    (*nfev)++;
+    for (int i = 0; i < 6; i++) v[i] = (f1[i] - f0[i]) / scale[i];
+    double d2 = rms6(v) / h0;
+    double h1;
+    if (d1 <= 1e-15 && d2 <= 1e-15) {
+        h1 = h0 * 1e-3;
+        if (h1 < 1e-6) h1 = 1e-6;
+    } else {
+        double dm = d1 > d2 ? d1 : d2;
+        h1 = pow(0.01 / dm, 1.0 / (order + 1));
+    }
+    double h = 100 * h0;
+    if (h1 < h) h = h1;
+    if (interval_length < h) h = interval_length;
+    if (p->max_step < h) h = p->max_step;
+    return h;
+}
+
+/* rk.py:14-71 */
+static void rk_step(const bhgo_params *p, const double y[6], const double f[6], double h,
+                    double K[7][6], double y_new[6], double f_new[6])
+{
+    memcpy(K[0], f, sizeof(double) * 6);
+    for (int s = 1; s < 6; s++) {
+        double ys[6];
+        for (int i = 0; i < 6; i++) {
+            double dot = 0.0;
+            for (int j = 0; j < s; j++) dot += K[j][i] * A_[s][j];
+            ys[i] = y[i] + dot * h;
+        }
+        rhs(p, ys, K[s]);
+    }
+    for (int i = 0; i < 6; i++) {
+        double dot = 0.0;
+        for (int j = 0; j < 6; j++) dot += K[j][i] * B_[j];
+        y_new[i] = y[i] + h * dot;
+    }
+    rhs(p, y_new, f_new);
+    memcpy(K[6], f_new, sizeof(double) * 6);
+}
+
+/* rk.py:552-574 with Q = K^T P (rk.py:176-178) */
+typedef struct {
+    double t_old, h;
+    double y_old[6];
+    double Q[6][4];
+} dense_t;
+
+static void dense_build(dense_t *d, double t_old, double t, const double y_old[6], double K[7][6])
+{
+    d->t_old = t_old;
+    d->h = t - t_old;
+    memcpy(d->y_old, y_old, sizeof(double) * 6);
+    for (int i = 0; i < 6; i++)
+        for (int m = 0; m < 4; m++) {
+            double s = 0.0;
+            for (int j = 0; j < 7; j++) s += K[j][i] * P_[j][m];
+            d->Q[i][m] = s;
+        }
+}
+
+static void dense_eval(const dense_t *d, double t, double y[6])
+{
+    double x = (t - d->t_old) / d->h;
+    double pw[4];
+    pw[0] = x;
+    for (int m = 1; m < 4; m++) pw[m] = pw[m - 1] * x;
+    for (int i = 0; i < 6; i++) {
+        double s = 0.0;
+        for (int m = 0; m < 4; m++) s += d->Q[i][m] * pw[m];
+        y[i] = d->h * s + d->y_old[i];
+    }
+}
+
+/* Hermite cubic used only by the fixed-step RK4 mode (scipy has no RK4; this mode is the
+   build's own "R-fine" regime) */
+typedef struct {
+    double t_old, h;
+    double y0[6], y1[6], f0[6], f1[6];
+} hermite_t;
+
+static void hermite_eval(const hermite_t *d, double t, double y[6])
+{
+    double s = (t - d->t_old) / d->h;
+    double s2 = s * s, s3 = s2 * s;
+    double h00 = 2 * s3 - 3 * s2 + 1, h10 = s3 - 2 * s2 + s, h01 = -2 * s3 + 3 * s2, h11 = s3 - s2;
+    for (int i = 0; i < 6; i++)
+        y[i] = h00 * d->y0[i] + h10 * d->h * d->f0[i] + h01 * d->y1[i] + h11 * d->h * d->f1[i];
+}
+
+/* event function g(t) = r(y(t)) - R evaluated through an interpolant */
+typedef struct {
+    int kind; /* 0 dense (DP54), 1 hermite (RK4) */
+    const dense_t *dn;
+    const hermite_t *hm;
+    double R;
+} evfun_t;
+
+static double ev_eval(const evfun_t *e, double t)
+{
+    double y[6];
+    if (e->kind == 0)
+        dense_eval(e->dn, t, y);
+    else
+        hermite_eval(e->hm, t, y);
+    return radius(y) - e->R;
+}
+
+/* Brent's method as scipy.optimize.brentq runs it (xtol = rtol = 4 eps, ivp.py:74-75) */
+static double brentq(const evfun_t *e, double xa, double xb)
+{
+    const double xtol = 4 * DBL_EPSILON, rtol = 4 * DBL_EPSILON;
+    double xpre = xa, xcur = xb, xblk = 0.0, fblk = 0.0, spre = 0.0, scur = 0.0;
+    double fpre = ev_eval(e, xpre), fcur = ev_eval(e, xcur);
+    if (fpre == 0.0) return xpre;
+    if (fcur == 0.0) return xcur;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0.0 && fcur != 0.0 && (signbit(fpre) != signbit(fcur))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        double delta = (xtol + rtol * fabs(xcur)) / 2;
+        double sbis = (xblk - xcur) / 2;
+        if (fcur == 0.0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            double lim = fabs(spre);
+            double alt = 3 * fabs(sbis) - delta;
+            if (alt < lim) lim = alt;
+            if (2 * fabs(stry) < lim) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0 ? delta : -delta);
+        fcur = ev_eval(e, xcur);
+    }
+    return xcur;
+}
+
+static void pack_end(const double y[6], double end[6])
+{
+    end[0] = y[1];
+    end[1] = y[3];
+    end[2] = y[5];
+    end[3] = y[0];
+    end[4] = y[2];
+    end[5] = y[4];
+}
+
+/* Events after an accepted step (ivp.py:109-126, :673-694).  Both events are terminal; when
+   both fire in one step the earlier root wins (handle_events sorts roots, ivp.py:111-122).
+   Returns 0 = none, else flag bit; *t_root and y_root filled. */
+static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, double g_e,
+                             double g_e_new, const evfun_t *base, double t_old, double t,
+                             double *t_root, double y_root[6])
+{
+    int hor = ((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0));
+    int ext = (p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0); /* direction = +1 */
+    if (!hor && !ext) return 0;
+    double rh = 0, re = 0;
+    evfun_t e = *base;
+    if (hor) {
+        e.R = p->r_s;
+        rh = brentq(&e, t_old, t);
+    }
+    if (ext) {
+        e.R = p->r_exit;
+        re = brentq(&e, t_old, t);
+    }
+    uint32_t flag;
+    if (hor && (!ext || rh <= re)) {
+        *t_root = rh;
+        flag = BHGO_FLAG_HIT_HORIZON;
+    } else {
+        *t_root = re;
+        flag = BHGO_FLAG_EXITED_SPHERE;
+    }
+    if (e.kind == 0)
+        dense_eval(e.dn, *t_root, y_root);
+    else
+        hermite_eval(e.hm, *t_root, y_root);
+    return flag;
+}
+
+typedef struct {
+    double end[6];
+    double t_end;
+    uint32_t flags, n_attempted, n_accepted, nfev;
+} ray_result;
+
+/* ---------------------------------------------------------------------------------------
+ * One ray, adaptive DP5(4): RungeKutta.__init__ (rk.py:84-104) + solve_ivp loop
+ * (ivp.py:654-723) + _step_impl (rk.py:111-176)
+ * ------------------------------------------------------------------------------------- */
+static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+{
+    double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
+    double f[6], K[7][6], y_new[6], f_new[6];
+    const double t_bound = p->lambda_end;
+    double t = 0.0;
+    memset(res, 0, sizeof(*res));
+    rhs(p, y, f);
+    res->nfev = 1;
+    double h_abs = select_initial_step(p, y, f, t, t_bound, &res->nfev);
+    double g_h = radius(y) - p->r_s;
+    double g_e = radius(y) - p->r_exit;
+    const uint32_t cap = p->max_steps ? p->max_steps : 0xFFFFFFFFu;
+
+    for (;;) {
+        if (t == t_bound) { /* base.py:189-194 */
+            res->flags |= BHGO_FLAG_REACHED_END;
+            break;
+        }
+        double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+        if (h_abs > p->max_step)
+            h_abs = p->max_step;
+        else if (h_abs < min_step)
+            h_abs = min_step;
+        int step_rejected = 0, failed = 0;
+        double h, t_new;
+        for (;;) {
+            if (h_abs < min_step) {
+                failed = BHGO_FLAG_STEP_TOO_SMALL;
+                break;
+            }
+            if (res->n_attempted >= cap) {
+                failed = BHGO_FLAG_MAX_STEPS;
+                break;
+            }
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t_bound > 0) t_new = t_bound;
+            h = t_new - t;
+            h_abs = fabs(h);
+            rk_step(p, y, f, h, K, y_new, f_new);
+            res->nfev += 6;
+            res->n_attempted++;
+            double ev[6];
+            for (int i = 0; i < 6; i++) {
+                double ay = fabs(y[i]), an = fabs(y_new[i]);
+                double scale = p->atol + (ay > an ? ay : an) * p->rtol; /* np.maximum: NaN propagates */
+                if (isnan(ay) || isnan(an)) scale = NAN;
+                double dot = 0.0;
+                for (int j = 0; j < 7; j++) dot += K[j][i] * E_[j];
+                ev[i] = dot * h / scale;
+            }
+            double error_norm = rms6(ev);
+            if (error_norm < 1) {
+                double factor;
+                if (error_norm == 0)
+                    factor = MAX_FACTOR;
+                else {
+                    factor = SAFETY * pow(error_norm, -0.2);
+                    if (factor > MAX_FACTOR) factor = MAX_FACTOR;
+                }
+                if (step_rejected && factor > 1) factor = 1;
+                h_abs *= factor;
+                break;
+            } else {
+                double fac = SAFETY * pow(error_norm, -0.2);
+                /* python max(MIN_FACTOR, nan) == MIN_FACTOR */
+                if (!(fac > MIN_FACTOR)) fac = MIN_FACTOR;
+                h_abs *= fac;
+                step_rejected = 1;
+            }
+        }
+        if (failed) {
+            res->flags |= (uint32_t)failed;
+            break;
+        }
+        double t_old = t;
+        double y_old[6];
+        memcpy(y_old, y, sizeof(y));
+        t = t_new;
+        memcpy(y, y_new, sizeof(y));
+        memcpy(f, f_new, sizeof(f));
+        res->n_accepted++;
+
+        double g_h_new = radius(y) - p->r_s;
+        double g_e_new = radius(y) - p->r_exit;
+        dense_t dn;
+        evfun_t base = {0, &dn, NULL, 0.0};
+        int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
+                  ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0));
+        if (any) {
+            dense_build(&dn, t_old, t, y_old, K);
+            double t_root, y_root[6];
+            uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, &base, t_old, t, &t_root, y_root);
+            if (fl) {
+                res->flags |= fl;
+                t = t_root;
+                memcpy(y, y_root, sizeof(y));
+                break;
+            }
+        }
+        g_h = g_h_new;
+        g_e = g_e_new;
+        if (t - t_bound >= 0) { /* base.py:203-204 */
+            res->flags |= BHGO_FLAG_REACHED_END;
+            break;
+        }
+    }
+    int bad = 0;
+    for (int i = 0; i < 6; i++) bad |= !isfinite(y[i]);
+    if (bad) res->flags |= BHGO_FLAG_NAN;
+    pack_end(y, res->end);
+    res->t_end = t;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * One ray, classic fixed-step RK4 (the build's own "R-fine" regime; not a scipy method)
+ * ------------------------------------------------------------------------------------- */
+static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+{
+    double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
+    double f[6];
+    const double t_bound = p->lambda_end;
+    double t = 0.0;
+    memset(res, 0, sizeof(*res));
+    rhs(p, y, f);
+    res->nfev = 1;
+    double g_h = radius(y) - p->r_s;
+    double g_e = radius(y) - p->r_exit;
+    const uint32_t cap = p->max_steps ? p->max_steps : 0xFFFFFFFFu;
+    for (;;) {
+        if (t >= t_bound) {
+            res->flags |= BHGO_FLAG_REACHED_END;
+            break;
+        }
+        if (res->n_attempted >= cap) {
+            res->flags |= BHGO_FLAG_MAX_STEPS;
+            break;
+        }
+        double h = p->h_fixed;
+        double t_new = t + h;
+        if (t_new - t_bound > 0) t_new = t_bound;
+        h = t_new - t;
+        double k2[6], k3[6], k4[6], ys[6], y_new[6], f_new[6];
+        for (int i = 0; i < 6; i++) ys[i] = y[i] + (0.5 * h) * f[i];
+        rhs(p, ys, k2);
+        for (int i = 0; i < 6; i++) ys[i] = y[i] + (0.5 * h) * k2[i];
+        rhs(p, ys, k3);
+        for (int i = 0; i < 6; i++) ys[i] = y[i] + h * k3[i];
+        rhs(p, ys, k4);
+        for (int i = 0; i < 6; i++) y_new[i] = y[i] + (h / 6.0) * (f[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        rhs(p, y_new, f_new);
+        res->nfev += 4;
+        res->n_attempted++;
+        res->n_accepted++;
+        hermite_t hm;
+        hm.t_old = t;
+        hm.h = h;
+        memcpy(hm.y0, y, sizeof(y));
+        memcpy(hm.y1, y_new, sizeof(y));
+        memcpy(hm.f0, f, sizeof(f));
+        memcpy(hm.f1, f_new, sizeof(f));
+        double t_old = t;
+        t = t_new;
+        memcpy(y, y_new, sizeof(y));
+        memcpy(f, f_new, sizeof(f));
+        double g_h_new = radius(y) - p->r_s;
+        double g_e_new = radius(y) - p->r_exit;
+        evfun_t base = {1, NULL, &hm, 0.0};
+        double t_root, y_root[6];
+        uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, &base, t_old, t, &t_root, y_root);
+        if (fl) {
+            res->flags |= fl;
+            t = t_root;
+            memcpy(y, y_root, sizeof(y));
+            break;
+        }
+        g_h = g_h_new;
+        g_e = g_e_new;
+        int bad = 0;
+        for (int i = 0; i < 6; i++) bad |= !isfinite(y[i]);
+        if (bad) break;
+    }
+    int bad = 0;
+    for (int i = 0; i < 6; i++) bad |= !isfinite(y[i]);
+    if (bad) res->flags |= BHGO_FLAG_NAN;
+    pack_end(y, res->end);
+    res->t_end = t;
+}
+
+static void trace_one(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+{
+    double r0 = sqrt(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]);
+    if (r0 <= p->r_s) {
+        /* 'start_inside_hole' -> (False, True, [], []) at RelativisticRenderEngine.py:311-313 */
+        memset(res, 0, sizeof(*res));
+        res->flags = BHGO_FLAG_START_INSIDE | BHGO_FLAG_HIT_HORIZON;
+        res->end[0] = x0[0];
+        res->end[1] = x0[1];
+        res->end[2] = x0[2];
+        res->end[3] = k0[0];
+        res->end[4] = k0[1];
+        res->end[5] = k0[2];
+        return;
+    }
+    if (p->method == BHGO_METHOD_RK4)
+        trace_rk4(p, x0, k0, res);
+    else
+        trace_dp54(p, x0, k0, res);
+}
+
+/* ---------------------------------------------------------------------------------------
+ * Public entry points (C ABI, called through ctypes from oracle/oracle.py)
+ * ------------------------------------------------------------------------------------- */
+int bhgo_abi_version(void) { return 1; }
+
+int bhgo_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* k0: [n][3]; x0: [3] if x0_shared else [n][3]; end: [n][6]; any of flags/n_attempted/
+   n_accepted/t_end may be NULL.  n_threads <= 0 -> OpenMP default. */
+int bhgo_trace(const bhgo_params *p, const double *x0, int x0_shared, const double *k0, size_t n,
+               double *end, uint8_t *flags, uint32_t *n_attempted, uint32_t *n_accepted,
+               double *t_end, int n_threads)
+{
+    if (!p || !x0 || !k0 || !end) return -1;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    long long nn = (long long)n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads)
+    for (long long i = 0; i < nn; i++) {
+        ray_result r;
+        const double *xi = x0_shared ? x0 : x0 + 3 * i;
+        trace_one(p, xi, k0 + 3 * i, &r);
+        memcpy(end + 6 * i, r.end, sizeof(double) * 6);
+        if (flags) flags[i] = (uint8_t)r.flags;
+        if (n_attempted) n_attempted[i] = r.n_attempted;
+        if (n_accepted) n_accepted[i] = r.n_accepted;
+        if (t_end) t_end[i] = r.t_end;
+    }
+    return 0;
+}
+
+/* RHS probe for tests: acc[n][3] from x[n][3], k[n][3] */
+int bhgo_acceleration(const bhgo_params *p, const double *x, const double *k, size_t n, double *acc)
+{
+    for (size_t i = 0; i < n; i++) {
+        if (p->rhs_form == BHGO_RHS_REDUCED)
+            acc_reduced(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);
+        else
+            acc_christoffel(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);
+    }
+    return 0;
+}

@@ -1,0 +1,242 @@
+"""scipy/sympy-driven restatement of the reference's per-ray geodesic solve.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this file; it is used
+by tests/, by tests/golden/make_golden.py (the fixture generator) and nowhere else.
+
+PARITY UNPINNED: the reference tree (bldevries/blackhole_geodesic_calculator) holds no
+solver arithmetic, no tests and no golden vectors for this path.  The arithmetic lives in
+the un-vendored, un-pinned third-party package ``curvedpy`` (reference README.md:23-24,
+README.md:93; import at raytracer/RelativisticRenderEngine.py:7), which is not installable
+here.  What this file follows instead, line by line:
+
+* the ODE  dk^a/dl = -Gamma^a_{mu nu} k^mu k^nu,  dx^b/dl = k^b        (README.md:198-209)
+* the Schwarzschild metric, used "in cartesian coordinates"            (README.md:162-174)
+* Christoffel symbols "calculated using sympy"                         (README.md:133-135, :182-184)
+* integrator = scipy.integrate.solve_ivp                               (README.md:196)
+* null rays (time_like=False), horizon radius r_s = 2*mass             (raytracer/RelativisticRenderEngine.py:95, :134)
+* state rows ordered k_x, x, k_y, y, k_z, z                            (raytracer/RelativisticRenderEngine.py:281, :301)
+* call signature / what is consumed: last sample + 'hit_blackhole'     (raytracer/RelativisticRenderEngine.py:293-313)
+
+scipy (1.15.3 here) *is* the third-party arithmetic for the RK update, so the C restatement
+in oracle/geodesic_oracle.c is checked step-for-step against ``solve_ivp`` driven from here.
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+from scipy.integrate import solve_ivp
+
+# state layout used by the reference's solver (RelativisticRenderEngine.py:301)
+#   y = [k_x, x, k_y, y, k_z, z]
+IK = (0, 2, 4)
+IX = (1, 3, 5)
+
+
+# --------------------------------------------------------------------------------------
+# RHS form 1: generic sympy derivation (what README.md:176-184 describes)
+# --------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=4)
+def sympy_christoffel_rhs():
+    """Derive -Gamma^i_{mu nu} k^mu k^nu for the Cartesian Schwarzschild metric with sympy.
+
+    Returns a numpy-lambdified function acc(x, y, z, kx, ky, kz, r_s) -> (ax, ay, az) with
+    k^t eliminated through the null condition g_{mu nu} k^mu k^nu = 0 (time_like=False,
+    RelativisticRenderEngine.py:134).  No hand simplification is applied: the expression
+    is the raw contraction, common sub-expressions shared by ``cse`` only.
+    """
+    import sympy as sp
+
+    t, x, y, z, rs = sp.symbols("t x y z r_s", real=True)
+    kt, kx, ky, kz = sp.symbols("k_t k_x k_y k_z", real=True)
+    X = [t, x, y, z]
+    K = [kt, kx, ky, kz]
+    r = sp.sqrt(x * x + y * y + z * z)
+    f = 1 - rs / r
+    n = [x / r, y / r, z / r]
+    g = sp.zeros(4, 4)
+    g[0, 0] = -f
+    for i in range(3):
+        for j in range(3):
+            g[i + 1, j + 1] = (1 if i == j else 0) + (rs / (r - rs)) * n[i] * n[j]
+    ginv = sp.zeros(4, 4)
+    ginv[0, 0] = 1 / g[0, 0]
+    g3 = g[1:, 1:]
+    # symbolic 3x3 inverse by adjugate/determinant, not simplified (the default Gaussian
+    # elimination spends minutes zero-testing pivots that contain sqrt)
+    ginv[1:, 1:] = g3.adjugate() / g3.det(method="berkowitz")
+    dg = [[[sp.diff(g[a, b], X[c]) for c in range(4)] for b in range(4)] for a in range(4)]
+
+    def gamma(s, m, nu):
+        return sp.Rational(1, 2) * sum(
+            ginv[s, rho] * (dg[nu][rho][m] + dg[rho][m][nu] - dg[m][nu][rho]) for rho in range(4)
+        )
+
+    # null condition -> (k^t)^2, kept as one shared sub-expression
+    kt2 = sum(g[i, j] * K[i] * K[j] for i in range(1, 4) for j in range(1, 4)) / f
+    acc = []
+    for i in range(1, 4):
+        expr = 0
+        for m in range(4):
+            for nu in range(4):
+                gam = gamma(i, m, nu)
+                if gam == 0:
+                    continue
+                if (m == 0) != (nu == 0):
+                    # static, diagonal-in-t metric: Gamma^i_{t j} is structurally zero
+                    raise AssertionError("unexpected non-zero Gamma^i_{tj}")
+                kk = kt2 if (m == 0 and nu == 0) else K[m] * K[nu]
+                expr -= gam * kk
+        acc.append(expr)
+    fn = sp.lambdify((x, y, z, kx, ky, kz, rs), acc, modules="numpy", cse=True)
+    return fn
+
+
+# --------------------------------------------------------------------------------------
+# RHS form 2/3: hand-reduced forms, numpy scalar arithmetic
+# --------------------------------------------------------------------------------------
+def acc_christoffel(x, k, r_s):
+    """a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ]."""
+    r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2]
+    r = np.sqrt(r2)
+    nk = (x[0] * k[0] + x[1] * k[1] + x[2] * k[2]) / r
+    kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2]
+    f = 1.0 - r_s / r
+    fp = r_s / r2
+    h = r_s / (r - r_s)
+    hp = -r_s / ((r - r_s) * (r - r_s))
+    kt2 = (kk + h * nk * nk) / f
+    s = 0.5 * f * fp * kt2 + 0.5 * f * hp * nk * nk + (r_s / r2) * (kk - nk * nk)
+    c = -s / r
+    return np.array([c * x[0], c * x[1], c * x[2]])
+
+
+def acc_reduced(x, k, r_s):
+    """a = -(3/2) r_s |x cross k|^2 x / r^5, L^2 recomputed from the current state."""
+    r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2]
+    kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2]
+    xk = x[0] * k[0] + x[1] * k[1] + x[2] * k[2]
+    L2 = r2 * kk - xk * xk
+    c = -1.5 * r_s * L2 / (r2 * r2 * np.sqrt(r2))
+    return np.array([c * x[0], c * x[1], c * x[2]])
+
+
+def make_rhs(r_s, form="christoffel"):
+    """RHS f(t, y) on the 6-D state [k_x, x, k_y, y, k_z, z]."""
+    if form == "sympy":
+        fn = sympy_christoffel_rhs()
+
+        def rhs(_t, y):
+            a = fn(y[1], y[3], y[5], y[0], y[2], y[4], r_s)
+            return np.array([a[0], y[0], a[1], y[2], a[2], y[4]], dtype=float)
+
+    else:
+        acc = {"christoffel": acc_christoffel, "reduced": acc_reduced}[form]
+
+        def rhs(_t, y):
+            a = acc((y[1], y[3], y[5]), (y[0], y[2], y[4]), r_s)
+            return np.array([a[0], y[0], a[1], y[2], a[2], y[4]])
+
+    return rhs
+
+
+# --------------------------------------------------------------------------------------
+# The per-ray solve (what calc_trajectory does, RelativisticRenderEngine.py:293-313)
+# --------------------------------------------------------------------------------------
+FLAG_HIT_HORIZON = 1
+FLAG_START_INSIDE = 2
+FLAG_REACHED_END = 4
+FLAG_EXITED_SPHERE = 8
+FLAG_MAX_STEPS = 16
+FLAG_STEP_TOO_SMALL = 32
+FLAG_NAN = 64
+
+
+def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
+              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None):
+    """Integrate one null geodesic with scipy.solve_ivp; returns a dict.
+
+    Events: horizon r - r_s = 0 (terminal, any direction); optional outward sphere exit
+    r - r_exit = 0 (terminal, direction +1) as the Limited engine's ray_trace does
+    (LimitedRelativisticRenderEngine.py:273-278).
+    """
+    k0 = np.asarray(k0, float)
+    x0 = np.asarray(x0, float)
+    out = {"nfev": 0, "n_accepted": 0, "n_attempted": 0, "t_end": 0.0}
+    if np.sqrt(np.dot(x0, x0)) <= r_s:
+        out.update(flags=FLAG_START_INSIDE | FLAG_HIT_HORIZON, end=np.concatenate([x0, k0]))
+        return out
+    y0 = np.array([k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]])
+
+    def ev_horizon(_t, y):
+        return np.sqrt(y[1] * y[1] + y[3] * y[3] + y[5] * y[5]) - r_s
+
+    ev_horizon.terminal = True
+    events = [ev_horizon]
+    if r_exit > 0.0:
+        def ev_exit(_t, y):
+            return np.sqrt(y[1] * y[1] + y[3] * y[3] + y[5] * y[5]) - r_exit
+
+        ev_exit.terminal = True
+        ev_exit.direction = 1.0
+        events.append(ev_exit)
+    t_eval = None
+    if nr_points_curve:
+        t_eval = np.linspace(0.0, lambda_end, nr_points_curve)
+    sol = solve_ivp(make_rhs(r_s, form), (0.0, lambda_end), y0, method=method, events=events,
+                    max_step=max_step, rtol=rtol, atol=atol, t_eval=t_eval)
+    flags = 0
+    if sol.status == 1:
+        if len(sol.t_events[0]) > 0:
+            flags |= FLAG_HIT_HORIZON
+            te, ye = sol.t_events[0][-1], sol.y_events[0][-1]
+        else:
+            flags |= FLAG_EXITED_SPHERE
+            te, ye = sol.t_events[1][-1], sol.y_events[1][-1]
+    elif sol.status == 0:
+        flags |= FLAG_REACHED_END
+        te, ye = (sol.t[-1], sol.y[:, -1]) if t_eval is None else (lambda_end, None)
+    else:
+        flags |= FLAG_STEP_TOO_SMALL
+        te, ye = (sol.t[-1], sol.y[:, -1])
+    if ye is None:  # t_eval path: last grid point == lambda_end
+        ye = sol.y[:, -1]
+    out.update(
+        flags=flags,
+        end=np.array([ye[1], ye[3], ye[5], ye[0], ye[2], ye[4]]),
+        t_end=float(te),
+        nfev=int(sol.nfev),
+        n_attempted=(int(sol.nfev) - 2) // 6 if method == "RK45" else -1,
+        n_accepted=(len(sol.t) - 1) if t_eval is None else -1,
+        sol=sol,
+    )
+    return out
+
+
+def trace_rays(k0, x0, **kw):
+    """Loop trace_ray over k0[N,3]; x0 is [3] (shared) or [N,3]."""
+    k0 = np.atleast_2d(np.asarray(k0, float))
+    x0 = np.asarray(x0, float)
+    n = k0.shape[0]
+    end = np.zeros((n, 6))
+    flags = np.zeros(n, np.uint8)
+    natt = np.zeros(n, np.uint32)
+    nacc = np.zeros(n, np.uint32)
+    tend = np.zeros(n)
+    for i in range(n):
+        xi = x0 if x0.ndim == 1 else x0[i]
+        r = trace_ray(k0[i], xi, **kw)
+        end[i] = r["end"]
+        flags[i] = r["flags"]
+        natt[i] = max(r["n_attempted"], 0)
+        nacc[i] = max(r["n_accepted"], 0)
+        tend[i] = r["t_end"]
+    return {"end": end, "flags": flags, "n_attempted": natt, "n_accepted": nacc, "t_end": tend}
+
+
+# --------------------------------------------------------------------------------------
+# Converged solve for physics known-answer tests
+# --------------------------------------------------------------------------------------
+def trace_ray_converged(k0, x0, r_s=1.0, lambda_end=50.0, form="reduced"):
+    return trace_ray(k0, x0, r_s=r_s, lambda_end=lambda_end, rtol=1e-12, atol=1e-14,
+                     form=form, method="DOP853")

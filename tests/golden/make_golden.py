@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ (run in the build container).
+
+The reference's own arithmetic (curvedpy) is not available, so these vectors come from the
+scipy/sympy restatement in oracle/scipy_reference.py -- i.e. from scipy.integrate.solve_ivp
+(the integrator README.md:196 names) applied to the README's ODE (README.md:198-209) with
+the call-site parameters of raytracer/RelativisticRenderEngine.py:134, :293-294.  They pin
+the C oracle (oracle/geodesic_oracle.c) and, through it, the HIP path.  PARITY UNPINNED with
+respect to curvedpy itself (see oracle/geodesic_oracle.c header).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Needs numpy, scipy, sympy only.  Takes about two minutes on one core.
+"""
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import scipy_reference as sr  # noqa: E402
+
+CAM = np.array([1e-4, 0.0, 30.0])  # RelativisticRenderEngineCamEdition.py:216-221 pickle names
+
+
+def euler_xyz_matrix(ax, ay, az):
+    """mathutils Euler order 'XYZ' (to_euler() default): rotate about X, then Y, then Z."""
+    cx, sx = math.cos(ax), math.sin(ax)
+    cy, sy = math.cos(ay), math.sin(ay)
+    cz, sz = math.cos(az), math.sin(az)
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def reference_ray_loop(width, height, samples, fov_x, fov_y, seed, euler=(0.0, 0.0, 0.0),
+                       mark=None):
+    """Pure-Python restatement of the direction loop, RelativisticRenderEngine.py:185-230.
+
+    Same statement order, same `random` calls, loop order sample -> row -> column, draws only
+    inside the mark window (:199, :219).  Returns directions[S, H, W, 3] (NaN where skipped).
+    """
+    aspectratio = height / width
+    dy = aspectratio / height
+    dx = 1 / width
+    random.seed(seed)
+    rot = euler_xyz_matrix(*euler)
+    y_min, y_max, x_min, x_max = mark if mark else (0, height, 0, width)
+    out = np.full((samples, height, width, 3), np.nan)
+    for s in range(samples):
+        for y in range(height):
+            if y >= y_min and y <= y_max:
+                for x in range(width):
+                    if x >= x_min and x <= x_max:
+                        aspectratio = height / width
+                        x_render = fov_x * (x - int(width / 2)) / width
+                        y_render = fov_y * (y - int(height / 2)) / height * aspectratio
+                        d = np.array([x_render + dx * (random.random() - 0.5),
+                                      y_render + dy * (random.random() - 0.5), -1.0])
+                        d = rot @ d
+                        d = d / math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+                        out[s, y, x] = d
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+def pack(res):
+    return dict(end=res["end"], flags=res["flags"], n_attempted=res["n_attempted"],
+                n_accepted=res["n_accepted"], t_end=res["t_end"])
+
+
+def main():
+    # ---- 1. config 1: 64x64x1 frame, default controller -------------------------------
+    dirs = reference_ray_loop(64, 64, 1, 0.6, 0.6, 42.0)
+    k0 = dirs.reshape(-1, 3)
+    res = sr.trace_rays(k0, CAM, r_s=1.0, lambda_end=50.0, form="christoffel")
+    save("frame64_christoffel", k0=k0, x0=CAM, r_s=1.0, lambda_end=50.0, max_step=np.inf,
+         rtol=1e-3, atol=1e-6, **pack(res))
+    res = sr.trace_rays(k0, CAM, r_s=1.0, lambda_end=50.0, form="reduced")
+    save("frame64_reduced", k0=k0, x0=CAM, r_s=1.0, lambda_end=50.0, max_step=np.inf,
+         rtol=1e-3, atol=1e-6, **pack(res))
+
+    # ---- 2. generic sympy contraction on a strided subset -----------------------------
+    sub = k0[::16]
+    res = sr.trace_rays(sub, CAM, r_s=1.0, lambda_end=50.0, form="sympy")
+    save("frame64_sympy_subset", k0=sub, x0=CAM, r_s=1.0, lambda_end=50.0, max_step=np.inf,
+         rtol=1e-3, atol=1e-6, **pack(res))
+
+    # ---- 3. ray generation (a7): small frames incl. rotation, non-square, mark window --
+    save("raygen",
+         d_8x6x2=reference_ray_loop(8, 6, 2, 0.6, 0.45, 42.0),
+         d_5x7x3_rot=reference_ray_loop(5, 7, 3, 1.0, 1.0, 7.0, euler=(0.3, -0.2, 1.1)),
+         d_6x6x2_mark=reference_ray_loop(6, 6, 2, 0.6, 0.6, 42.0, mark=(1, 4, 2, 3)),
+         first_draws=np.array([(random.seed(42.0), [random.random() for _ in range(8)])[1]][0]))
+
+    # ---- 4. fine regime: max_step = 0.1 (CamEdition.py:216 pickle name) ---------------
+    fine = k0[:: 64 * 4 + 3][:24]
+    res = sr.trace_rays(fine, CAM, r_s=1.0, lambda_end=50.0, max_step=0.1, form="christoffel")
+    save("fine_maxstep01", k0=fine, x0=CAM, r_s=1.0, lambda_end=50.0, max_step=0.1,
+         rtol=1e-3, atol=1e-6, **pack(res))
+
+    # ---- 5. Fig. 5 geometry (README.md:68-70): x0 = -15 r_s, y0 = 3..19, k = (1,0,0) ---
+    y0s = np.arange(3.0, 20.0)
+    x0s = np.stack([-15.0 * np.ones_like(y0s), y0s, np.zeros_like(y0s)], 1)
+    kf = np.tile(np.array([1.0, 0.0, 0.0]), (len(y0s), 1))
+    res = sr.trace_rays(kf, x0s, r_s=1.0, lambda_end=60.0, form="christoffel")
+    defl = []
+    for i in range(len(y0s)):
+        c = sr.trace_ray(kf[i], x0s[i], r_s=1.0, lambda_end=4000.0, rtol=1e-12, atol=1e-14,
+                         form="reduced", method="DOP853")
+        kx, ky = c["end"][3], c["end"][4]
+        defl.append(math.degrees(math.atan2(-ky, kx)))
+    save("fig5", k0=kf, x0=x0s, r_s=1.0, lambda_end=60.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
+         deflection_deg_converged=np.array(defl), **pack(res))
+
+    # ---- 6. capture threshold b_c = 3 sqrt(3)/2 r_s -----------------------------------
+    bs = np.array([2.40, 2.55, 2.59, 2.60, 2.61, 2.65, 2.80])
+    xs = np.stack([-40.0 * np.ones_like(bs), bs, np.zeros_like(bs)], 1)
+    kc = np.tile(np.array([1.0, 0.0, 0.0]), (len(bs), 1))
+    hit = []
+    for i in range(len(bs)):
+        c = sr.trace_ray(kc[i], xs[i], r_s=1.0, lambda_end=200.0, rtol=1e-11, atol=1e-13,
+                         form="reduced", method="DOP853")
+        hit.append(c["flags"] & 1)
+    res = sr.trace_rays(kc, xs, r_s=1.0, lambda_end=200.0, rtol=1e-8, atol=1e-10, form="christoffel")
+    save("capture", k0=kc, x0=xs, r_s=1.0, lambda_end=200.0, max_step=np.inf, rtol=1e-8,
+         atol=1e-10, hit_converged=np.array(hit, np.uint8), **pack(res))
+
+    # ---- 7. sphere exit (Limited engine: ratio 30, curve_end heuristic :277-279) -------
+    rng = np.random.default_rng(5)
+    n = 48
+    pos = rng.normal(size=(n, 3))
+    pos = 30.0 * pos / np.linalg.norm(pos, axis=1)[:, None]
+    aim = rng.normal(size=(n, 3)) * 4.0  # aim near the hole
+    dirs_in = aim - pos
+    dirs_in /= np.linalg.norm(dirs_in, axis=1)[:, None]
+    lam = 50 + 2 * 50 * (30 / 20 - 1)
+    res = sr.trace_rays(dirs_in, pos, r_s=1.0, lambda_end=lam, r_exit=30.0, form="christoffel")
+    save("sphere_exit", k0=dirs_in, x0=pos, r_s=1.0, lambda_end=lam, max_step=np.inf, rtol=1e-3,
+         atol=1e-6, r_exit=30.0, **pack(res))
+
+    # ---- 8. other masses / off-centre hole (bh_loc subtraction, :278) ------------------
+    k8 = k0[5::97][:40]
+    res = sr.trace_rays(k8, np.array([3.0, -2.0, 45.0]), r_s=2.5, lambda_end=80.0, form="christoffel")
+    save("mass_1p25", k0=k8, x0=np.array([3.0, -2.0, 45.0]), r_s=2.5, lambda_end=80.0,
+         max_step=np.inf, rtol=1e-3, atol=1e-6, **pack(res))
+
+
+if __name__ == "__main__":
+    main()
