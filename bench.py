@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- the null-geodesic hot path on BASELINE.json's headline workload.
+
+A "step" is one pass of the hot path over one frame's worth of rays per GPU: 1024 x 1024 pixels
+x 5 samples = 5,242,880 null geodesics (BASELINE.json config 2; camera (1e-4, 0, 30), fov 0.6,
+mass 0.5 -> r_s = 1, curve_end 50, directions from the reference's pinhole + MT19937 jitter,
+raytracer/RelativisticRenderEngine.py:185-230, seed 42).  Inputs are resident in HBM when the
+timed region starts; the timed region is trace (+ per-pixel reduce) and, for N > 1, the single
+gather of per-pixel results to rank 0.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): WEAK scaling -- the frame
+grows to (1024*nx) x (1024*ny), nx*ny = N, same field of view, so every rank still traces
+5,242,880 rays of the same distribution; 32x32-pixel tiles are dealt round-robin to ranks.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic flop per attempted ray-step: 6 RHS x 44 + 390 bookkeeping
+FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468,
+                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130}
+PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--regime", choices=["adaptive", "fine", "rk4"], default="adaptive",
+                    help="adaptive: DP5(4) rtol 1e-3 atol 1e-6 max_step inf (engine + scipy defaults); "
+                         "fine: same with max_step 0.1; rk4: fixed step 0.1")
+    ap.add_argument("--rhs", choices=["christoffel", "reduced"], default="christoffel")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time (0 = skip)")
+    return ap.parse_args()
+
+
+def grid_for(n):
+    nx = n
+    ny = 1
+    while nx % 2 == 0 and nx // 2 >= ny * 2:
+        nx //= 2
+        ny *= 2
+    return nx, ny
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd import dist as bdist
+    from blackhole_geodesic_calculator_amd.raygen import camera_directions_for_pixels, python_random_stream
+
+    ctx = _ffi.Context(local_rank)
+    nx, ny = grid_for(world)
+    W, H, S = a.width * nx, a.height * ny, a.samples
+    cam = np.array([1e-4, 0.0, 30.0])
+    method = "rk4" if a.regime == "rk4" else "dp54"
+    params = _ffi.make_params(
+        r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
+        h_fixed=0.1, method=_ffi.METHOD_RK4 if method == "rk4" else _ffi.METHOD_DP54,
+        rhs_form=_ffi.RHS_REDUCED if a.rhs == "reduced" else _ffi.RHS_CHRISTOFFEL)
+
+    # ---- synthetic input: this rank's tiles of the frame, all samples of a pixel together ----
+    pixels = bdist.rank_pixels(W, H, a.tile, rank, world)
+    stream = python_random_stream(42.0, 2 * S * W * H)
+    k0 = camera_directions_for_pixels(W, H, S, pixels, 0.6, 0.6, 42.0, stream=stream)  # [S, P, 3]
+    del stream
+    k0 = np.ascontiguousarray(k0.reshape(-1, 3))
+    n = k0.shape[0]
+    P = len(pixels)
+    dk = torch.from_numpy(k0).cuda()
+    dend = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+    dfl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    dac = torch.empty(n, dtype=torch.int32, device="cuda")
+    ts = torch.cuda.current_stream()
+
+    def trace():
+        ctx.trace_device(params, n, dk.data_ptr(), dend.data_ptr(), x0_shared=cam, d_flags=dfl.data_ptr(),
+                         d_n_steps=dst.data_ptr(), d_n_accepted=dac.data_ptr(), stream=ts.cuda_stream)
+
+    def frame_end():
+        # per-pixel result handed to the frame owner: horizon fraction + mean exit direction over the
+        # S samples (what the shading step consumes; reduced on device, 4 doubles per pixel)
+        hit = (dfl.view(S, P) & 1).to(torch.float64).mean(0)
+        dirs = dend.view(S, P, 6)[:, :, 3:6].mean(0)
+        pix = torch.cat([dirs, hit[:, None]], dim=1)
+        if world > 1:
+            return bdist.gather_frame(pix, W, H, a.tile)
+        return pix
+
+    kernel_ms = []
+
+    def step(timed):
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(ts)
+            trace()
+            e1.record(ts)
+            kernel_ms.append((e0, e1))
+        else:
+            trace()
+        return frame_end()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ray_steps = int(dst.to(torch.int64).sum().item())
+    k_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) if kernel_ms else float("nan")
+    tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tot)
+    rays_all, steps_all = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        F = FLOP_PER_STEP[(method, a.rhs)]
+        ms_per_step = dt / a.steps * 1e3
+        achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 Schwarzschild frame per GPU",
+            "value": rays_all / (dt / a.steps) / 1e6,
+            "unit": "Mrays/s",
+            "ray_steps_per_s": steps_all / (dt / a.steps),
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE.json configs[1]: {a.width}x{a.height} x{S} multisample Schwarzschild frame per GPU "
+                            f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50",
+                "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
+                "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
+                "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
+                "tile": a.tile, "frame_end": "per-pixel reduce" + (" + 1 RCCL gather to rank 0" if world > 1 else ""),
+                "launch": ctx.last_launch(),
+            },
+            "roofline": {
+                "bound": "valu_fp64",
+                "kernel": f"trace_{method}_kernel<{a.rhs}>",
+                "achieved": achieved_tf,
+                "peak": PEAK_FP64_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS,
+                "traffic": None,
+                "flop_per_ray_step": F,
+                "ray_steps_per_launch": ray_steps,
+                "kernel_ms": k_ms,
+                "hbm_algorithmic_GBps": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9,
+                "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            },
+        }
+        if a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(k0, cam, a, method)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(k0, cam, a, method):
+    """The C oracle (a port of the algorithm, see oracle/geodesic_oracle.c) timed on this host's
+    cores on a bounded sample of the same rays.  Reported baseline only; never the thing shipped."""
+    from oracle import oracle as oc
+    oc.build()
+    kw = dict(r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
+              h_fixed=0.1, method=1 if method == "rk4" else 0, rhs_form=1 if a.rhs == "reduced" else 0)
+    cores = oc.num_threads()
+    n = len(k0)
+    probe = k0[:: max(1, n // 16384)]
+    t = time.perf_counter()
+    oc.trace(probe, cam, **kw)
+    rate = len(probe) / (time.perf_counter() - t)
+    m = int(min(n, max(len(probe), rate * a.cpu_seconds)))
+    stride = max(1, n // m)
+    sample = np.ascontiguousarray(k0[::stride])
+    t = time.perf_counter()
+    o = oc.trace(sample, cam, **kw)
+    dt = time.perf_counter() - t
+    return {
+        "value": len(sample) / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "ray_steps_per_s": float(o["n_attempted"].sum()) / dt,
+        "sample": f"every {stride}th ray of rank 0's {n} rays ({len(sample)} rays, {dt:.1f} s, OpenMP over rays)",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+"""ctypes binding of libbhgeo.so (C ABI declared in include/bhgeo.h).
+
+The library is the product: there is no Python or CPU fallback.  Importing this module never
+touches the GPU; `load()` raises loudly when the shared library has not been built, and
+`Context()` raises when no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbhgeo.so")
+
+ABI_VERSION = 1
+
+OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
+
+FLAG_HIT_HORIZON = 1
+FLAG_START_INSIDE = 2
+FLAG_REACHED_END = 4
+FLAG_EXITED_SPHERE = 8
+FLAG_MAX_STEPS = 16
+FLAG_STEP_TOO_SMALL = 32
+FLAG_NAN = 64
+
+METHOD_DP54 = 0
+METHOD_RK4 = 1
+RHS_CHRISTOFFEL = 0
+RHS_REDUCED = 1
+
+# every symbol include/bhgeo.h declares (tests check the built library exports all of them)
+EXPORTS = (
+    "bhg_version", "bhg_device_count", "bhg_last_error", "bhg_default_params", "bhg_create",
+    "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
+    "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream",
+)
+
+
+class BhgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbhgeo error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct bhg_params (include/bhgeo.h)."""
+    _fields_ = [
+        ("r_s", C.c_double),
+        ("lambda_end", C.c_double),
+        ("max_step", C.c_double),
+        ("rtol", C.c_double),
+        ("atol", C.c_double),
+        ("h_fixed", C.c_double),
+        ("r_exit", C.c_double),
+        ("method", C.c_int32),
+        ("rhs_form", C.c_int32),
+        ("max_steps", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def load():
+    """dlopen libbhgeo.so and declare the prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C blackhole_geodesic_calculator_amd/csrc` (hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME
+    # libamdhip64.so.7).  If torch is importable, import it first so that libbhgeo binds to that
+    # already-loaded runtime; two runtimes in one process leave the second without a GPU.
+    if "torch" not in sys.modules and not os.environ.get("BHGEO_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH)
+    L.bhg_version.restype = C.c_int
+    L.bhg_device_count.restype = C.c_int
+    L.bhg_last_error.restype = C.c_char_p
+    L.bhg_default_params.restype = None
+    L.bhg_default_params.argtypes = [C.POINTER(Params)]
+    L.bhg_create.restype = C.c_int
+    L.bhg_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.bhg_destroy.restype = None
+    L.bhg_destroy.argtypes = [C.c_void_p]
+    L.bhg_device_name.restype = C.c_int
+    L.bhg_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.bhg_num_cus.restype = C.c_int
+    L.bhg_num_cus.argtypes = [C.c_void_p]
+    L.bhg_trace.restype = C.c_int
+    L.bhg_trace.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int, _dp, C.c_size_t, _dp, _u8p,
+                            _u32p, _u32p]
+    L.bhg_trace_device.restype = C.c_int
+    L.bhg_trace_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+    L.bhg_acceleration.restype = C.c_int
+    L.bhg_acceleration.argtypes = [C.c_void_p, C.POINTER(Params), _dp, _dp, C.c_size_t, _dp]
+    L.bhg_synchronize.restype = C.c_int
+    L.bhg_synchronize.argtypes = [C.c_void_p]
+    L.bhg_context_stream.restype = C.c_void_p
+    L.bhg_context_stream.argtypes = [C.c_void_p]
+    L.bhg_last_launch.restype = C.c_int
+    L.bhg_last_launch.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    if L.bhg_version() != ABI_VERSION:
+        raise ImportError(f"libbhgeo ABI {L.bhg_version()} != expected {ABI_VERSION}")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise BhgError(rc, load().bhg_last_error().decode())
+
+
+def default_params() -> Params:
+    p = Params()
+    load().bhg_default_params(C.byref(p))
+    return p
+
+
+def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
+                r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0) -> Params:
+    return Params(float(r_s), float(lambda_end), float(max_step), float(rtol), float(atol),
+                  float(h_fixed), float(r_exit), int(method), int(rhs_form), int(max_steps), 0)
+
+
+def device_count() -> int:
+    return load().bhg_device_count()
+
+
+def _np_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+class Context:
+    """One bhg_context = one device + stream.  Not thread-safe; one call at a time."""
+
+    def __init__(self, device: int = 0):
+        L = load()
+        h = C.c_void_p()
+        _check(L.bhg_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().bhg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(load().bhg_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def num_cus(self) -> int:
+        return load().bhg_num_cus(self._h)
+
+    def last_launch(self):
+        out = (C.c_int32 * 4)()
+        _check(load().bhg_last_launch(self._h, out))
+        return {"workgroups": out[0], "threads": out[1], "waves_per_cu": out[2], "persistent": bool(out[3])}
+
+    @property
+    def stream(self) -> int:
+        """The context's own hipStream_t as an integer handle."""
+        return load().bhg_context_stream(self._h) or 0
+
+    def synchronize(self):
+        _check(load().bhg_synchronize(self._h))
+
+    # -- host buffers -------------------------------------------------------------------
+    def trace(self, k0, x0, params: Params, want_accepted=True):
+        """k0[N,3], x0[3] (shared) or [N,3] -> (end[N,6], flags[N] u8, n_steps[N] u32, n_accepted[N] u32)."""
+        k0 = np.ascontiguousarray(k0, dtype=np.float64)
+        if k0.ndim != 2 or k0.shape[1] != 3:
+            raise ValueError("k0 must have shape [N, 3]")
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = k0.shape[0]
+        shared = x0.ndim == 1
+        if shared:
+            if x0.shape != (3,):
+                raise ValueError("x0 must have shape [3] or [N, 3]")
+        elif x0.shape != (n, 3):
+            raise ValueError("x0 must have shape [3] or [N, 3]")
+        end = np.empty((n, 6), np.float64)
+        flags = np.empty(n, np.uint8)
+        steps = np.empty(n, np.uint32)
+        acc = np.empty(n, np.uint32) if want_accepted else None
+        _check(load().bhg_trace(self._h, C.byref(params), _np_dp(x0), 1 if shared else 0, _np_dp(k0), n,
+                                _np_dp(end), flags.ctypes.data_as(_u8p), steps.ctypes.data_as(_u32p),
+                                acc.ctypes.data_as(_u32p) if acc is not None else None))
+        return end, flags, steps, acc
+
+    # -- device buffers (raw addresses, e.g. torch.Tensor.data_ptr()) -------------------
+    def trace_device(self, params: Params, n, d_k0, d_end, x0_shared=None, d_x0=0, d_flags=0,
+                     d_n_steps=0, d_n_accepted=0, stream=0):
+        xs = None
+        if x0_shared is not None:
+            xs = (C.c_double * 3)(*[float(v) for v in x0_shared])
+        _check(load().bhg_trace_device(self._h, C.byref(params), xs, C.c_void_p(d_x0 or None),
+                                       C.c_void_p(d_k0), int(n), C.c_void_p(d_end),
+                                       C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),
+                                       C.c_void_p(d_n_accepted or None), C.c_void_p(stream or None)))
+
+    def acceleration(self, x, k, params: Params):
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        k = np.ascontiguousarray(np.atleast_2d(k), dtype=np.float64)
+        a = np.empty_like(x)
+        _check(load().bhg_acceleration(self._h, C.byref(params), _np_dp(x), _np_dp(k), x.shape[0], _np_dp(a)))
+        return a

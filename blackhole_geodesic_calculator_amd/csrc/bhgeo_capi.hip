@@ -1,0 +1,324 @@
+// bhgeo_capi.hip -- the C ABI of libbhgeo.so (declared in include/bhgeo.h).
+//
+// Each entry point replaces a piece of the reference's per-ray Python hand-off
+// (raytracer/RelativisticRenderEngine.py:134, :293-313; batched contract of
+// raytracer/RelativisticRenderEngineCamEdition.py:225-228).  There is no CPU fallback: every
+// compute entry point needs a HIP device and fails with BHG_E_NO_DEVICE / BHG_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/bhgeo.h"
+#include "geodesic_kernels.h"
+
+static_assert(BHG_FLAG_HIT_HORIZON == bhg::BHG_FLAG_HIT_HORIZON_, "flag mismatch");
+static_assert(BHG_FLAG_START_INSIDE == bhg::BHG_FLAG_START_INSIDE_, "flag mismatch");
+static_assert(BHG_FLAG_REACHED_END == bhg::BHG_FLAG_REACHED_END_, "flag mismatch");
+static_assert(BHG_FLAG_EXITED_SPHERE == bhg::BHG_FLAG_EXITED_SPHERE_, "flag mismatch");
+static_assert(BHG_FLAG_MAX_STEPS == bhg::BHG_FLAG_MAX_STEPS_, "flag mismatch");
+static_assert(BHG_FLAG_STEP_TOO_SMALL == bhg::BHG_FLAG_STEP_TOO_SMALL_, "flag mismatch");
+static_assert(BHG_FLAG_NAN == bhg::BHG_FLAG_NAN_, "flag mismatch");
+static_assert(BHG_METHOD_DP54 == bhg::BHG_METHOD_DP54_ && BHG_METHOD_RK4 == bhg::BHG_METHOD_RK4_, "method mismatch");
+static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_, "rhs mismatch");
+static_assert(sizeof(bhg_params) == 72, "bhg_params layout is part of the ABI");
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorOutOfMemory) ? BHG_E_NOMEM : BHG_E_HIP;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fail_hip(_e, #expr); \
+    } while (0)
+
+}  // namespace
+
+struct bhg_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    unsigned long long *counter = nullptr;  // work counter (device)
+    int num_cus = 0;
+    char name[256] = {0};
+    // staging buffers for the host-buffer entry point, grown on demand
+    void *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    void *d_out = nullptr;
+    size_t d_out_bytes = 0;
+    int32_t last_launch[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int ensure(void **p, size_t *have, size_t need)
+{
+    if (*have >= need) return BHG_OK;
+    if (*p) {
+        HIP_TRY(hipFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    size_t want = need + need / 4 + 4096;
+    HIP_TRY(hipMalloc(p, want));
+    *have = want;
+    return BHG_OK;
+}
+
+int validate(const bhg_params *p)
+{
+    if (!p) return fail(BHG_E_INVALID, "params is NULL");
+    if (p->reserved != 0) return fail(BHG_E_INVALID, "params.reserved must be 0");
+    if (!(p->r_s >= 0.0) || !std::isfinite(p->r_s)) return fail(BHG_E_INVALID, "r_s must be finite and >= 0");
+    if (!(p->lambda_end >= 0.0) || !std::isfinite(p->lambda_end))
+        return fail(BHG_E_INVALID, "lambda_end must be finite and >= 0");
+    if (!(p->r_exit >= 0.0) || !std::isfinite(p->r_exit)) return fail(BHG_E_INVALID, "r_exit must be finite and >= 0");
+    if (p->method == BHG_METHOD_DP54) {
+        if (!(p->max_step > 0.0)) return fail(BHG_E_INVALID, "max_step must be > 0 (use +inf for unset)");
+        if (!(p->rtol > 0.0) || !(p->atol > 0.0) || !std::isfinite(p->rtol) || !std::isfinite(p->atol))
+            return fail(BHG_E_INVALID, "rtol and atol must be finite and > 0");
+    } else if (p->method == BHG_METHOD_RK4) {
+        if (!(p->h_fixed > 0.0) || !std::isfinite(p->h_fixed)) return fail(BHG_E_INVALID, "h_fixed must be finite and > 0");
+    } else {
+        return fail(BHG_E_INVALID, "unknown method");
+    }
+    if (p->rhs_form != BHG_RHS_CHRISTOFFEL && p->rhs_form != BHG_RHS_REDUCED)
+        return fail(BHG_E_INVALID, "unknown rhs_form");
+    return BHG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bhg_version(void) { return BHG_ABI_VERSION; }
+
+int bhg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *bhg_last_error(void) { return g_err.c_str(); }
+
+void bhg_default_params(bhg_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->r_s = 1.0;  // mass 0.5 (RelativisticRenderEngine.py:506), r_s = 2 M (:95)
+    p->lambda_end = 50.0;  // integration_depth default (:508)
+    p->max_step = INFINITY;  // max_integration_step -1 -> inf (:59-60); property default 1e4 (:507)
+    p->rtol = 1e-3;  // scipy rk.py:86
+    p->atol = 1e-6;
+    p->h_fixed = 0.1;
+    p->r_exit = 0.0;
+    p->method = BHG_METHOD_DP54;
+    p->rhs_form = BHG_RHS_CHRISTOFFEL;
+    p->max_steps = 0;
+    p->reserved = 0;
+}
+
+int bhg_create(int device, bhg_context **out)
+{
+    if (!out) return fail(BHG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = bhg_device_count();
+    if (n <= 0) return fail(BHG_E_NO_DEVICE, "no HIP device visible (libbhgeo has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(BHG_E_NO_DEVICE, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    bhg_context *c = new (std::nothrow) bhg_context();
+    if (!c) return fail(BHG_E_NOMEM, "host allocation failed");
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail_hip(e, "hipGetDeviceProperties");
+    }
+    c->num_cus = prop.multiProcessorCount;
+    std::snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail_hip(e, "hipStreamCreate");
+    }
+    e = hipMalloc((void **)&c->counter, 256);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail_hip(e, "hipMalloc(counter)");
+    }
+    *out = c;
+    return BHG_OK;
+}
+
+void bhg_destroy(bhg_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->counter) (void)hipFree(c->counter);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bhg_device_name(bhg_context *c, char *buf, size_t buflen)
+{
+    if (!c || !buf || buflen == 0) return fail(BHG_E_INVALID, "bad argument");
+    std::snprintf(buf, buflen, "%s", c->name);
+    return BHG_OK;
+}
+
+int bhg_num_cus(bhg_context *c) { return c ? c->num_cus : fail(BHG_E_INVALID, "ctx is NULL"); }
+
+int bhg_synchronize(bhg_context *c)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BHG_OK;
+}
+
+void *bhg_context_stream(bhg_context *c) { return c ? (void *)c->stream : nullptr; }
+
+int bhg_last_launch(bhg_context *c, int32_t out[4])
+{
+    if (!c || !out) return fail(BHG_E_INVALID, "bad argument");
+    std::memcpy(out, c->last_launch, sizeof(c->last_launch));
+    return BHG_OK;
+}
+
+int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_shared, const double *d_x0,
+                     const double *d_k0, size_t n, double *d_end, uint8_t *d_flags, uint32_t *d_n_steps,
+                     uint32_t *d_n_accepted, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    if (n == 0) return BHG_OK;
+    if (!d_k0 || !d_end) return fail(BHG_E_INVALID, "k0 / end is NULL");
+    if (!x0_shared && !d_x0) return fail(BHG_E_INVALID, "neither x0_shared nor d_x0 given");
+    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+
+    bhg::TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.k0 = d_k0;
+    a.x0 = d_x0;
+    a.end = d_end;
+    a.flags = d_flags;
+    a.n_steps = d_n_steps;
+    a.n_accepted = d_n_accepted;
+    a.counter = c->counter;
+    a.n = n;
+    if (!d_x0) {
+        a.x0s[0] = x0_shared[0];
+        a.x0s[1] = x0_shared[1];
+        a.x0s[2] = x0_shared[2];
+    }
+    a.r_s = p->r_s;
+    a.lambda_end = p->lambda_end;
+    a.max_step = p->max_step;
+    a.rtol = p->rtol;
+    a.atol = p->atol;
+    a.h_fixed = p->h_fixed;
+    a.r_exit = p->r_exit;
+    a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
+    const bool has_exit = p->r_exit > 0.0;
+
+    int per_cu = 0;
+    HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, has_exit, &per_cu));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 32) per_cu = 32;
+    // persistent waves: fill every resident wave slot once; never more waves than 64-ray batches
+    size_t batches = (n + 63) / 64;
+    size_t grid = (size_t)per_cu * (size_t)c->num_cus;
+    if (grid > batches) grid = batches;
+    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), s));
+    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, has_exit, (int)grid, s));
+    c->last_launch[0] = (int32_t)grid;
+    c->last_launch[1] = 64;
+    c->last_launch[2] = per_cu;
+    c->last_launch[3] = 1;
+    return BHG_OK;
+}
+
+int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
+              size_t n, double *end, uint8_t *flags, uint32_t *n_steps, uint32_t *n_accepted)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    if (n == 0) return BHG_OK;
+    if (!x0 || !k0 || !end) return fail(BHG_E_INVALID, "x0 / k0 / end is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = n * 3 * sizeof(double) * (x0_is_shared ? 1 : 2);
+    const size_t off_flags = n * 6 * sizeof(double);
+    const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
+    const size_t off_acc = off_steps + n * sizeof(uint32_t);
+    const size_t out_bytes = off_acc + n * sizeof(uint32_t);
+    rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
+    if (rc != BHG_OK) return rc;
+    rc = ensure(&c->d_out, &c->d_out_bytes, out_bytes);
+    if (rc != BHG_OK) return rc;
+    double *d_k0 = (double *)c->d_in;
+    double *d_x0 = x0_is_shared ? nullptr : d_k0 + n * 3;
+    char *o = (char *)c->d_out;
+    HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    rc = bhg_trace_device(c, p, x0_is_shared ? x0 : nullptr, d_x0, d_k0, n, (double *)o, (uint8_t *)(o + off_flags),
+                          (uint32_t *)(o + off_steps), (uint32_t *)(o + off_acc), c->stream);
+    if (rc != BHG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(end, o, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, o + off_flags, n, hipMemcpyDeviceToHost, c->stream));
+    if (n_steps) HIP_TRY(hipMemcpyAsync(n_steps, o + off_steps, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    if (n_accepted)
+        HIP_TRY(hipMemcpyAsync(n_accepted, o + off_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BHG_OK;
+}
+
+int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const double *k, size_t n, double *acc)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    if (n == 0) return BHG_OK;
+    if (!x || !k || !acc) return fail(BHG_E_INVALID, "x / k / acc is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure(&c->d_in, &c->d_in_bytes, n * 6 * sizeof(double));
+    if (rc != BHG_OK) return rc;
+    rc = ensure(&c->d_out, &c->d_out_bytes, n * 3 * sizeof(double));
+    if (rc != BHG_OK) return rc;
+    double *dx = (double *)c->d_in, *dk = dx + 3 * n;
+    HIP_TRY(hipMemcpyAsync(dx, x, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dk, k, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(bhg::launch_accel(dx, dk, p->r_s, n, (double *)c->d_out, p->rhs_form, c->stream));
+    HIP_TRY(hipMemcpyAsync(acc, c->d_out, n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BHG_OK;
+}
+
+}  // extern "C"

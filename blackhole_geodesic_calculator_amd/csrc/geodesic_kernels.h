@@ -1,0 +1,42 @@
+// geodesic_kernels.h -- internal interface between the C-ABI layer (bhgeo_capi.hip) and the
+// gfx950 kernels (geodesic_kernels.hip).  Not installed; the public surface is include/bhgeo.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bhg {
+
+// mirrors of the public constants (include/bhgeo.h); static_asserts in bhgeo_capi.hip tie them
+constexpr uint32_t BHG_FLAG_HIT_HORIZON_ = 1u;
+constexpr uint32_t BHG_FLAG_START_INSIDE_ = 2u;
+constexpr uint32_t BHG_FLAG_REACHED_END_ = 4u;
+constexpr uint32_t BHG_FLAG_EXITED_SPHERE_ = 8u;
+constexpr uint32_t BHG_FLAG_MAX_STEPS_ = 16u;
+constexpr uint32_t BHG_FLAG_STEP_TOO_SMALL_ = 32u;
+constexpr uint32_t BHG_FLAG_NAN_ = 64u;
+constexpr int BHG_METHOD_DP54_ = 0;
+constexpr int BHG_METHOD_RK4_ = 1;
+constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
+constexpr int BHG_RHS_REDUCED_ = 1;
+
+// Kernel arguments (passed by value -> SGPRs).  All pointers are device addresses.
+struct TraceArgs {
+    const double *k0;            // [n][3]
+    const double *x0;            // [n][3] or nullptr -> x0s
+    double *end;                 // [n][6]
+    uint8_t *flags;              // [n] or nullptr
+    uint32_t *n_steps;           // [n] or nullptr
+    uint32_t *n_accepted;        // [n] or nullptr
+    unsigned long long *counter; // work counter, zeroed before launch
+    uint64_t n;
+    double x0s[3];
+    double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit;
+    uint32_t max_steps;
+};
+
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s);
+hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu);
+hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
+                        hipStream_t s);
+
+}  // namespace bhg

@@ -1,0 +1,1030 @@
+// geodesic_kernels.hip -- hand-written CDNA4 (gfx950) kernels for the null-geodesic hot path.
+//
+// What this replaces (reference file:line):
+//   curvedpy.GeodesicIntegratorSchwarzschild.calc_trajectory, called once per ray at
+//   raytracer/RelativisticRenderEngine.py:293-294; ODE README.md:198-209; metric README.md:162-174;
+//   integrator scipy solve_ivp/RK45 (README.md:196; scipy/integrate/_ivp/rk.py:111-176).
+//
+// Design (MI355X-first, not a translation of the scipy loop):
+//   * one wavefront lane owns one ray; the whole 6-D phase-space state, the seven stage
+//     accelerations and the controller state live in VGPRs for the life of the ray;
+//   * the first-order system dx/dl = k, dk/dl = a(x,k) is advanced in Nystrom form: only the
+//     stage ACCELERATIONS are stored (21 doubles instead of 42), stage positions are formed from
+//     x, k and the products a~ = A*A of the Dormand-Prince tableau -- algebraically the same RK
+//     method, half the stage registers;
+//   * workgroup = one 64-lane wavefront, persistent: a lane whose ray ends (horizon, sphere
+//     exit, lambda_end) writes its result and refills from a per-wave LDS queue; the queue is
+//     filled 64 rays at a time by ALL lanes together (coalesced k0 loads, the scipy initial-step
+//     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
+//     always runs converged and the integrate loop always runs (nearly) full;
+//   * work is handed out in 64-ray batches from one device counter, fetched one batch ahead;
+//   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
+//     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
+//     element-wise ODE, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geodesic_kernels.h"
+
+namespace bhg {
+
+// ------------------------------------------------------------------------------------------
+// Dormand-Prince 5(4) coefficients (values as in scipy rk.py:377-404) and the derived
+// Nystrom tables.  Index 1-based like the literature; stage 7 is the FSAL stage (a_7j = b_j).
+// ------------------------------------------------------------------------------------------
+struct Tableau {
+    double a[8][8];   // a[i][j]
+    double c[8];      // c[i] = sum_j a[i][j]
+    double at[8][8];  // at[i][l] = sum_j a[i][j] a[j][l]          (position stages)
+    double e[8];      // error weights E_j                          (rk.py:388-389)
+    double et[8];     // et[l] = sum_j E_j a[j][l]                  (position error)
+    double p[8][4];   // dense output P                             (rk.py:391-404)
+    double sig[4];    // sig[m] = sum_j P[j][m]
+    double pt[8][4];  // pt[l][m] = sum_j P[j][m] a[j][l]
+};
+
+constexpr Tableau make_tableau()
+{
+    Tableau t{};
+    t.a[2][1] = 1.0 / 5;
+    t.a[3][1] = 3.0 / 40;
+    t.a[3][2] = 9.0 / 40;
+    t.a[4][1] = 44.0 / 45;
+    t.a[4][2] = -56.0 / 15;
+    t.a[4][3] = 32.0 / 9;
+    t.a[5][1] = 19372.0 / 6561;
+    t.a[5][2] = -25360.0 / 2187;
+    t.a[5][3] = 64448.0 / 6561;
+    t.a[5][4] = -212.0 / 729;
+    t.a[6][1] = 9017.0 / 3168;
+    t.a[6][2] = -355.0 / 33;
+    t.a[6][3] = 46732.0 / 5247;
+    t.a[6][4] = 49.0 / 176;
+    t.a[6][5] = -5103.0 / 18656;
+    t.a[7][1] = 35.0 / 384;
+    t.a[7][2] = 0.0;
+    t.a[7][3] = 500.0 / 1113;
+    t.a[7][4] = 125.0 / 192;
+    t.a[7][5] = -2187.0 / 6784;
+    t.a[7][6] = 11.0 / 84;
+    t.c[1] = 0.0;
+    t.c[2] = 1.0 / 5;
+    t.c[3] = 3.0 / 10;
+    t.c[4] = 4.0 / 5;
+    t.c[5] = 8.0 / 9;
+    t.c[6] = 1.0;
+    t.c[7] = 1.0;
+    for (int i = 1; i <= 7; i++)
+        for (int l = 1; l <= 7; l++) {
+            double s = 0.0;
+            for (int j = 1; j <= 7; j++) s += t.a[i][j] * t.a[j][l];
+            t.at[i][l] = s;
+        }
+    t.e[1] = -71.0 / 57600;
+    t.e[2] = 0.0;
+    t.e[3] = 71.0 / 16695;
+    t.e[4] = -71.0 / 1920;
+    t.e[5] = 17253.0 / 339200;
+    t.e[6] = -22.0 / 525;
+    t.e[7] = 1.0 / 40;
+    for (int l = 1; l <= 7; l++) {
+        double s = 0.0;
+        for (int j = 1; j <= 7; j++) s += t.e[j] * t.a[j][l];
+        t.et[l] = s;
+    }
+    t.p[1][0] = 1.0;
+    t.p[1][1] = -8048581381.0 / 2820520608.0;
+    t.p[1][2] = 8663915743.0 / 2820520608.0;
+    t.p[1][3] = -12715105075.0 / 11282082432.0;
+    t.p[3][1] = 131558114200.0 / 32700410799.0;
+    t.p[3][2] = -68118460800.0 / 10900136933.0;
+    t.p[3][3] = 87487479700.0 / 32700410799.0;
+    t.p[4][1] = -1754552775.0 / 470086768.0;
+    t.p[4][2] = 14199869525.0 / 1410260304.0;
+    t.p[4][3] = -10690763975.0 / 1880347072.0;
+    t.p[5][1] = 127303824393.0 / 49829197408.0;
+    t.p[5][2] = -318862633887.0 / 49829197408.0;
+    t.p[5][3] = 701980252875.0 / 199316789632.0;
+    t.p[6][1] = -282668133.0 / 205662961.0;
+    t.p[6][2] = 2019193451.0 / 616988883.0;
+    t.p[6][3] = -1453857185.0 / 822651844.0;
+    t.p[7][1] = 40617522.0 / 29380423.0;
+    t.p[7][2] = -110615467.0 / 29380423.0;
+    t.p[7][3] = 69997945.0 / 29380423.0;
+    for (int m = 0; m < 4; m++) {
+        double s = 0.0;
+        for (int j = 1; j <= 7; j++) s += t.p[j][m];
+        t.sig[m] = s;
+        for (int l = 1; l <= 7; l++) {
+            double q = 0.0;
+            for (int j = 1; j <= 7; j++) q += t.p[j][m] * t.a[j][l];
+            t.pt[l][m] = q;
+        }
+    }
+    return t;
+}
+
+__device__ constexpr Tableau TB = make_tableau();
+
+// ------------------------------------------------------------------------------------------
+// fp64 helpers: hardware seed + Newton.  Operands are O(1e-6 .. 1e6): no scaling needed.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);  // v_rcp_f64, ~2^-23 relative
+    double e = __builtin_fma(-x, y, 1.0);
+    double t = __builtin_fma(e, e, e);   // e + e^2
+    return __builtin_fma(y, t, y);       // cubic: residual ~e^3
+}
+
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);  // v_rsq_f64, ~2^-23 relative
+    double y2 = y * y;
+    double e = __builtin_fma(-x, y2, 1.0);           // 1 - x y^2
+    double p = __builtin_fma(0.375, e, 0.5);          // 1/2 + 3/8 e
+    double t = y * e;
+    return __builtin_fma(t, p, y);                    // cubic: residual ~e^3
+}
+
+// x^(-1/10) for x in [1e-11, 1e7]: fp32 exp2/log2 seed (~1e-7) + one cubic Newton step.
+__device__ __forceinline__ double pow_m0p1(double x)
+{
+    float xf = (float)x;
+    float s = __builtin_amdgcn_exp2f(-0.1f * __builtin_amdgcn_logf(xf));  // v_exp_f32(v_log_f32)
+    double y = (double)s;
+    double y2 = y * y;
+    double y4 = y2 * y2;
+    double y8 = y4 * y4;
+    double y10 = y8 * y2;
+    double t = __builtin_fma(-x, y10, 1.0);           // 1 - x y^10
+    double p = __builtin_fma(0.055, t, 0.1);          // (1-t)^(-1/10) = 1 + t/10 + 11/200 t^2 + ...
+    double u = y * t;
+    return __builtin_fma(u, p, y);
+}
+
+// ------------------------------------------------------------------------------------------
+// RHS: spatial acceleration a^i = -Gamma^i_{mu nu} k^mu k^nu, k^t from the null condition
+// (README.md:198-209; time_like=False at RelativisticRenderEngine.py:134).  Also returns r.
+// ------------------------------------------------------------------------------------------
+template <int RHS>
+__device__ __forceinline__ void accel(const double x[3], const double k[3], double r_s,
+                                      double a[3], double &r)
+{
+    double r2 = __builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]));
+    double kk = __builtin_fma(k[2], k[2], __builtin_fma(k[1], k[1], k[0] * k[0]));
+    double xk = __builtin_fma(x[2], k[2], __builtin_fma(x[1], k[1], x[0] * k[0]));
+    double rinv = rsqrt_nr(r2);
+    r = r2 * rinv;
+    double c;
+    if (RHS == BHG_RHS_REDUCED_) {
+        // a = -(3/2) r_s |x cross k|^2 x / r^5
+        double L2 = __builtin_fma(r2, kk, -(xk * xk));
+        double w = rinv * rinv;
+        double rinv5 = w * w * rinv;
+        c = (-1.5 * r_s) * L2 * rinv5;
+    } else {
+        // a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ]
+        // f = 1 - r_s/r, f' = r_s/r^2, h = r_s/(r-r_s), h' = -r_s/(r-r_s)^2,
+        // (k^t)^2 = (|k|^2 + h (n.k)^2)/f          -- singular at r = r_s like the contraction
+        double w = rinv * rinv;        // 1/r^2
+        double u = r_s * rinv;         // r_s/r
+        double nk2 = xk * xk * w;      // (n.k)^2
+        double f = 1.0 - u;
+        double fp = r_s * w;
+        double q = rcp_nr(f);          // 1/f
+        double h = u * q;              // r_s/(r - r_s)
+        double hp = -(fp * q) * q;     // -r_s/(r - r_s)^2
+        double kt2 = __builtin_fma(h, nk2, kk) * q;
+        double s = __builtin_fma(0.5 * f, __builtin_fma(hp, nk2, fp * kt2), fp * (kk - nk2));
+        c = -s * rinv;
+    }
+    a[0] = c * x[0];
+    a[1] = c * x[1];
+    a[2] = c * x[2];
+}
+
+__device__ __forceinline__ double ulp_of(double t)
+{
+    // nextafter(t, +inf) - t for t >= 0 (rk.py:119)
+    long long b = __double_as_longlong(t) & 0x7FF0000000000000LL;
+    double ulp = __longlong_as_double(b) * 2.220446049250313e-16;
+    return t == 0.0 ? 4.9406564584124654e-324 : ulp;
+}
+
+// Cross-lane hand-off through LDS inside ONE wavefront: DS operations of a wave execute in
+// program order, so only the compiler needs fencing.  (A workgroup-scope __syncthreads() would
+// also drain vmcnt and stall on the in-flight result stores and the prefetched work counter.)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// quartic dense output of one DP5(4) step, positions and directions (rk.py:393-404, :552-574)
+struct Dense {
+    double x0[3], v0[3];
+    double qx[4][3], qv[4][3];
+    double t0, h;
+};
+
+__device__ __forceinline__ void dense_pos(const Dense &d, double t, double x[3])
+{
+    double th = (t - d.t0) / d.h;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double s = __builtin_fma(d.qx[3][i], th, d.qx[2][i]);
+        s = __builtin_fma(s, th, d.qx[1][i]);
+        s = __builtin_fma(s, th, d.qx[0][i]);
+        x[i] = __builtin_fma(d.h * th, s, d.x0[i]);
+    }
+}
+
+__device__ __forceinline__ void dense_dir(const Dense &d, double t, double v[3])
+{
+    double th = (t - d.t0) / d.h;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double s = __builtin_fma(d.qv[3][i], th, d.qv[2][i]);
+        s = __builtin_fma(s, th, d.qv[1][i]);
+        s = __builtin_fma(s, th, d.qv[0][i]);
+        v[i] = __builtin_fma(d.h * th, s, d.v0[i]);
+    }
+}
+
+__device__ __forceinline__ double dense_g(const Dense &d, double t, double R)
+{
+    double x[3];
+    dense_pos(d, t, x);
+    return sqrt(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]))) - R;
+}
+
+// Brent's method on g(t) = r(t) - R over [ta, tb], xtol = rtol = 4 eps (ivp.py:51-76).
+// Rare and divergent: runs once per ray that ends on the horizon or on the exit sphere.
+template <class F>
+__device__ __forceinline__ double brent_root(const F &g, double xa, double xb)
+{
+    const double tol = 4.0 * 2.220446049250313e-16;
+    double xpre = xa, xcur = xb, xblk = 0.0, fblk = 0.0, spre = 0.0, scur = 0.0;
+    double fpre = g(xpre), fcur = g(xcur);
+    if (fpre == 0.0) return xpre;
+    if (fcur == 0.0) return xcur;
+    for (int it = 0; it < 100; it++) {
+        if (fpre != 0.0 && fcur != 0.0 && ((fpre < 0.0) != (fcur < 0.0))) {
+            xblk = xpre;
+            fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur;
+            xcur = xblk;
+            xblk = xpre;
+            fpre = fcur;
+            fcur = fblk;
+            fblk = fpre;
+        }
+        double delta = (tol + tol * fabs(xcur)) * 0.5;
+        double sbis = (xblk - xcur) * 0.5;
+        if (fcur == 0.0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur);
+                double dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            double lim = fmin(fabs(spre), 3.0 * fabs(sbis) - delta);
+            if (2.0 * fabs(stry) < lim) {
+                spre = scur;
+                scur = stry;
+            } else {
+                spre = sbis;
+                scur = sbis;
+            }
+        } else {
+            spre = sbis;
+            scur = sbis;
+        }
+        xpre = xcur;
+        fpre = fcur;
+        if (fabs(scur) > delta)
+            xcur += scur;
+        else
+            xcur += (sbis > 0.0 ? delta : -delta);
+        fcur = g(xcur);
+    }
+    return xcur;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-wave LDS queue of prepared rays (filled converged, drained lane by lane)
+// ------------------------------------------------------------------------------------------
+struct WaveQueue {
+    double x[3][64];
+    double k[3][64];
+    double a[3][64];   // FSAL acceleration at the start point
+    double h[64];      // initial |h| (common.py:68-134)
+    double r[64];      // r at the start point
+    uint32_t idx[64];
+};
+
+struct Result {
+    double x[3], v[3];
+    uint32_t flags, n_att, n_acc;
+};
+
+__device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
+                                             const double v[3], uint32_t flags, uint32_t n_att,
+                                             uint32_t n_acc)
+{
+    bool bad = !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(v[0]) &&
+                 isfinite(v[1]) && isfinite(v[2]));
+    if (bad) flags |= BHG_FLAG_NAN_;
+    double *e = A.end + (size_t)idx * 6;
+    // 48 contiguous bytes per lane: three 16-byte stores
+    reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
+    reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
+    reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
+    if (A.flags) A.flags[idx] = (uint8_t)flags;
+    if (A.n_steps) A.n_steps[idx] = n_att;
+    if (A.n_accepted) A.n_accepted[idx] = n_acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool HAS_EXIT>
+__global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
+{
+    __shared__ WaveQueue Q;
+    const uint32_t lane = threadIdx.x;
+    const double r_s = A.r_s, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+    const double max_step = A.max_step;
+    const uint64_t n = A.n;
+
+    // per-lane ray state
+    bool active = false;
+    bool rejected = false;
+    double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+    double t = 0.0, h_abs = 0.0, r_cur = 0.0;
+    uint32_t idx = 0, n_att = 0, n_acc = 0;
+
+    // wave-uniform queue state
+    int q_head = 0, q_count = 0;
+    bool exhausted = false;
+    uint64_t next_base;
+    {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(A.counter, 64ull);
+        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
+                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    }
+
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        if (idle) {
+            for (;;) {
+                if (q_count == 0) {
+                    if (exhausted) break;
+                    const uint64_t base = next_base;
+                    if (base >= n) {
+                        exhausted = true;
+                        break;
+                    }
+                    {
+                        unsigned long long b = 0;
+                        if (lane == 0) b = atomicAdd(A.counter, 64ull);
+                        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
+                                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+                    }
+                    // ---- converged setup of rays base .. base+63 -------------------------
+                    const uint64_t i = base + lane;
+                    const bool have = i < n;
+                    double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
+                    bool valid = false;
+                    if (have) {
+                        pk[0] = A.k0[i * 3 + 0];
+                        pk[1] = A.k0[i * 3 + 1];
+                        pk[2] = A.k0[i * 3 + 2];
+                        if (A.x0) {
+                            px[0] = A.x0[i * 3 + 0];
+                            px[1] = A.x0[i * 3 + 1];
+                            px[2] = A.x0[i * 3 + 2];
+                        } else {
+                            px[0] = A.x0s[0];
+                            px[1] = A.x0s[1];
+                            px[2] = A.x0s[2];
+                        }
+                        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+                        if (r0 <= r_s) {
+                            // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
+                            store_result(A, (uint32_t)i, px, pk,
+                                         BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+                        } else {
+                            valid = true;
+                            // f0 and the Hairer initial step (common.py:68-134, order = 4)
+                            accel<RHS>(px, pk, r_s, pa, pr);
+                            double isc[6];
+                            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
+                                double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
+                                isc[c] = sk;
+                                isc[3 + c] = sx;
+                                double y0k = pk[c] * sk, y0x = px[c] * sx;
+                                double f0k = pa[c] * sk, f0x = pk[c] * sx;
+                                d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
+                                d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
+                            }
+                            d0 = sqrt(d0 * (1.0 / 6.0));
+                            d1 = sqrt(d1 * (1.0 / 6.0));
+                            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                            h0 = fmin(h0, t_bound);
+                            double x1[3], k1[3], f1[3], r1;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                x1[c] = __builtin_fma(h0, pk[c], px[c]);
+                                k1[c] = __builtin_fma(h0, pa[c], pk[c]);
+                            }
+                            accel<RHS>(x1, k1, r_s, f1, r1);
+                            double d2 = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                double dk = (f1[c] - pa[c]) * isc[c];
+                                double dx = (k1[c] - pk[c]) * isc[3 + c];
+                                d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
+                            }
+                            d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
+                            double h1;
+                            if (d1 <= 1e-15 && d2 <= 1e-15)
+                                h1 = fmax(1e-6, h0 * 1e-3);
+                            else
+                                h1 = pow(0.01 / fmax(d1, d2), 0.2);
+                            ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, max_step));
+                        }
+                    }
+                    const uint64_t vmask = __ballot(valid);
+                    if (valid) {
+                        const uint32_t s = lane_rank(vmask);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            Q.x[c][s] = px[c];
+                            Q.k[c][s] = pk[c];
+                            Q.a[c][s] = pa[c];
+                        }
+                        Q.h[s] = ph;
+                        Q.r[s] = pr;
+                        Q.idx[s] = (uint32_t)i;
+                    }
+                    wave_lds_sync();
+                    q_head = 0;
+                    q_count = __builtin_popcountll(vmask);
+                    if (q_count == 0) continue;
+                }
+                const int n_idle = __builtin_popcountll(idle);
+                const int take = n_idle < q_count ? n_idle : q_count;
+                if (!active) {
+                    const int rk = (int)lane_rank(idle);
+                    if (rk < take) {
+                        const int s = q_head + rk;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            x[c] = Q.x[c][s];
+                            v[c] = Q.k[c][s];
+                            a1[c] = Q.a[c][s];
+                        }
+                        h_abs = Q.h[s];
+                        r_cur = Q.r[s];
+                        idx = Q.idx[s];
+                        t = 0.0;
+                        n_att = 0;
+                        n_acc = 0;
+                        rejected = false;
+                        active = true;
+                    }
+                }
+                wave_lds_sync();
+                q_head += take;
+                q_count -= take;
+                idle = __ballot(!active);
+                if (!idle) break;
+            }
+            if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
+        }
+
+        if (active) {
+            // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
+            uint32_t term = 0;
+            const double min_step = 10.0 * ulp_of(t);
+            if (!rejected) {
+                if (h_abs > max_step)
+                    h_abs = max_step;
+                else if (h_abs < min_step)
+                    h_abs = min_step;
+            }
+            if (h_abs < min_step)
+                term = BHG_FLAG_STEP_TOO_SMALL_;
+            else if (n_att >= A.max_steps)
+                term = BHG_FLAG_MAX_STEPS_;
+            if (term == 0 && t == t_bound) term = BHG_FLAG_REACHED_END_;  // base.py:189-194
+            if (term) {
+                store_result(A, idx, x, v, term, n_att, n_acc);
+                active = false;
+            } else {
+                double t_new = t + h_abs;
+                if (t_new - t_bound > 0.0) t_new = t_bound;
+                const double h = t_new - t;
+                h_abs = fabs(h);
+                const double h2 = h * h;
+
+                double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3];
+                double xs[3], vs[3], rs_;
+                // stage 2
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    vs[c] = __builtin_fma(h * TB.a[2][1], a1[c], v[c]);
+                    xs[c] = __builtin_fma(h * TB.c[2], v[c], x[c]);
+                }
+                accel<RHS>(xs, vs, r_s, a2, rs_);
+                // stage 3
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sv = __builtin_fma(TB.a[3][2], a2[c], TB.a[3][1] * a1[c]);
+                    vs[c] = __builtin_fma(h, sv, v[c]);
+                    double sx = TB.at[3][1] * a1[c];
+                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[3], v[c], x[c]));
+                }
+                accel<RHS>(xs, vs, r_s, a3, rs_);
+                // stage 4
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sv = __builtin_fma(TB.a[4][3], a3[c],
+                                              __builtin_fma(TB.a[4][2], a2[c], TB.a[4][1] * a1[c]));
+                    vs[c] = __builtin_fma(h, sv, v[c]);
+                    double sx = __builtin_fma(TB.at[4][2], a2[c], TB.at[4][1] * a1[c]);
+                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[4], v[c], x[c]));
+                }
+                accel<RHS>(xs, vs, r_s, a4, rs_);
+                // stage 5
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sv = __builtin_fma(
+                        TB.a[5][4], a4[c],
+                        __builtin_fma(TB.a[5][3], a3[c],
+                                      __builtin_fma(TB.a[5][2], a2[c], TB.a[5][1] * a1[c])));
+                    vs[c] = __builtin_fma(h, sv, v[c]);
+                    double sx = __builtin_fma(TB.at[5][3], a3[c],
+                                              __builtin_fma(TB.at[5][2], a2[c], TB.at[5][1] * a1[c]));
+                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[5], v[c], x[c]));
+                }
+                accel<RHS>(xs, vs, r_s, a5, rs_);
+                // stage 6
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sv = __builtin_fma(
+                        TB.a[6][5], a5[c],
+                        __builtin_fma(TB.a[6][4], a4[c],
+                                      __builtin_fma(TB.a[6][3], a3[c],
+                                                    __builtin_fma(TB.a[6][2], a2[c], TB.a[6][1] * a1[c]))));
+                    vs[c] = __builtin_fma(h, sv, v[c]);
+                    double sx = __builtin_fma(
+                        TB.at[6][4], a4[c],
+                        __builtin_fma(TB.at[6][3], a3[c],
+                                      __builtin_fma(TB.at[6][2], a2[c], TB.at[6][1] * a1[c])));
+                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[6], v[c], x[c]));
+                }
+                accel<RHS>(xs, vs, r_s, a6, rs_);
+                // new solution (stage 7 = FSAL; b_2 = 0)
+                double xn[3], vn[3], r_new;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sv = __builtin_fma(
+                        TB.a[7][6], a6[c],
+                        __builtin_fma(TB.a[7][5], a5[c],
+                                      __builtin_fma(TB.a[7][4], a4[c],
+                                                    __builtin_fma(TB.a[7][3], a3[c], TB.a[7][1] * a1[c]))));
+                    vn[c] = __builtin_fma(h, sv, v[c]);
+                    double sx = __builtin_fma(
+                        TB.at[7][5], a5[c],
+                        __builtin_fma(TB.at[7][4], a4[c],
+                                      __builtin_fma(TB.at[7][3], a3[c],
+                                                    __builtin_fma(TB.at[7][2], a2[c], TB.at[7][1] * a1[c]))));
+                    xn[c] = __builtin_fma(h2, sx, __builtin_fma(h, v[c], x[c]));
+                }
+                accel<RHS>(xn, vn, r_s, a7, r_new);
+                n_att++;
+
+                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components
+                double errsq = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double ev = __builtin_fma(
+                        TB.e[7], a7[c],
+                        __builtin_fma(TB.e[6], a6[c],
+                                      __builtin_fma(TB.e[5], a5[c],
+                                                    __builtin_fma(TB.e[4], a4[c],
+                                                                  __builtin_fma(TB.e[3], a3[c], TB.e[1] * a1[c])))));
+                    ev *= h;
+                    double ex = __builtin_fma(
+                        TB.et[6], a6[c],
+                        __builtin_fma(TB.et[5], a5[c],
+                                      __builtin_fma(TB.et[4], a4[c],
+                                                    __builtin_fma(TB.et[3], a3[c],
+                                                                  __builtin_fma(TB.et[2], a2[c], TB.et[1] * a1[c])))));
+                    ex *= h2;
+                    double scv = __builtin_fma(fmax(fabs(v[c]), fabs(vn[c])), rtol, atol);
+                    double scx = __builtin_fma(fmax(fabs(x[c]), fabs(xn[c])), rtol, atol);
+                    double qv = ev * rcp_nr(scv);
+                    double qx = ex * rcp_nr(scx);
+                    errsq = __builtin_fma(qv, qv, __builtin_fma(qx, qx, errsq));
+                }
+                errsq *= (1.0 / 6.0);
+                // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
+                if (!(r_new == r_new)) errsq = __builtin_nan("");
+
+                // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
+                double fac;
+                if (errsq < 3.4e6) {
+                    fac = 0.9 * pow_m0p1(fmax(errsq, 1e-11));
+                } else {
+                    fac = 0.2;  // also the NaN case: python max(0.2, nan) == 0.2
+                }
+                if (errsq < 1.0) {
+                    fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
+                    if (rejected) fac = fmin(1.0, fac);
+                    h_abs *= fac;
+                    rejected = false;
+                    n_acc++;
+
+                    // events between step ends (ivp.py:109-126): horizon any direction, exit outward
+                    const bool ev_h = ((r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
+                                      ((r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+                    const bool ev_e = HAS_EXIT && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                    if (ev_h || ev_e) {
+                        Dense d;
+                        d.t0 = t;
+                        d.h = h;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            d.x0[c] = x[c];
+                            d.v0[c] = v[c];
+#pragma unroll
+                            for (int m = 0; m < 4; m++) {
+                                double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] +
+                                            TB.p[5][m] * a5[c] + TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
+                                double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] +
+                                            TB.pt[4][m] * a4[c] + TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
+                                d.qv[m][c] = qv;
+                                d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
+                            }
+                        }
+                        double rh = 0.0, re = 0.0;
+                        if (ev_h) rh = brent_root([&](double tt) { return dense_g(d, tt, r_s); }, t, t_new);
+                        if (ev_e) re = brent_root([&](double tt) { return dense_g(d, tt, A.r_exit); }, t, t_new);
+                        double t_root;
+                        uint32_t fl;
+                        if (ev_h && (!ev_e || rh <= re)) {
+                            t_root = rh;
+                            fl = BHG_FLAG_HIT_HORIZON_;
+                        } else {
+                            t_root = re;
+                            fl = BHG_FLAG_EXITED_SPHERE_;
+                        }
+                        double xe[3], ve[3];
+                        dense_pos(d, t_root, xe);
+                        dense_dir(d, t_root, ve);
+                        store_result(A, idx, xe, ve, fl, n_att, n_acc);
+                        active = false;
+                    } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
+                        store_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_, n_att, n_acc);
+                        active = false;
+                    } else {
+                        t = t_new;
+                        r_cur = r_new;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            x[c] = xn[c];
+                            v[c] = vn[c];
+                            a1[c] = a7[c];
+                        }
+                    }
+                } else {
+                    h_abs *= fmax(0.2, fac);
+                    rejected = true;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fixed-step classic RK4 ("R-fine" regime).  Same persistent lane-refill wave.
+// Events are located on the cubic Hermite interpolant of the step.
+// ------------------------------------------------------------------------------------------
+struct Hermite {
+    double x0[3], x1[3], v0[3], v1[3], a0[3], a1[3];
+    double t0, h;
+};
+
+__device__ __forceinline__ void hermite_eval(const Hermite &d, double t, double x[3], double v[3])
+{
+    double s = (t - d.t0) / d.h;
+    double s2 = s * s, s3 = s2 * s;
+    double h00 = 2 * s3 - 3 * s2 + 1, h10 = s3 - 2 * s2 + s, h01 = -2 * s3 + 3 * s2, h11 = s3 - s2;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        x[c] = h00 * d.x0[c] + h10 * d.h * d.v0[c] + h01 * d.x1[c] + h11 * d.h * d.v1[c];
+        v[c] = h00 * d.v0[c] + h10 * d.h * d.a0[c] + h01 * d.v1[c] + h11 * d.h * d.a1[c];
+    }
+}
+
+__device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R)
+{
+    double x[3], v[3];
+    hermite_eval(d, t, x, v);
+    return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) - R;
+}
+
+template <int RHS, bool HAS_EXIT>
+__global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
+{
+    __shared__ WaveQueue Q;
+    const uint32_t lane = threadIdx.x;
+    const double r_s = A.r_s, t_bound = A.lambda_end, hf = A.h_fixed;
+    const uint64_t n = A.n;
+
+    bool active = false;
+    double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
+    double t = 0.0, r_cur = 0.0;
+    uint32_t idx = 0, n_att = 0;
+
+    int q_head = 0, q_count = 0;
+    bool exhausted = false;
+    uint64_t next_base;
+    {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(A.counter, 64ull);
+        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
+                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    }
+
+    for (;;) {
+        uint64_t idle = __ballot(!active);
+        if (idle) {
+            for (;;) {
+                if (q_count == 0) {
+                    if (exhausted) break;
+                    const uint64_t base = next_base;
+                    if (base >= n) {
+                        exhausted = true;
+                        break;
+                    }
+                    {
+                        unsigned long long b = 0;
+                        if (lane == 0) b = atomicAdd(A.counter, 64ull);
+                        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
+                                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+                    }
+                    const uint64_t i = base + lane;
+                    double px[3], pk[3], pa[3], pr = 0.0;
+                    bool valid = false;
+                    if (i < n) {
+                        pk[0] = A.k0[i * 3 + 0];
+                        pk[1] = A.k0[i * 3 + 1];
+                        pk[2] = A.k0[i * 3 + 2];
+                        if (A.x0) {
+                            px[0] = A.x0[i * 3 + 0];
+                            px[1] = A.x0[i * 3 + 1];
+                            px[2] = A.x0[i * 3 + 2];
+                        } else {
+                            px[0] = A.x0s[0];
+                            px[1] = A.x0s[1];
+                            px[2] = A.x0s[2];
+                        }
+                        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+                        if (r0 <= r_s) {
+                            store_result(A, (uint32_t)i, px, pk,
+                                         BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+                        } else {
+                            valid = true;
+                            accel<RHS>(px, pk, r_s, pa, pr);
+                        }
+                    }
+                    const uint64_t vmask = __ballot(valid);
+                    if (valid) {
+                        const uint32_t s = lane_rank(vmask);
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            Q.x[c][s] = px[c];
+                            Q.k[c][s] = pk[c];
+                            Q.a[c][s] = pa[c];
+                        }
+                        Q.r[s] = pr;
+                        Q.idx[s] = (uint32_t)i;
+                    }
+                    wave_lds_sync();
+                    q_head = 0;
+                    q_count = __builtin_popcountll(vmask);
+                    if (q_count == 0) continue;
+                }
+                const int n_idle = __builtin_popcountll(idle);
+                const int take = n_idle < q_count ? n_idle : q_count;
+                if (!active) {
+                    const int rk = (int)lane_rank(idle);
+                    if (rk < take) {
+                        const int s = q_head + rk;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            x[c] = Q.x[c][s];
+                            v[c] = Q.k[c][s];
+                            a1[c] = Q.a[c][s];
+                        }
+                        r_cur = Q.r[s];
+                        idx = Q.idx[s];
+                        t = 0.0;
+                        n_att = 0;
+                        active = true;
+                    }
+                }
+                wave_lds_sync();
+                q_head += take;
+                q_count -= take;
+                idle = __ballot(!active);
+                if (!idle) break;
+            }
+            if (idle == ~0ull) break;
+        }
+
+        if (active) {
+            uint32_t term = 0;
+            if (t >= t_bound) term = BHG_FLAG_REACHED_END_;
+            else if (n_att >= A.max_steps) term = BHG_FLAG_MAX_STEPS_;
+            if (term) {
+                store_result(A, idx, x, v, term, n_att, n_att);
+                active = false;
+            } else {
+                double t_new = t + hf;
+                if (t_new - t_bound > 0.0) t_new = t_bound;
+                const double h = t_new - t;
+                const double hh = 0.5 * h;
+                double a2[3], a3[3], a4[3], a5[3], xs[3], vs[3], rr, r_new;
+                // k2 = f(y + h/2 k1): position slope = v, velocity slope = a1
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    xs[c] = __builtin_fma(hh, v[c], x[c]);
+                    vs[c] = __builtin_fma(hh, a1[c], v[c]);
+                }
+                double v2[3] = {vs[0], vs[1], vs[2]};
+                accel<RHS>(xs, vs, r_s, a2, rr);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    xs[c] = __builtin_fma(hh, v2[c], x[c]);
+                    vs[c] = __builtin_fma(hh, a2[c], v[c]);
+                }
+                double v3[3] = {vs[0], vs[1], vs[2]};
+                accel<RHS>(xs, vs, r_s, a3, rr);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    xs[c] = __builtin_fma(h, v3[c], x[c]);
+                    vs[c] = __builtin_fma(h, a3[c], v[c]);
+                }
+                double v4[3] = {vs[0], vs[1], vs[2]};
+                accel<RHS>(xs, vs, r_s, a4, rr);
+                double xn[3], vn[3];
+                const double h6 = h * (1.0 / 6.0);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    xn[c] = __builtin_fma(h6, __builtin_fma(2.0, v3[c], __builtin_fma(2.0, v2[c], v[c])) + v4[c], x[c]);
+                    vn[c] = __builtin_fma(h6, __builtin_fma(2.0, a3[c], __builtin_fma(2.0, a2[c], a1[c])) + a4[c], v[c]);
+                }
+                accel<RHS>(xn, vn, r_s, a5, r_new);
+                n_att++;
+                const bool ev_h = ((r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
+                                  ((r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+                const bool ev_e = HAS_EXIT && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                if (ev_h || ev_e) {
+                    Hermite d;
+                    d.t0 = t;
+                    d.h = h;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        d.x0[c] = x[c];
+                        d.x1[c] = xn[c];
+                        d.v0[c] = v[c];
+                        d.v1[c] = vn[c];
+                        d.a0[c] = a1[c];
+                        d.a1[c] = a5[c];
+                    }
+                    double rh = 0.0, re = 0.0;
+                    if (ev_h) rh = brent_root([&](double tt) { return hermite_g(d, tt, r_s); }, t, t_new);
+                    if (ev_e) re = brent_root([&](double tt) { return hermite_g(d, tt, A.r_exit); }, t, t_new);
+                    double t_root;
+                    uint32_t fl;
+                    if (ev_h && (!ev_e || rh <= re)) {
+                        t_root = rh;
+                        fl = BHG_FLAG_HIT_HORIZON_;
+                    } else {
+                        t_root = re;
+                        fl = BHG_FLAG_EXITED_SPHERE_;
+                    }
+                    double xe[3], ve[3];
+                    hermite_eval(d, t_root, xe, ve);
+                    store_result(A, idx, xe, ve, fl, n_att, n_att);
+                    active = false;
+                } else if (!(r_new == r_new)) {
+                    store_result(A, idx, xn, vn, 0, n_att, n_att);  // NaN flag added by store_result
+                    active = false;
+                } else {
+                    t = t_new;
+                    r_cur = r_new;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        x[c] = xn[c];
+                        v[c] = vn[c];
+                        a1[c] = a5[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Acceleration probe (tests compare the device RHS with the oracle's)
+// ------------------------------------------------------------------------------------------
+template <int RHS>
+__global__ void accel_kernel(const double *x, const double *k, double r_s, uint64_t n, double *acc)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double px[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    double pk[3] = {k[3 * i], k[3 * i + 1], k[3 * i + 2]};
+    double a[3], r;
+    accel<RHS>(px, pk, r_s, a, r);
+    acc[3 * i] = a[0];
+    acc[3 * i + 1] = a[1];
+    acc[3 * i + 2] = a[2];
+}
+
+// ------------------------------------------------------------------------------------------
+// Launchers
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool EX>
+static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipStream_t s)
+{
+    if (method == BHG_METHOD_RK4_)
+        hipLaunchKernelGGL((trace_rk4_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((trace_dp54_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int RHS, bool EX>
+static hipError_t occupancy_variant(int method, int *blocks_per_cu)
+{
+    if (method == BHG_METHOD_RK4_)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_rk4_kernel<RHS, EX>, 64, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_dp54_kernel<RHS, EX>, 64, 0);
+}
+
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s)
+{
+    if (rhs == BHG_RHS_REDUCED_)
+        return has_exit ? launch_variant<BHG_RHS_REDUCED_, true>(a, method, grid, s)
+                        : launch_variant<BHG_RHS_REDUCED_, false>(a, method, grid, s);
+    return has_exit ? launch_variant<BHG_RHS_CHRISTOFFEL_, true>(a, method, grid, s)
+                    : launch_variant<BHG_RHS_CHRISTOFFEL_, false>(a, method, grid, s);
+}
+
+hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu)
+{
+    if (rhs == BHG_RHS_REDUCED_)
+        return has_exit ? occupancy_variant<BHG_RHS_REDUCED_, true>(method, blocks_per_cu)
+                        : occupancy_variant<BHG_RHS_REDUCED_, false>(method, blocks_per_cu);
+    return has_exit ? occupancy_variant<BHG_RHS_CHRISTOFFEL_, true>(method, blocks_per_cu)
+                    : occupancy_variant<BHG_RHS_CHRISTOFFEL_, false>(method, blocks_per_cu);
+}
+
+hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
+                        hipStream_t s)
+{
+    int grid = (int)((n + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    if (rhs == BHG_RHS_REDUCED_)
+        hipLaunchKernelGGL((accel_kernel<BHG_RHS_REDUCED_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+    else
+        hipLaunchKernelGGL((accel_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+    return hipGetLastError();
+}
+
+}  // namespace bhg

@@ -1,0 +1,108 @@
+"""Host-side mirror of the solver object the reference's render engine drives.
+
+Reference interface (the package it comes from, curvedpy, is not in the reference tree):
+    curvedpy.GeodesicIntegratorSchwarzschild(mass=, time_like=False, verbose=False)
+                                                    raytracer/RelativisticRenderEngine.py:134
+    .calc_trajectory(k0_xyz, x0_xyz, max_step=, curve_end=, nr_points_curve=10000, verbose=False)
+        -> (k_xyz, x_xyz, result)                   raytracer/RelativisticRenderEngine.py:293-294
+    consumed: x_xyz[axis][-1], k_xyz[axis][-1]      :299-308
+              result['start_inside_hole'], result['hit_blackhole']   :296-297
+
+Same names, argument meaning and return shapes; the arithmetic runs on the GPU through
+libbhgeo.so (include/bhgeo.h).  `trace()` is the batched form (one launch for N rays) that the
+frame driver and the pre-traced camera use (Cam edition contract, CamEdition.py:225-228).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi
+
+_METHODS = {"RK45": _ffi.METHOD_DP54, "DP54": _ffi.METHOD_DP54, "RK4": _ffi.METHOD_RK4}
+_RHS = {"christoffel": _ffi.RHS_CHRISTOFFEL, "reduced": _ffi.RHS_REDUCED}
+
+
+class GeodesicIntegratorSchwarzschild:
+    """Null-geodesic integrator around a Schwarzschild black hole of horizon radius 2*mass."""
+
+    def __init__(self, mass=1.0, time_like=False, verbose=False, *, device=0, rtol=1e-3, atol=1e-6,
+                 method="RK45", rhs_form="christoffel", h_fixed=0.1, max_steps=0, context=None):
+        if time_like:
+            # the engine only ever passes time_like=False (RelativisticRenderEngine.py:134)
+            raise NotImplementedError("only null geodesics (time_like=False) are on the GPU path")
+        if method not in _METHODS:
+            raise ValueError(f"method must be one of {sorted(_METHODS)}")
+        if rhs_form not in _RHS:
+            raise ValueError(f"rhs_form must be one of {sorted(_RHS)}")
+        self.mass = float(mass)
+        self.r_s = 2.0 * self.mass  # R_horizon = 2*M in geometrized units (:95)
+        self.time_like = False
+        self.verbose = bool(verbose)
+        self.rtol, self.atol = float(rtol), float(atol)
+        self.method, self.rhs_form = method, rhs_form
+        self.h_fixed, self.max_steps = float(h_fixed), int(max_steps)
+        self._ctx = context if context is not None else _ffi.Context(device)
+
+    # ------------------------------------------------------------------------------------
+    @property
+    def context(self) -> _ffi.Context:
+        return self._ctx
+
+    def params(self, max_step=np.inf, curve_end=50.0, r_exit=0.0) -> _ffi.Params:
+        if max_step is None or max_step == -1:  # the engine's "unset" sentinel (:59-60)
+            max_step = np.inf
+        return _ffi.make_params(r_s=self.r_s, lambda_end=curve_end, max_step=max_step, rtol=self.rtol,
+                                atol=self.atol, h_fixed=self.h_fixed, r_exit=r_exit,
+                                method=_METHODS[self.method], rhs_form=_RHS[self.rhs_form],
+                                max_steps=self.max_steps)
+
+    # ------------------------------------------------------------------------------------
+    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0):
+        """Batched solve.  k0[N,3] (or [...,3]); x0[3] shared origin or same leading shape as k0.
+
+        Returns dict with
+            ray_end[..., 6]            position (0:3) and direction (3:6) at the end of each curve
+            ray_blackhole_hit[...]     uint8, 1 where the ray ended on the horizon
+            flags[...], n_steps[...], n_accepted[...]
+        """
+        k0 = np.asarray(k0, dtype=np.float64)
+        lead = k0.shape[:-1]
+        k0f = k0.reshape(-1, 3)
+        x0 = np.asarray(x0, dtype=np.float64)
+        x0f = x0 if x0.ndim == 1 else x0.reshape(-1, 3)
+        end, flags, steps, acc = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit))
+        return {
+            "ray_end": end.reshape(lead + (6,)),
+            "ray_blackhole_hit": ((flags & _ffi.FLAG_HIT_HORIZON) != 0).astype(np.uint8).reshape(lead),
+            "flags": flags.reshape(lead),
+            "n_steps": steps.reshape(lead),
+            "n_accepted": acc.reshape(lead),
+        }
+
+    # ------------------------------------------------------------------------------------
+    def calc_trajectory(self, k0_xyz, x0_xyz, max_step=np.inf, curve_end=50, nr_points_curve=50,
+                        verbose=False, **_ignored):
+        """Per-ray drop-in for the call at RelativisticRenderEngine.py:293-294.
+
+        Returns (k_xyz, x_xyz, result): k_xyz and x_xyz have shape (3, 2) -- the start of the
+        curve and its end -- so that `x_xyz[axis][-1]` / `k_xyz[axis][-1]` (:307-308) give the
+        end location and direction.  `nr_points_curve` is accepted for signature compatibility;
+        the engine consumes only the last sample, so the intermediate samples are not produced.
+        """
+        k0 = np.asarray(k0_xyz, dtype=np.float64).reshape(3)
+        x0 = np.asarray(x0_xyz, dtype=np.float64).reshape(3)
+        out = self.trace(k0[None, :], x0, max_step=max_step, curve_end=curve_end)
+        end = out["ray_end"][0]
+        flags = int(out["flags"][0])
+        x_xyz = np.stack([x0, end[0:3]], axis=1)
+        k_xyz = np.stack([k0, end[3:6]], axis=1)
+        result = {
+            "start_inside_hole": bool(flags & _ffi.FLAG_START_INSIDE),
+            "hit_blackhole": bool(flags & _ffi.FLAG_HIT_HORIZON),
+            "flags": flags,
+            "n_steps": int(out["n_steps"][0]),
+            "n_accepted": int(out["n_accepted"][0]),
+        }
+        if verbose or self.verbose:
+            print("calc_trajectory:", result)
+        return k_xyz, x_xyz, result

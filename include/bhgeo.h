@@ -1,0 +1,141 @@
+/*
+ * bhgeo.h -- C ABI of libbhgeo.so, the MI355X (gfx950) null-geodesic ray integrator.
+ *
+ * This is the drop-in boundary for ONE path of bldevries/blackhole_geodesic_calculator: the
+ * per-ray geodesic solve the Blender render engine hands to the third-party `curvedpy` package.
+ * The reference has no FFI today -- the boundary is a Python method call per ray:
+ *
+ *     self.GeoInt = curvedpy.GeodesicIntegratorSchwarzschild(mass=, time_like=False, verbose=False)
+ *                                                   raytracer/RelativisticRenderEngine.py:134
+ *     k_xyz, x_xyz, result = self.GeoInt.calc_trajectory(k0_xyz, x0_xyz, max_step=, curve_end=,
+ *                                                   nr_points_curve=10000, verbose=False)
+ *                                                   raytracer/RelativisticRenderEngine.py:293-294
+ *
+ * and, batched per frame, the arrays of a pre-traced camera:
+ *
+ *     cam.ray_blackhole_hit[iy, ix], cam.ray_end[iy, ix, 3:6]
+ *                                                   raytracer/RelativisticRenderEngineCamEdition.py:225-228
+ *
+ * The entry points below are what a ctypes binding for that path binds (INTEGRATION.md shows the
+ * stub).  Plain pointers and sizes only; no torch / numpy types.  All floating point is IEEE fp64.
+ *
+ * Array layouts (row-major, C-contiguous):
+ *     k0    [n][3]   initial spatial direction k^i   (k0_xyz, RelativisticRenderEngine.py:287)
+ *     x0    [3]      shared origin, BH-centred       (x0_xyz, :278, :288)   -- or [n][3] per ray
+ *     end   [n][6]   {x, y, z, k_x, k_y, k_z} at the end of the curve
+ *                    (= x_xyz[:, -1], k_xyz[:, -1] at :307-308; = ray_end[..., 0:6] of the Cam edition)
+ *     flags [n]      BHG_FLAG_* bits (result['hit_blackhole'], result['start_inside_hole'], :296-297)
+ *     n_steps [n]    attempted RK steps (accepted + rejected)
+ *     n_accepted [n] accepted RK steps
+ *
+ * Threading: one bhg_context per device; calls on one context must not overlap.  Host-buffer
+ * calls block until the results are in the caller's buffers.  Device-buffer calls enqueue on the
+ * given HIP stream and return; the library keeps no pointer after the call's work completes.
+ *
+ * Errors: every int-returning function returns BHG_OK (0) or a negative BHG_E_* code;
+ * bhg_last_error() gives a thread-local message for the last failure.  There is no CPU
+ * fallback: without a usable gfx950 device the calls fail with BHG_E_NO_DEVICE.
+ */
+#ifndef BHGEO_H
+#define BHGEO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BHG_ABI_VERSION 1
+
+/* return codes */
+#define BHG_OK 0
+#define BHG_E_INVALID (-1)   /* bad argument (NULL pointer, non-finite / negative parameter) */
+#define BHG_E_NO_DEVICE (-2) /* no HIP device / device index out of range */
+#define BHG_E_HIP (-3)       /* a HIP runtime call failed; see bhg_last_error() */
+#define BHG_E_NOMEM (-4)     /* device allocation failed */
+
+/* per-ray flag bits */
+#define BHG_FLAG_HIT_HORIZON 1u     /* result['hit_blackhole']  (RelativisticRenderEngine.py:297) */
+#define BHG_FLAG_START_INSIDE 2u    /* result['start_inside_hole'] (:296, :311-313) */
+#define BHG_FLAG_REACHED_END 4u     /* lambda reached curve_end */
+#define BHG_FLAG_EXITED_SPHERE 8u   /* crossed r = r_exit outward (LimitedRelativisticRenderEngine.py:273-278) */
+#define BHG_FLAG_MAX_STEPS 16u      /* attempted-step cap hit */
+#define BHG_FLAG_STEP_TOO_SMALL 32u /* scipy's failure mode (rk.py:132-133) */
+#define BHG_FLAG_NAN 64u            /* non-finite end state */
+
+/* integrators */
+#define BHG_METHOD_DP54 0 /* Dormand-Prince 5(4) with scipy RK45's controller (README.md:196) */
+#define BHG_METHOD_RK4 1  /* classic fixed-step RK4 with step h_fixed */
+
+/* right-hand-side formulations (algebraically identical for null rays) */
+#define BHG_RHS_CHRISTOFFEL 0 /* -Gamma^i_{mu nu} k^mu k^nu, k^t from the null condition (README.md:198-209) */
+#define BHG_RHS_REDUCED 1     /* -(3/2) r_s |x cross k|^2 x / r^5 (regular at the horizon) */
+
+typedef struct bhg_params {
+    double r_s;         /* horizon radius = 2*mass                 (RelativisticRenderEngine.py:95) */
+    double lambda_end;  /* curve_end                               (:62, :294) */
+    double max_step;    /* max_step; +inf for "unset" (-1)         (:57-60) */
+    double rtol;        /* DP54 relative tolerance, scipy default 1e-3 */
+    double atol;        /* DP54 absolute tolerance, scipy default 1e-6 */
+    double h_fixed;     /* RK4 step */
+    double r_exit;      /* 0 = off; else terminate when r crosses r_exit outward */
+    int32_t method;     /* BHG_METHOD_* */
+    int32_t rhs_form;   /* BHG_RHS_* */
+    uint32_t max_steps; /* cap on attempted steps per ray; 0 = library default (1<<20) */
+    uint32_t reserved;  /* must be 0 */
+} bhg_params;
+
+typedef struct bhg_context bhg_context;
+
+/* --- library ---------------------------------------------------------------------------- */
+int bhg_version(void);                /* BHG_ABI_VERSION */
+int bhg_device_count(void);           /* number of HIP devices, 0 if none, never fails */
+const char *bhg_last_error(void);     /* thread-local, never NULL */
+void bhg_default_params(bhg_params *p); /* engine defaults: r_s=1 (mass 0.5), lambda_end=50,
+                                           max_step=inf, rtol=1e-3, atol=1e-6, DP54, Christoffel
+                                           (RelativisticRenderEngine.py:506-508; scipy rk.py:85-87) */
+
+/* --- context ---------------------------------------------------------------------------- */
+int bhg_create(int device, bhg_context **out); /* replaces the per-frame solver construction (:134) */
+void bhg_destroy(bhg_context *ctx);
+int bhg_device_name(bhg_context *ctx, char *buf, size_t buflen);
+int bhg_num_cus(bhg_context *ctx);
+
+/* --- the hot path ----------------------------------------------------------------------- */
+/* Host buffers.  Batched replacement of N calc_trajectory calls (:293-294): copies k0 (and x0)
+ * to the device, integrates all rays, copies end/flags/n_steps back.  x0_is_shared != 0: x0 is
+ * [3]; else [n][3].  flags, n_steps, n_accepted may be NULL. */
+int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared,
+              const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
+              uint32_t *n_accepted);
+
+/* Device buffers (all d_* are device addresses on ctx's device; x0_shared is a HOST [3] array or
+ * NULL when d_x0 [n][3] is given).  Enqueues on `stream` (a hipStream_t; NULL = HIP's null
+ * stream, as everywhere in HIP; bhg_context_stream() gives the context's own stream) and
+ * returns without synchronising.  Two calls on one context must not be in flight at once:
+ * they share the context's work counter. */
+int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
+                     const double *d_x0, const double *d_k0, size_t n, double *d_end,
+                     uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
+
+/* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
+ * Lets tests compare the device RHS with the oracle's term by term. */
+int bhg_acceleration(bhg_context *ctx, const bhg_params *p, const double *x, const double *k,
+                     size_t n, double *acc);
+
+/* Wait for everything enqueued on the context's own stream. */
+int bhg_synchronize(bhg_context *ctx);
+
+/* The context's own non-blocking stream (a hipStream_t), used by the host-buffer calls. */
+void *bhg_context_stream(bhg_context *ctx);
+
+/* Kernel launch geometry chosen for the last bhg_trace* call (for DESIGN/bench reporting):
+ * out[0] = workgroups, out[1] = threads per workgroup, out[2] = resident waves per CU,
+ * out[3] = 1 if the persistent lane-refill kernel ran. */
+int bhg_last_launch(bhg_context *ctx, int32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BHGEO_H */

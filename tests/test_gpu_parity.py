@@ -1,0 +1,245 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libbhgeo.so via ctypes) and is compared with the CPU oracle on identical inputs.
+
+Stated tolerances (fp64):
+  * flags, attempted and accepted step counts: identical (same controller decisions);
+  * end state: |gpu - oracle| <= 1e-8 absolute on O(1..50) values for the default controller
+    (the device kernel re-associates the RK sums in Nystrom form and uses FMA; rays that skim the
+    photon sphere amplify that 1e-16 noise by up to ~1e7), median <= 1e-12.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import CAM, GOLDEN_TRACE_SETS, frame_rays, golden_kwargs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL_END = 1e-8
+
+
+def _params(**kw):
+    from blackhole_geodesic_calculator_amd import _ffi
+    return _ffi.make_params(**kw)
+
+
+def _compare(ctx, oracle, k0, x0, tol=TOL_END, **kw):
+    o = oracle.trace(k0, x0, **kw)
+    end, flags, steps, acc = ctx.trace(k0, x0, _params(**kw))
+    assert np.array_equal(flags, o["flags"])
+    assert np.array_equal(steps, o["n_attempted"])
+    assert np.array_equal(acc, o["n_accepted"])
+    d = np.abs(end - o["end"]).max(1) if len(end) else np.zeros(0)
+    assert d.max(initial=0.0) <= tol, f"max end-state difference {d.max()}"
+    return end, flags, steps, d
+
+
+@pytest.mark.parametrize("rhs_form", [0, 1])
+@pytest.mark.parametrize("name", GOLDEN_TRACE_SETS)
+def test_golden_vectors(ctx, oracle, name, rhs_form):
+    """GPU against the committed scipy vectors AND against the oracle on the same inputs."""
+    g = load_golden(name)
+    kw = golden_kwargs(g, rhs_form)
+    end, flags, steps, d = _compare(ctx, oracle, g["k0"], g["x0"], **kw)
+    assert np.array_equal(flags, g["flags"])
+    assert np.array_equal(steps, g["n_attempted"])
+    assert np.abs(end - g["end"]).max() <= TOL_END
+    assert np.median(d) <= 1e-11
+
+
+@pytest.mark.parametrize("rhs_form", [0, 1])
+def test_acceleration_matches_oracle(ctx, oracle, rhs_form):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(4000, 3)) * 6
+    x = x[np.linalg.norm(x, axis=1) > 1.2]
+    k = rng.normal(size=x.shape)
+    a = ctx.acceleration(x, k, _params(r_s=1.0, rhs_form=rhs_form))
+    ref = oracle.acceleration(x, k, r_s=1.0, rhs_form=rhs_form)
+    rel = np.abs(a - ref).max(1) / np.abs(ref).max(1)
+    assert rel.max() < 2e-13  # Christoffel form cancels near the horizon; reduced form ~1e-15
+
+
+@pytest.mark.parametrize("rhs_form", [0, 1])
+def test_seeded_rays_default_controller(ctx, oracle, rhs_form):
+    k = frame_rays(50000, seed=21)
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, rhs_form=rhs_form)
+
+
+def test_per_ray_origins_and_ragged_sizes(ctx, oracle):
+    rng = np.random.default_rng(22)
+    for n in (1, 2, 63, 64, 65, 127, 129, 1000):
+        k = frame_rays(n, seed=n)
+        x0 = CAM + rng.normal(size=(n, 3)) * np.array([2.0, 2.0, 4.0])
+        _compare(ctx, oracle, k, x0, r_s=1.0, lambda_end=60.0)
+
+
+def test_empty_input(ctx):
+    end, flags, steps, acc = ctx.trace(np.zeros((0, 3)), CAM, _params())
+    assert end.shape == (0, 6) and flags.shape == (0,) and steps.shape == (0,)
+
+
+def test_start_inside_mixed_with_normal_rays(ctx, oracle):
+    n = 500
+    k = frame_rays(n, seed=23)
+    x0 = np.tile(CAM, (n, 1))
+    x0[::7] = np.array([0.3, -0.2, 0.4])  # inside the horizon
+    x0[5::64] = np.array([0.0, 0.0, 1.0])  # exactly on it: r0 <= r_s counts as inside
+    end, flags, steps, _ = _compare(ctx, oracle, k, x0, r_s=1.0, lambda_end=50.0)
+    inside = (flags & 2) != 0
+    assert inside.sum() == len(range(0, n, 7)) + len([i for i in range(5, n, 64) if i % 7])
+    assert np.all(steps[inside] == 0)
+    assert np.array_equal(end[inside, 0:3], x0[inside]) and np.array_equal(end[inside, 3:6], k[inside])
+
+
+def test_flat_space_and_other_masses(ctx, oracle):
+    k = frame_rays(300, seed=24)
+    end, flags, _, _ = _compare(ctx, oracle, k, CAM, r_s=0.0, lambda_end=50.0, rhs_form=1)
+    assert np.all(flags == 4)
+    assert np.abs(end[:, 0:3] - (CAM + 50.0 * k)).max() < 1e-12
+    _compare(ctx, oracle, k, CAM, r_s=0.0, lambda_end=50.0, rhs_form=0)
+    _compare(ctx, oracle, k, np.array([2.0, -1.0, 60.0]), r_s=3.0, lambda_end=120.0)
+
+
+def test_max_step_regimes(ctx, oracle):
+    k = frame_rays(600, seed=25)
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, max_step=0.1)           # R-fine, ~490 steps/ray
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, max_step=1e4)           # the engine's property default
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-8, atol=1e-10)  # tight tolerances
+
+
+def test_step_cap_and_tiny_lambda(ctx, oracle):
+    k = frame_rays(200, seed=26)
+    _, flags, steps, _ = _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, max_steps=5)
+    assert np.all((flags == 16) == (steps == 5)) and (flags == 16).any()
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=1e-3)
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=0.0)
+
+
+def test_sphere_exit_event(ctx, oracle):
+    rng = np.random.default_rng(27)
+    n = 2000
+    pos = rng.normal(size=(n, 3))
+    pos = 30.0 * pos / np.linalg.norm(pos, axis=1)[:, None]
+    aim = rng.normal(size=(n, 3)) * 5.0
+    d = aim - pos
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    end, flags, _, _ = _compare(ctx, oracle, d, pos, r_s=1.0, lambda_end=100.0, r_exit=30.0)
+    ex = flags == 8
+    assert ex.sum() > 0.8 * n
+    assert np.abs(np.linalg.norm(end[ex, 0:3], axis=1) - 30.0).max() < 1e-9
+
+
+@pytest.mark.parametrize("rhs_form", [0, 1])
+def test_rk4_fixed_step(ctx, oracle, rhs_form):
+    k = frame_rays(3000, seed=28)
+    _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.1, rhs_form=rhs_form)
+    _compare(ctx, oracle, k[:200], CAM, r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.37, rhs_form=rhs_form, r_exit=40.0)
+
+
+def test_nonfinite_input_is_flagged_not_hung(ctx):
+    k = frame_rays(130, seed=29)
+    k[3] = np.nan
+    k[77, 1] = np.inf
+    end, flags, steps, _ = ctx.trace(k, CAM, _params())
+    assert (flags[3] & 64) and (flags[77] & 64)
+    ok = np.ones(130, bool)
+    ok[[3, 77]] = False
+    assert np.all((flags[ok] & 64) == 0) and np.isfinite(end[ok]).all()
+
+
+def test_invalid_arguments_are_rejected(ctx):
+    from blackhole_geodesic_calculator_amd import _ffi
+    k = frame_rays(4, seed=1)
+    for bad in (dict(r_s=-1.0), dict(rtol=0.0), dict(lambda_end=float("nan")), dict(method=7), dict(rhs_form=5),
+                dict(max_step=0.0), dict(method=1, h_fixed=0.0)):
+        with pytest.raises(_ffi.BhgError) as ei:
+            ctx.trace(k, CAM, _params(**bad))
+        assert ei.value.code == _ffi.E_INVALID
+
+
+# ---- size-independent properties at BASELINE.json's full size (config 2: 1024 x 1024 x 5) -------
+@pytest.fixture(scope="module")
+def full_frame(ctx):
+    from blackhole_geodesic_calculator_amd import camera_directions
+    k0 = camera_directions(1024, 1024, 5, 0.6, 0.6, 42.0).reshape(-1, 3)
+    end, flags, steps, acc = ctx.trace(k0, CAM, _params(r_s=1.0, lambda_end=50.0))
+    return k0, end, flags, steps, acc
+
+
+def test_full_frame_subsample_matches_oracle(full_frame, oracle):
+    k0, end, flags, steps, acc = full_frame
+    idx = np.arange(0, len(k0), 257)
+    o = oracle.trace(k0[idx], CAM, r_s=1.0, lambda_end=50.0)
+    assert np.array_equal(flags[idx], o["flags"])
+    assert np.array_equal(steps[idx], o["n_attempted"])
+    assert np.abs(end[idx] - o["end"]).max() <= TOL_END
+    assert np.all(flags != 0) and np.all((flags & ~np.uint8(5)) == 0)  # every ray ended: horizon or lambda_end
+
+
+def test_full_frame_order_independence(ctx, full_frame):
+    """A ray's result must not depend on which lane / wave / batch traced it: permuting the
+    input permutes the output bit for bit (exercises the lane-refill queue at full size)."""
+    k0, end, flags, steps, acc = full_frame
+    perm = np.random.default_rng(31).permutation(len(k0))
+    e2, f2, s2, a2 = ctx.trace(k0[perm], CAM, _params(r_s=1.0, lambda_end=50.0))
+    assert np.array_equal(f2, flags[perm]) and np.array_equal(s2, steps[perm]) and np.array_equal(a2, acc[perm])
+    assert np.array_equal(e2, end[perm])
+
+
+def test_full_frame_mirror_symmetry(full_frame):
+    """The camera sits (almost) on the z axis: the horizon-hit fraction must match the shadow's
+    analytic size to within the loose default tolerance, and step counts must be bounded."""
+    k0, end, flags, steps, acc = full_frame
+    assert steps.max() < 200 and steps[flags == 4].min() >= 1
+    assert 0.03 < ((flags & 1) != 0).mean() < 0.08
+
+
+def test_full_frame_conservation_tight(ctx):
+    """L = x cross k and E are conserved along every escaping ray (tight tolerances)."""
+    k0 = frame_rays(1 << 20, seed=33)
+    end, flags, _, _ = ctx.trace(k0, CAM, _params(r_s=1.0, lambda_end=50.0, rtol=1e-10, atol=1e-12, rhs_form=1))
+    esc = flags == 4
+    L0 = np.cross(np.broadcast_to(CAM, k0.shape), k0)
+    L1 = np.cross(end[:, 0:3], end[:, 3:6])
+    assert np.abs(L1 - L0)[esc].max() < 1e-5
+    frac = ((flags & 1) != 0).mean()
+    # shadow of b_c = 2.598 r_s seen from r = 30: tan(alpha) ~ b_c sqrt(1 - r_s/r)/r; uniform rays in a 0.6 x 0.6 window
+    alpha = math.asin(1.5 * math.sqrt(3.0) * math.sqrt(1 - 1 / 30.0) / 30.0)
+    assert abs(frac - math.pi * math.tan(alpha) ** 2 / 0.36) < 2e-3
+
+
+def test_device_buffer_entry_point_matches_host_entry_point(ctx, full_frame):
+    import torch
+    k0, end, flags, steps, acc = full_frame
+    n = 200000
+    dk = torch.from_numpy(k0[:n]).cuda()
+    dend = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+    dfl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.trace_device(_params(r_s=1.0, lambda_end=50.0), n, dk.data_ptr(), dend.data_ptr(), x0_shared=CAM,
+                     d_flags=dfl.data_ptr(), d_n_steps=dst.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dend.cpu().numpy(), end[:n])
+    assert np.array_equal(dfl.cpu().numpy(), flags[:n])
+    assert np.array_equal(dst.cpu().numpy().astype(np.uint32), steps[:n])
+
+
+def test_calc_trajectory_adaptor(ctx, oracle):
+    """The per-ray drop-in for RelativisticRenderEngine.py:293-313."""
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, time_like=False, verbose=False, context=ctx)
+    for b in (0.5, 2.62, 5.0):
+        k0 = np.array([b / 30.0, 0.0, -1.0])
+        k0 /= np.linalg.norm(k0)
+        k_xyz, x_xyz, result = gi.calc_trajectory(k0, CAM, max_step=np.inf, curve_end=50, nr_points_curve=10000, verbose=False)
+        o = oracle.trace(k0[None], CAM, r_s=1.0, lambda_end=50.0)
+        x, y, z = x_xyz
+        k_x, k_y, k_z = k_xyz
+        end_loc = np.array([x[-1], y[-1], z[-1]])
+        end_dir = np.array([k_x[-1], k_y[-1], k_z[-1]])
+        assert result["start_inside_hole"] is False
+        assert result["hit_blackhole"] == bool(o["flags"][0] & 1)
+        assert np.abs(end_loc - o["end"][0, 0:3]).max() < TOL_END and np.abs(end_dir - o["end"][0, 3:6]).max() < TOL_END
+    _, _, result = gi.calc_trajectory(np.array([0, 0, -1.0]), np.array([0.1, 0.1, 0.1]))
+    assert result["start_inside_hole"] is True and result["hit_blackhole"] is True

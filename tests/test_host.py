@@ -1,0 +1,94 @@
+"""CPU tests of the host side: ray generation bit-reproducibility, the C-ABI library loads and
+exports every symbol include/bhgeo.h declares, argument validation, loud failure without a GPU.
+No compute call is made here."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def test_python_random_stream_is_bit_identical():
+    from blackhole_geodesic_calculator_amd import python_random_stream
+    for seed in (42.0, 42, 7.0, 123456789, 0.5):
+        random.seed(seed)
+        want = np.array([random.random() for _ in range(2000)])
+        got = python_random_stream(seed, 2000)
+        assert np.array_equal(want, got)
+    assert np.array_equal(python_random_stream(42.0, 8), load_golden("raygen")["first_draws"])
+
+
+def test_camera_directions_match_reference_loop():
+    from blackhole_geodesic_calculator_amd import camera_directions
+    g = load_golden("raygen")
+    assert np.array_equal(camera_directions(8, 6, 2, 0.6, 0.45, 42.0), g["d_8x6x2"])
+    d = camera_directions(5, 7, 3, 1.0, 1.0, 7.0, rotation_euler=(0.3, -0.2, 1.1))
+    assert np.abs(d - g["d_5x7x3_rot"]).max() < 5e-16
+    d = camera_directions(6, 6, 2, 0.6, 0.6, 42.0, mark=(1, 4, 2, 3))
+    assert np.array_equal(np.isnan(d), np.isnan(g["d_6x6x2_mark"]))
+    assert np.array_equal(np.nan_to_num(d), np.nan_to_num(g["d_6x6x2_mark"]))
+    d = camera_directions(64, 64, 1, 0.6, 0.6, 42.0).reshape(-1, 3)
+    assert np.array_equal(d, load_golden("frame64_christoffel")["k0"])
+    assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-15
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "bhgeo.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(bhg_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from blackhole_geodesic_calculator_amd import _ffi
+    lib = _ffi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 13
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/bhgeo.h but not exported"
+    assert sorted(_ffi.EXPORTS) == declared
+    assert lib.bhg_version() == _ffi.ABI_VERSION
+
+
+def test_params_struct_layout_and_defaults():
+    from blackhole_geodesic_calculator_amd import _ffi
+    assert ctypes.sizeof(_ffi.Params) == 72
+    p = _ffi.default_params()
+    assert (p.r_s, p.lambda_end, p.rtol, p.atol) == (1.0, 50.0, 1e-3, 1e-6)
+    assert p.max_step == float("inf") and p.method == _ffi.METHOD_DP54 and p.rhs_form == _ffi.RHS_CHRISTOFFEL
+
+
+def test_fails_loudly_without_gpu():
+    from blackhole_geodesic_calculator_amd import _ffi
+    if _ffi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_ffi.BhgError) as ei:
+        _ffi.Context(0)
+    assert ei.value.code == _ffi.E_NO_DEVICE
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    with pytest.raises(_ffi.BhgError):
+        GeodesicIntegratorSchwarzschild(mass=0.5)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "blackhole_geodesic_calculator_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "geodesic_oracle" not in src, f
+
+
+def test_integrator_argument_checks():
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    with pytest.raises(NotImplementedError):
+        GeodesicIntegratorSchwarzschild(mass=0.5, time_like=True, context=object())
+    with pytest.raises(ValueError):
+        GeodesicIntegratorSchwarzschild(mass=0.5, method="LSODA", context=object())
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=object())
+    assert gi.r_s == 1.0
+    assert gi.params(max_step=-1).max_step == float("inf")

@@ -1,0 +1,140 @@
+"""CPU tests: the C oracle (oracle/geodesic_oracle.c) against the committed scipy golden vectors,
+against scipy.solve_ivp run live, and against physics known answers.
+The oracle is the checker for the GPU path; this file is what pins the checker."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import CAM, GOLDEN_TRACE_SETS, frame_rays, golden_kwargs, load_golden
+
+
+@pytest.mark.parametrize("name", GOLDEN_TRACE_SETS)
+def test_oracle_matches_scipy_golden(oracle, name):
+    g = load_golden(name)
+    form = 1 if name.endswith("reduced") else 0
+    o = oracle.trace(g["k0"], g["x0"], **golden_kwargs(g, form))
+    assert np.array_equal(o["flags"], g["flags"])
+    assert np.array_equal(o["n_attempted"], g["n_attempted"])  # same accept/reject decisions as scipy
+    assert np.array_equal(o["n_accepted"], g["n_accepted"])
+    # tolerance: fp64 reassociation noise amplified along the curve; 5e-10 absolute on O(10) values
+    assert np.abs(o["end"] - g["end"]).max() < 5e-10
+    assert np.abs(o["t_end"] - g["t_end"]).max() < 1e-10
+
+
+def test_oracle_matches_live_scipy(oracle):
+    """scipy is importable wherever the tests run: compare step-for-step on fresh rays."""
+    from oracle import scipy_reference as sr
+    k = frame_rays(24, seed=11)
+    ref = sr.trace_rays(k, CAM, r_s=1.0, lambda_end=50.0, form="christoffel")
+    o = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rhs_form=0)
+    assert np.array_equal(o["flags"], ref["flags"])
+    assert np.array_equal(o["n_attempted"], ref["n_attempted"])
+    assert np.abs(o["end"] - ref["end"]).max() < 5e-10
+
+
+def test_rhs_forms_agree(oracle):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(500, 3)) * 6
+    x = x[np.linalg.norm(x, axis=1) > 1.3]
+    k = rng.normal(size=x.shape)
+    a0 = oracle.acceleration(x, k, r_s=1.0, rhs_form=0)
+    a1 = oracle.acceleration(x, k, r_s=1.0, rhs_form=1)
+    scale = np.abs(a1).max(1)
+    assert (np.abs(a0 - a1).max(1) / scale).max() < 1e-12
+
+
+def test_rhs_matches_sympy_contraction(oracle):
+    from oracle import scipy_reference as sr
+    fn = sr.sympy_christoffel_rhs()
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(100, 3)) * 5
+    x = x[np.linalg.norm(x, axis=1) > 1.3]
+    k = rng.normal(size=x.shape)
+    a = oracle.acceleration(x, k, r_s=1.0, rhs_form=0)
+    for i in range(len(x)):
+        ref = np.array(fn(x[i, 0], x[i, 1], x[i, 2], k[i, 0], k[i, 1], k[i, 2], 1.0))
+        assert np.abs(a[i] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_flat_limit_is_straight_line(oracle):
+    k = frame_rays(50, seed=2)
+    o = oracle.trace(k, CAM, r_s=0.0, lambda_end=50.0, rhs_form=1)
+    assert np.all(o["flags"] == oracle.FLAG_REACHED_END)
+    assert np.abs(o["end"][:, 0:3] - (CAM + 50.0 * k)).max() < 1e-12
+    assert np.abs(o["end"][:, 3:6] - k).max() < 1e-15
+
+
+def test_fig5_deflection_known_answers(oracle):
+    """README Fig. 5 geometry: x0 = -15 r_s, k = (1,0,0); asymptotic deflection angles."""
+    g = load_golden("fig5")
+    want = {3.0: 98.075, 4.0: 48.98, 5.0: 33.62, 10.0: 13.16, 19.0: 5.875}
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=4000.0, rtol=1e-11, atol=1e-13, rhs_form=1)
+    defl = np.degrees(np.arctan2(-o["end"][:, 4], o["end"][:, 3]))
+    assert np.abs(defl - g["deflection_deg_converged"]).max() < 1e-5
+    for i, y0 in enumerate(g["x0"][:, 1]):
+        if float(y0) in want:
+            assert abs(defl[i] - want[float(y0)]) < 6e-3
+
+
+def test_capture_threshold(oracle):
+    """b_c = 3 sqrt(3)/2 r_s = 2.598: rays below are captured, above escape."""
+    g = load_golden("capture")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=200.0, rtol=1e-10, atol=1e-12, rhs_form=1)
+    hit = (o["flags"] & oracle.FLAG_HIT_HORIZON) != 0
+    b = g["x0"][:, 1]
+    assert np.array_equal(hit, b < 1.5 * math.sqrt(3.0))
+    assert np.array_equal(hit.astype(np.uint8), g["hit_converged"])
+
+
+def test_conserved_quantities(oracle):
+    k = frame_rays(200, seed=5)
+    o = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-10, atol=1e-12, rhs_form=0)
+    esc = o["flags"] == oracle.FLAG_REACHED_END
+    L0 = np.cross(np.broadcast_to(CAM, k.shape), k)
+    L1 = np.cross(o["end"][:, 0:3], o["end"][:, 3:6])
+    assert np.abs(L1 - L0)[esc].max() < 1e-6
+    # E = f k^t with (k^t)^2 from the null condition
+    def energy(x, kk):
+        r = np.linalg.norm(x, axis=1)
+        n = x / r[:, None]
+        nk = (n * kk).sum(1)
+        f = 1 - 1.0 / r
+        kt2 = ((kk * kk).sum(1) + (1.0 / (r - 1.0)) * nk * nk) / f
+        return f * np.sqrt(kt2)
+    e0 = energy(np.broadcast_to(CAM, k.shape), k)
+    e1 = energy(o["end"][:, 0:3], o["end"][:, 3:6])
+    assert np.abs(e1 / e0 - 1)[esc].max() < 1e-7
+
+
+def test_rotation_equivariance(oracle):
+    k = frame_rays(64, seed=6)
+    th = 0.7
+    R = np.array([[math.cos(th), -math.sin(th), 0], [math.sin(th), math.cos(th), 0], [0, 0, 1]]) @ \
+        np.array([[1, 0, 0], [0, math.cos(0.4), -math.sin(0.4)], [0, math.sin(0.4), math.cos(0.4)]])
+    kw = dict(r_s=1.0, lambda_end=50.0, rtol=1e-10, atol=1e-12, rhs_form=1)
+    a = oracle.trace(k, CAM, **kw)
+    b = oracle.trace(k @ R.T, R @ CAM, **kw)
+    assert np.array_equal(a["flags"], b["flags"])
+    esc = a["flags"] == oracle.FLAG_REACHED_END
+    assert np.abs(a["end"][:, 0:3] @ R.T - b["end"][:, 0:3])[esc].max() < 1e-5
+    assert np.abs(a["end"][:, 3:6] @ R.T - b["end"][:, 3:6])[esc].max() < 1e-6
+
+
+def test_start_inside_and_caps(oracle):
+    k = frame_rays(4, seed=7)
+    o = oracle.trace(k, np.array([0.3, 0.2, 0.1]), r_s=1.0, lambda_end=50.0)
+    assert np.all(o["flags"] == (oracle.FLAG_START_INSIDE | oracle.FLAG_HIT_HORIZON))
+    assert np.all(o["n_attempted"] == 0)
+    o = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, max_steps=3)
+    assert np.all(o["flags"] == oracle.FLAG_MAX_STEPS) and np.all(o["n_attempted"] == 3)
+
+
+def test_rk4_converges_to_dp54(oracle):
+    k = frame_rays(32, seed=8)
+    a = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.02, rhs_form=1)
+    b = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-11, atol=1e-13, rhs_form=1)
+    same = a["flags"] == b["flags"]
+    assert same.mean() > 0.9
+    esc = same & (a["flags"] == oracle.FLAG_REACHED_END)
+    assert np.median(np.abs(a["end"] - b["end"])[esc].max(1)) < 1e-5
