@@ -17,6 +17,9 @@
 //     filled 64 rays at a time by ALL lanes together (coalesced k0 loads, the scipy initial-step
 //     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
 //     always runs converged and the integrate loop always runs (nearly) full;
+//   * a lane whose accepted step crosses the horizon / exit sphere parks the step in a per-wave
+//     LDS event queue and refills at once; the wave drains that queue converged (recompute the
+//     step, quartic dense output, Brent root) so the rare root search never runs one lane wide;
 //   * work is handed out in 64-ray batches from one device counter, fetched one batch ahead;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
 //     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
@@ -325,21 +328,61 @@ __device__ __forceinline__ double brent_root(const F &g, double xa, double xb)
     return xcur;
 }
 
+// x^(1/5) for the initial-step heuristic (common.py:131): fp32 seed + one cubic Newton step on
+// z = x^(-1/5), then x^(1/5) = x z^4.
+__device__ __forceinline__ double pow_0p2(double x)
+{
+    float xf = (float)x;
+    float s = __builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
+    double z = (double)s;
+    double z2 = z * z;
+    double z4 = z2 * z2;
+    double z5 = z4 * z;
+    double t = __builtin_fma(-x, z5, 1.0);
+    double p = __builtin_fma(0.12, t, 0.2);  // (1-t)^(-1/5) = 1 + t/5 + 3/25 t^2 + ...
+    double u = z * t;
+    z = __builtin_fma(u, p, z);
+    z2 = z * z;
+    return x * (z2 * z2);
+}
+
 // ------------------------------------------------------------------------------------------
-// Per-wave LDS queue of prepared rays (filled converged, drained lane by lane)
+// Per-wave LDS: a queue of prepared rays (filled converged, drained lane by lane) and a queue
+// of steps that crossed the horizon / exit sphere (filled lane by lane, drained converged).
 // ------------------------------------------------------------------------------------------
-struct WaveQueue {
-    double x[3][64];
-    double k[3][64];
-    double a[3][64];   // FSAL acceleration at the start point
-    double h[64];      // initial |h| (common.py:68-134)
-    double r[64];      // r at the start point
-    uint32_t idx[64];
+constexpr int EVQ_CAP = 32;
+
+struct WaveLds {
+    // prepared rays
+    double qx[3][64];
+    double qk[3][64];
+    double qa[3][64];  // FSAL acceleration at the start point
+    double qh[64];     // initial |h| (common.py:68-134)
+    double qr[64];     // r at the start point
+    uint32_t qidx[64];
+    // pending terminal events: the step's start state; the step is recomputed when drained
+    double ex[3][EVQ_CAP];
+    double ev[3][EVQ_CAP];
+    double ea[3][EVQ_CAP];
+    double et[EVQ_CAP];
+    double eh[EVQ_CAP];
+    uint32_t eidx[EVQ_CAP];
+    uint32_t enatt[EVQ_CAP];
+    uint32_t enacc[EVQ_CAP];
+    uint32_t ekind[EVQ_CAP];
 };
 
-struct Result {
-    double x[3], v[3];
-    uint32_t flags, n_att, n_acc;
+struct Lane {
+    double x[3], v[3], a1[3];
+    double t, h_abs, r_cur;
+    uint32_t idx, n_att, n_acc;
+    bool active, rejected;
+};
+
+struct Wave {
+    int q_head, q_count, e_count;
+    bool exhausted;
+    uint64_t next_base;
 };
 
 __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
@@ -359,378 +402,314 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     if (A.n_accepted) A.n_accepted[idx] = n_acc;
 }
 
-// ------------------------------------------------------------------------------------------
-// Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
-// ------------------------------------------------------------------------------------------
-template <int RHS, bool HAS_EXIT>
-__global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
+__device__ __forceinline__ uint64_t fetch_batch(const TraceArgs &A, uint32_t lane)
 {
-    __shared__ WaveQueue Q;
-    const uint32_t lane = threadIdx.x;
-    const double r_s = A.r_s, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
-    const double max_step = A.max_step;
-    const uint64_t n = A.n;
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd(A.counter, 64ull);
+    return __builtin_amdgcn_readfirstlane((uint32_t)b) |
+           ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+}
 
-    // per-lane ray state
-    bool active = false;
-    bool rejected = false;
-    double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
-    double t = 0.0, h_abs = 0.0, r_cur = 0.0;
-    uint32_t idx = 0, n_att = 0, n_acc = 0;
-
-    // wave-uniform queue state
-    int q_head = 0, q_count = 0;
-    bool exhausted = false;
-    uint64_t next_base;
-    {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(A.counter, 64ull);
-        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
-                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+// Converged setup of rays base .. base+63: coalesced loads, start-inside test, f0, and (DP54)
+// the Hairer initial step; survivors are compacted into the LDS ray queue with ballot/mbcnt.
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ void prepare_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane,
+                                              uint64_t base)
+{
+    const double r_s = A.r_s;
+    const uint64_t i = base + lane;
+    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = 0.0;
+    bool valid = false;
+    if (i < A.n) {
+        pk[0] = A.k0[i * 3 + 0];
+        pk[1] = A.k0[i * 3 + 1];
+        pk[2] = A.k0[i * 3 + 2];
+        if (A.x0) {
+            px[0] = A.x0[i * 3 + 0];
+            px[1] = A.x0[i * 3 + 1];
+            px[2] = A.x0[i * 3 + 2];
+        } else {
+            px[0] = A.x0s[0];
+            px[1] = A.x0s[1];
+            px[2] = A.x0s[2];
+        }
+        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+        if (r0 <= r_s) {
+            // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
+            store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+        } else {
+            valid = true;
+            accel<RHS>(px, pk, r_s, pa, pr);
+            if (ADAPTIVE) {
+                // select_initial_step (common.py:68-134) with order = 4
+                const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+                double isc[6];
+                double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
+                    double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
+                    isc[c] = sk;
+                    isc[3 + c] = sx;
+                    double y0k = pk[c] * sk, y0x = px[c] * sx;
+                    double f0k = pa[c] * sk, f0x = pk[c] * sx;
+                    d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
+                    d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
+                }
+                d0 = sqrt(d0 * (1.0 / 6.0));
+                d1 = sqrt(d1 * (1.0 / 6.0));
+                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+                h0 = fmin(h0, t_bound);
+                double x1[3], k1[3], f1[3], r1;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    x1[c] = __builtin_fma(h0, pk[c], px[c]);
+                    k1[c] = __builtin_fma(h0, pa[c], pk[c]);
+                }
+                accel<RHS>(x1, k1, r_s, f1, r1);
+                double d2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double dk = (f1[c] - pa[c]) * isc[c];
+                    double dx = (k1[c] - pk[c]) * isc[3 + c];
+                    d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
+                }
+                d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
+                double h1;
+                if (d1 <= 1e-15 && d2 <= 1e-15) {
+                    h1 = fmax(1e-6, h0 * 1e-3);
+                } else {
+                    double q = 0.01 / fmax(d1, d2);
+                    // the fast path needs a normal fp32 range; outside it (degenerate inputs) use libm
+                    h1 = (q > 1e-30 && q < 1e30) ? pow_0p2(q) : pow(q, 0.2);
+                }
+                ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, A.max_step));
+            }
+        }
     }
+    const uint64_t vmask = __ballot(valid);
+    if (valid) {
+        const uint32_t s = lane_rank(vmask);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            Q.qx[c][s] = px[c];
+            Q.qk[c][s] = pk[c];
+            Q.qa[c][s] = pa[c];
+        }
+        Q.qh[s] = ph;
+        Q.qr[s] = pr;
+        Q.qidx[s] = (uint32_t)i;
+    }
+    wave_lds_sync();
+    W.q_head = 0;
+    W.q_count = __builtin_popcountll(vmask);
+}
 
+// Give idle lanes new rays.  Returns the idle mask afterwards (all ones: nothing left at all).
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave &W, Lane &L, uint32_t lane,
+                                           uint64_t idle)
+{
     for (;;) {
-        uint64_t idle = __ballot(!active);
-        if (idle) {
-            for (;;) {
-                if (q_count == 0) {
-                    if (exhausted) break;
-                    const uint64_t base = next_base;
-                    if (base >= n) {
-                        exhausted = true;
-                        break;
-                    }
-                    {
-                        unsigned long long b = 0;
-                        if (lane == 0) b = atomicAdd(A.counter, 64ull);
-                        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
-                                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
-                    }
-                    // ---- converged setup of rays base .. base+63 -------------------------
-                    const uint64_t i = base + lane;
-                    const bool have = i < n;
-                    double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
-                    bool valid = false;
-                    if (have) {
-                        pk[0] = A.k0[i * 3 + 0];
-                        pk[1] = A.k0[i * 3 + 1];
-                        pk[2] = A.k0[i * 3 + 2];
-                        if (A.x0) {
-                            px[0] = A.x0[i * 3 + 0];
-                            px[1] = A.x0[i * 3 + 1];
-                            px[2] = A.x0[i * 3 + 2];
-                        } else {
-                            px[0] = A.x0s[0];
-                            px[1] = A.x0s[1];
-                            px[2] = A.x0s[2];
-                        }
-                        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
-                        if (r0 <= r_s) {
-                            // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
-                            store_result(A, (uint32_t)i, px, pk,
-                                         BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
-                        } else {
-                            valid = true;
-                            // f0 and the Hairer initial step (common.py:68-134, order = 4)
-                            accel<RHS>(px, pk, r_s, pa, pr);
-                            double isc[6];
-                            double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
-                                double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
-                                isc[c] = sk;
-                                isc[3 + c] = sx;
-                                double y0k = pk[c] * sk, y0x = px[c] * sx;
-                                double f0k = pa[c] * sk, f0x = pk[c] * sx;
-                                d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
-                                d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
-                            }
-                            d0 = sqrt(d0 * (1.0 / 6.0));
-                            d1 = sqrt(d1 * (1.0 / 6.0));
-                            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                            h0 = fmin(h0, t_bound);
-                            double x1[3], k1[3], f1[3], r1;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                x1[c] = __builtin_fma(h0, pk[c], px[c]);
-                                k1[c] = __builtin_fma(h0, pa[c], pk[c]);
-                            }
-                            accel<RHS>(x1, k1, r_s, f1, r1);
-                            double d2 = 0.0;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                double dk = (f1[c] - pa[c]) * isc[c];
-                                double dx = (k1[c] - pk[c]) * isc[3 + c];
-                                d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
-                            }
-                            d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
-                            double h1;
-                            if (d1 <= 1e-15 && d2 <= 1e-15)
-                                h1 = fmax(1e-6, h0 * 1e-3);
-                            else
-                                h1 = pow(0.01 / fmax(d1, d2), 0.2);
-                            ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, max_step));
-                        }
-                    }
-                    const uint64_t vmask = __ballot(valid);
-                    if (valid) {
-                        const uint32_t s = lane_rank(vmask);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            Q.x[c][s] = px[c];
-                            Q.k[c][s] = pk[c];
-                            Q.a[c][s] = pa[c];
-                        }
-                        Q.h[s] = ph;
-                        Q.r[s] = pr;
-                        Q.idx[s] = (uint32_t)i;
-                    }
-                    wave_lds_sync();
-                    q_head = 0;
-                    q_count = __builtin_popcountll(vmask);
-                    if (q_count == 0) continue;
-                }
-                const int n_idle = __builtin_popcountll(idle);
-                const int take = n_idle < q_count ? n_idle : q_count;
-                if (!active) {
-                    const int rk = (int)lane_rank(idle);
-                    if (rk < take) {
-                        const int s = q_head + rk;
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            x[c] = Q.x[c][s];
-                            v[c] = Q.k[c][s];
-                            a1[c] = Q.a[c][s];
-                        }
-                        h_abs = Q.h[s];
-                        r_cur = Q.r[s];
-                        idx = Q.idx[s];
-                        t = 0.0;
-                        n_att = 0;
-                        n_acc = 0;
-                        rejected = false;
-                        active = true;
-                    }
-                }
-                wave_lds_sync();
-                q_head += take;
-                q_count -= take;
-                idle = __ballot(!active);
-                if (!idle) break;
+        if (W.q_count == 0) {
+            if (W.exhausted) break;
+            const uint64_t base = W.next_base;
+            if (base >= A.n) {
+                W.exhausted = true;
+                break;
             }
-            if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
+            W.next_base = fetch_batch(A, lane);  // one batch ahead: latency hidden behind the setup
+            prepare_batch<RHS, ADAPTIVE>(A, Q, W, lane, base);
+            if (W.q_count == 0) continue;
         }
-
-        if (active) {
-            // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
-            uint32_t term = 0;
-            const double min_step = 10.0 * ulp_of(t);
-            if (!rejected) {
-                if (h_abs > max_step)
-                    h_abs = max_step;
-                else if (h_abs < min_step)
-                    h_abs = min_step;
-            }
-            if (h_abs < min_step)
-                term = BHG_FLAG_STEP_TOO_SMALL_;
-            else if (n_att >= A.max_steps)
-                term = BHG_FLAG_MAX_STEPS_;
-            if (term == 0 && t == t_bound) term = BHG_FLAG_REACHED_END_;  // base.py:189-194
-            if (term) {
-                store_result(A, idx, x, v, term, n_att, n_acc);
-                active = false;
-            } else {
-                double t_new = t + h_abs;
-                if (t_new - t_bound > 0.0) t_new = t_bound;
-                const double h = t_new - t;
-                h_abs = fabs(h);
-                const double h2 = h * h;
-
-                double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3];
-                double xs[3], vs[3], rs_;
-                // stage 2
+        const int n_idle = __builtin_popcountll(idle);
+        const int take = n_idle < W.q_count ? n_idle : W.q_count;
+        if (!L.active) {
+            const int rk = (int)lane_rank(idle);
+            if (rk < take) {
+                const int s = W.q_head + rk;
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    vs[c] = __builtin_fma(h * TB.a[2][1], a1[c], v[c]);
-                    xs[c] = __builtin_fma(h * TB.c[2], v[c], x[c]);
+                    L.x[c] = Q.qx[c][s];
+                    L.v[c] = Q.qk[c][s];
+                    L.a1[c] = Q.qa[c][s];
                 }
-                accel<RHS>(xs, vs, r_s, a2, rs_);
-                // stage 3
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sv = __builtin_fma(TB.a[3][2], a2[c], TB.a[3][1] * a1[c]);
-                    vs[c] = __builtin_fma(h, sv, v[c]);
-                    double sx = TB.at[3][1] * a1[c];
-                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[3], v[c], x[c]));
-                }
-                accel<RHS>(xs, vs, r_s, a3, rs_);
-                // stage 4
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sv = __builtin_fma(TB.a[4][3], a3[c],
-                                              __builtin_fma(TB.a[4][2], a2[c], TB.a[4][1] * a1[c]));
-                    vs[c] = __builtin_fma(h, sv, v[c]);
-                    double sx = __builtin_fma(TB.at[4][2], a2[c], TB.at[4][1] * a1[c]);
-                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[4], v[c], x[c]));
-                }
-                accel<RHS>(xs, vs, r_s, a4, rs_);
-                // stage 5
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sv = __builtin_fma(
-                        TB.a[5][4], a4[c],
-                        __builtin_fma(TB.a[5][3], a3[c],
-                                      __builtin_fma(TB.a[5][2], a2[c], TB.a[5][1] * a1[c])));
-                    vs[c] = __builtin_fma(h, sv, v[c]);
-                    double sx = __builtin_fma(TB.at[5][3], a3[c],
-                                              __builtin_fma(TB.at[5][2], a2[c], TB.at[5][1] * a1[c]));
-                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[5], v[c], x[c]));
-                }
-                accel<RHS>(xs, vs, r_s, a5, rs_);
-                // stage 6
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sv = __builtin_fma(
-                        TB.a[6][5], a5[c],
-                        __builtin_fma(TB.a[6][4], a4[c],
-                                      __builtin_fma(TB.a[6][3], a3[c],
-                                                    __builtin_fma(TB.a[6][2], a2[c], TB.a[6][1] * a1[c]))));
-                    vs[c] = __builtin_fma(h, sv, v[c]);
-                    double sx = __builtin_fma(
-                        TB.at[6][4], a4[c],
-                        __builtin_fma(TB.at[6][3], a3[c],
-                                      __builtin_fma(TB.at[6][2], a2[c], TB.at[6][1] * a1[c])));
-                    xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[6], v[c], x[c]));
-                }
-                accel<RHS>(xs, vs, r_s, a6, rs_);
-                // new solution (stage 7 = FSAL; b_2 = 0)
-                double xn[3], vn[3], r_new;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sv = __builtin_fma(
-                        TB.a[7][6], a6[c],
-                        __builtin_fma(TB.a[7][5], a5[c],
-                                      __builtin_fma(TB.a[7][4], a4[c],
-                                                    __builtin_fma(TB.a[7][3], a3[c], TB.a[7][1] * a1[c]))));
-                    vn[c] = __builtin_fma(h, sv, v[c]);
-                    double sx = __builtin_fma(
-                        TB.at[7][5], a5[c],
-                        __builtin_fma(TB.at[7][4], a4[c],
-                                      __builtin_fma(TB.at[7][3], a3[c],
-                                                    __builtin_fma(TB.at[7][2], a2[c], TB.at[7][1] * a1[c]))));
-                    xn[c] = __builtin_fma(h2, sx, __builtin_fma(h, v[c], x[c]));
-                }
-                accel<RHS>(xn, vn, r_s, a7, r_new);
-                n_att++;
-
-                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components
-                double errsq = 0.0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double ev = __builtin_fma(
-                        TB.e[7], a7[c],
-                        __builtin_fma(TB.e[6], a6[c],
-                                      __builtin_fma(TB.e[5], a5[c],
-                                                    __builtin_fma(TB.e[4], a4[c],
-                                                                  __builtin_fma(TB.e[3], a3[c], TB.e[1] * a1[c])))));
-                    ev *= h;
-                    double ex = __builtin_fma(
-                        TB.et[6], a6[c],
-                        __builtin_fma(TB.et[5], a5[c],
-                                      __builtin_fma(TB.et[4], a4[c],
-                                                    __builtin_fma(TB.et[3], a3[c],
-                                                                  __builtin_fma(TB.et[2], a2[c], TB.et[1] * a1[c])))));
-                    ex *= h2;
-                    double scv = __builtin_fma(fmax(fabs(v[c]), fabs(vn[c])), rtol, atol);
-                    double scx = __builtin_fma(fmax(fabs(x[c]), fabs(xn[c])), rtol, atol);
-                    double qv = ev * rcp_nr(scv);
-                    double qx = ex * rcp_nr(scx);
-                    errsq = __builtin_fma(qv, qv, __builtin_fma(qx, qx, errsq));
-                }
-                errsq *= (1.0 / 6.0);
-                // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
-                if (!(r_new == r_new)) errsq = __builtin_nan("");
-
-                // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
-                double fac;
-                if (errsq < 3.4e6) {
-                    fac = 0.9 * pow_m0p1(fmax(errsq, 1e-11));
-                } else {
-                    fac = 0.2;  // also the NaN case: python max(0.2, nan) == 0.2
-                }
-                if (errsq < 1.0) {
-                    fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
-                    if (rejected) fac = fmin(1.0, fac);
-                    h_abs *= fac;
-                    rejected = false;
-                    n_acc++;
-
-                    // events between step ends (ivp.py:109-126): horizon any direction, exit outward
-                    const bool ev_h = ((r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
-                                      ((r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
-                    const bool ev_e = HAS_EXIT && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    if (ev_h || ev_e) {
-                        Dense d;
-                        d.t0 = t;
-                        d.h = h;
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            d.x0[c] = x[c];
-                            d.v0[c] = v[c];
-#pragma unroll
-                            for (int m = 0; m < 4; m++) {
-                                double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] +
-                                            TB.p[5][m] * a5[c] + TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
-                                double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] +
-                                            TB.pt[4][m] * a4[c] + TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
-                                d.qv[m][c] = qv;
-                                d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
-                            }
-                        }
-                        double rh = 0.0, re = 0.0;
-                        if (ev_h) rh = brent_root([&](double tt) { return dense_g(d, tt, r_s); }, t, t_new);
-                        if (ev_e) re = brent_root([&](double tt) { return dense_g(d, tt, A.r_exit); }, t, t_new);
-                        double t_root;
-                        uint32_t fl;
-                        if (ev_h && (!ev_e || rh <= re)) {
-                            t_root = rh;
-                            fl = BHG_FLAG_HIT_HORIZON_;
-                        } else {
-                            t_root = re;
-                            fl = BHG_FLAG_EXITED_SPHERE_;
-                        }
-                        double xe[3], ve[3];
-                        dense_pos(d, t_root, xe);
-                        dense_dir(d, t_root, ve);
-                        store_result(A, idx, xe, ve, fl, n_att, n_acc);
-                        active = false;
-                    } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
-                        store_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_, n_att, n_acc);
-                        active = false;
-                    } else {
-                        t = t_new;
-                        r_cur = r_new;
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            x[c] = xn[c];
-                            v[c] = vn[c];
-                            a1[c] = a7[c];
-                        }
-                    }
-                } else {
-                    h_abs *= fmax(0.2, fac);
-                    rejected = true;
-                }
+                L.h_abs = Q.qh[s];
+                L.r_cur = Q.qr[s];
+                L.idx = Q.qidx[s];
+                L.t = 0.0;
+                L.n_att = 0;
+                L.n_acc = 0;
+                L.rejected = false;
+                L.active = true;
             }
         }
+        wave_lds_sync();
+        W.q_head += take;
+        W.q_count -= take;
+        idle = __ballot(!L.active);
+        if (!idle) break;
     }
+    return idle;
 }
 
 // ------------------------------------------------------------------------------------------
-// Fixed-step classic RK4 ("R-fine" regime, SURVEY.md 8d).  Same persistent lane-refill wave.
-// Events are located on the cubic Hermite interpolant of the step.
+// One Dormand-Prince step in Nystrom form: stages 2..7 from (x, v, a1, h).
+// Used by the integrate loop AND by the event drain, so both see bit-identical stage values
+// (the library is built with -ffp-contract=off; every FMA below is explicit).
 // ------------------------------------------------------------------------------------------
+template <int RHS>
+__device__ __forceinline__ void dp54_stages(const double x[3], const double v[3], const double a1[3], double h,
+                                            double r_s, double a2[3], double a3[3], double a4[3], double a5[3],
+                                            double a6[3], double a7[3], double xn[3], double vn[3], double &r_new)
+{
+    const double h2 = h * h;
+    double xs[3], vs[3], rs_;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        vs[c] = __builtin_fma(h * TB.a[2][1], a1[c], v[c]);
+        xs[c] = __builtin_fma(h * TB.c[2], v[c], x[c]);
+    }
+    accel<RHS>(xs, vs, r_s, a2, rs_);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sv = __builtin_fma(TB.a[3][2], a2[c], TB.a[3][1] * a1[c]);
+        vs[c] = __builtin_fma(h, sv, v[c]);
+        double sx = TB.at[3][1] * a1[c];
+        xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[3], v[c], x[c]));
+    }
+    accel<RHS>(xs, vs, r_s, a3, rs_);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sv = __builtin_fma(TB.a[4][3], a3[c], __builtin_fma(TB.a[4][2], a2[c], TB.a[4][1] * a1[c]));
+        vs[c] = __builtin_fma(h, sv, v[c]);
+        double sx = __builtin_fma(TB.at[4][2], a2[c], TB.at[4][1] * a1[c]);
+        xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[4], v[c], x[c]));
+    }
+    accel<RHS>(xs, vs, r_s, a4, rs_);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sv = __builtin_fma(
+            TB.a[5][4], a4[c],
+            __builtin_fma(TB.a[5][3], a3[c], __builtin_fma(TB.a[5][2], a2[c], TB.a[5][1] * a1[c])));
+        vs[c] = __builtin_fma(h, sv, v[c]);
+        double sx = __builtin_fma(TB.at[5][3], a3[c], __builtin_fma(TB.at[5][2], a2[c], TB.at[5][1] * a1[c]));
+        xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[5], v[c], x[c]));
+    }
+    accel<RHS>(xs, vs, r_s, a5, rs_);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sv = __builtin_fma(
+            TB.a[6][5], a5[c],
+            __builtin_fma(TB.a[6][4], a4[c],
+                          __builtin_fma(TB.a[6][3], a3[c], __builtin_fma(TB.a[6][2], a2[c], TB.a[6][1] * a1[c]))));
+        vs[c] = __builtin_fma(h, sv, v[c]);
+        double sx = __builtin_fma(
+            TB.at[6][4], a4[c],
+            __builtin_fma(TB.at[6][3], a3[c], __builtin_fma(TB.at[6][2], a2[c], TB.at[6][1] * a1[c])));
+        xs[c] = __builtin_fma(h2, sx, __builtin_fma(h * TB.c[6], v[c], x[c]));
+    }
+    accel<RHS>(xs, vs, r_s, a6, rs_);
+    // new solution (stage 7 = FSAL; b_2 = 0)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sv = __builtin_fma(
+            TB.a[7][6], a6[c],
+            __builtin_fma(TB.a[7][5], a5[c],
+                          __builtin_fma(TB.a[7][4], a4[c], __builtin_fma(TB.a[7][3], a3[c], TB.a[7][1] * a1[c]))));
+        vn[c] = __builtin_fma(h, sv, v[c]);
+        double sx = __builtin_fma(
+            TB.at[7][5], a5[c],
+            __builtin_fma(TB.at[7][4], a4[c],
+                          __builtin_fma(TB.at[7][3], a3[c], __builtin_fma(TB.at[7][2], a2[c], TB.at[7][1] * a1[c]))));
+        xn[c] = __builtin_fma(h2, sx, __builtin_fma(h, v[c], x[c]));
+    }
+    accel<RHS>(xn, vn, r_s, a7, r_new);
+}
+
+constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u;
+
+// Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
+// Runs converged on the lanes of the event drain: the step is recomputed from its start state.
+template <int RHS>
+__device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
+                                                   const double a1[3], double t, double h, uint32_t kind,
+                                                   uint32_t idx, uint32_t n_att, uint32_t n_acc)
+{
+    double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+    dp54_stages<RHS>(x, v, a1, h, A.r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+    Dense d;
+    d.t0 = t;
+    d.h = h;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        d.x0[c] = x[c];
+        d.v0[c] = v[c];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] + TB.p[5][m] * a5[c] +
+                        TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
+            double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] + TB.pt[4][m] * a4[c] +
+                        TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
+            d.qv[m][c] = qv;
+            d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
+        }
+    }
+    const double t_new = t + h;
+    double rh = 0.0, re = 0.0;
+    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return dense_g(d, tt, A.r_s); }, t, t_new);
+    if (kind & EV_EXIT) re = brent_root([&](double tt) { return dense_g(d, tt, A.r_exit); }, t, t_new);
+    double t_root;
+    uint32_t fl;
+    if ((kind & EV_HORIZON) && (!(kind & EV_EXIT) || rh <= re)) {  // earliest root wins (ivp.py:111-122)
+        t_root = rh;
+        fl = BHG_FLAG_HIT_HORIZON_;
+    } else {
+        t_root = re;
+        fl = BHG_FLAG_EXITED_SPHERE_;
+    }
+    double xe[3], ve[3];
+    dense_pos(d, t_root, xe);
+    dense_dir(d, t_root, ve);
+    store_result(A, idx, xe, ve, fl, n_att, n_acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fixed-step classic RK4 step and its event resolution (cubic Hermite interpolant of the step)
+// ------------------------------------------------------------------------------------------
+template <int RHS>
+__device__ __forceinline__ void rk4_step(const double x[3], const double v[3], const double a1[3], double h,
+                                         double r_s, double xn[3], double vn[3], double an[3], double &r_new)
+{
+    const double hh = 0.5 * h;
+    double a2[3], a3[3], a4[3], xs[3], v2[3], v3[3], v4[3], rr;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        xs[c] = __builtin_fma(hh, v[c], x[c]);
+        v2[c] = __builtin_fma(hh, a1[c], v[c]);
+    }
+    accel<RHS>(xs, v2, r_s, a2, rr);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        xs[c] = __builtin_fma(hh, v2[c], x[c]);
+        v3[c] = __builtin_fma(hh, a2[c], v[c]);
+    }
+    accel<RHS>(xs, v3, r_s, a3, rr);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        xs[c] = __builtin_fma(h, v3[c], x[c]);
+        v4[c] = __builtin_fma(h, a3[c], v[c]);
+    }
+    accel<RHS>(xs, v4, r_s, a4, rr);
+    const double h6 = h * (1.0 / 6.0);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        xn[c] = __builtin_fma(h6, __builtin_fma(2.0, v3[c], __builtin_fma(2.0, v2[c], v[c])) + v4[c], x[c]);
+        vn[c] = __builtin_fma(h6, __builtin_fma(2.0, a3[c], __builtin_fma(2.0, a2[c], a1[c])) + a4[c], v[c]);
+    }
+    accel<RHS>(xn, vn, r_s, an, r_new);
+}
+
 struct Hermite {
     double x0[3], x1[3], v0[3], v1[3], a0[3], a1[3];
     double t0, h;
@@ -755,208 +734,308 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
     return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) - R;
 }
 
+template <int RHS>
+__device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
+                                                  const double a1[3], double t, double h, uint32_t kind,
+                                                  uint32_t idx, uint32_t n_att, uint32_t n_acc)
+{
+    Hermite d;
+    double r_new;
+    rk4_step<RHS>(x, v, a1, h, A.r_s, d.x1, d.v1, d.a1, r_new);
+    d.t0 = t;
+    d.h = h;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        d.x0[c] = x[c];
+        d.v0[c] = v[c];
+        d.a0[c] = a1[c];
+    }
+    const double t_new = t + h;
+    double rh = 0.0, re = 0.0;
+    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return hermite_g(d, tt, A.r_s); }, t, t_new);
+    if (kind & EV_EXIT) re = brent_root([&](double tt) { return hermite_g(d, tt, A.r_exit); }, t, t_new);
+    double t_root;
+    uint32_t fl;
+    if ((kind & EV_HORIZON) && (!(kind & EV_EXIT) || rh <= re)) {
+        t_root = rh;
+        fl = BHG_FLAG_HIT_HORIZON_;
+    } else {
+        t_root = re;
+        fl = BHG_FLAG_EXITED_SPHERE_;
+    }
+    double xe[3], ve[3];
+    hermite_eval(d, t_root, xe, ve);
+    store_result(A, idx, xe, ve, fl, n_att, n_acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// Event queue: lanes whose accepted step crossed the horizon / exit sphere park the step's
+// start state in LDS and go straight back to work; the wave drains the queue converged.
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane)
+{
+    if ((int)lane < W.e_count) {
+        double x[3], v[3], a1[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            x[c] = Q.ex[c][lane];
+            v[c] = Q.ev[c][lane];
+            a1[c] = Q.ea[c][lane];
+        }
+        const double t = Q.et[lane], h = Q.eh[lane];
+        const uint32_t idx = Q.eidx[lane], natt = Q.enatt[lane], nacc = Q.enacc[lane], kind = Q.ekind[lane];
+        if (ADAPTIVE)
+            dp54_resolve_event<RHS>(A, x, v, a1, t, h, kind, idx, natt, nacc);
+        else
+            rk4_resolve_event<RHS>(A, x, v, a1, t, h, kind, idx, natt, nacc);
+    }
+    wave_lds_sync();
+    W.e_count = 0;
+}
+
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ void push_events(const TraceArgs &A, WaveLds &Q, Wave &W, const Lane &L, uint32_t lane,
+                                            bool push, double h, uint32_t kind)
+{
+    uint64_t pm = __ballot(push);
+    while (pm) {
+        if (W.e_count == EVQ_CAP) drain_events<RHS, ADAPTIVE>(A, Q, W, lane);
+        const int free_ = EVQ_CAP - W.e_count;
+        const int want = __builtin_popcountll(pm);
+        const int take = want < free_ ? want : free_;
+        if (push) {
+            const int rk = (int)lane_rank(pm);
+            if (rk < take) {
+                const int s = W.e_count + rk;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    Q.ex[c][s] = L.x[c];
+                    Q.ev[c][s] = L.v[c];
+                    Q.ea[c][s] = L.a1[c];
+                }
+                Q.et[s] = L.t;
+                Q.eh[s] = h;
+                Q.eidx[s] = L.idx;
+                Q.enatt[s] = L.n_att;
+                Q.enacc[s] = L.n_acc;
+                Q.ekind[s] = kind;
+                push = false;
+            }
+        }
+        wave_lds_sync();
+        W.e_count += take;
+        pm = __ballot(push);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool HAS_EXIT>
+__global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
+{
+    __shared__ WaveLds Q;
+    const uint32_t lane = threadIdx.x;
+    const double r_s = A.r_s, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+    const double max_step = A.max_step;
+
+    Lane L;
+#pragma unroll
+    for (int c = 0; c < 3; c++) L.x[c] = L.v[c] = L.a1[c] = 0.0;
+    L.t = L.h_abs = L.r_cur = 0.0;
+    L.idx = L.n_att = L.n_acc = 0;
+    L.active = L.rejected = false;
+    Wave W;
+    W.q_head = W.q_count = W.e_count = 0;
+    W.exhausted = false;
+    W.next_base = fetch_batch(A, lane);
+
+    for (;;) {
+        uint64_t idle = __ballot(!L.active);
+        if (idle) {
+            idle = refill<RHS, true>(A, Q, W, L, lane, idle);
+            if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
+        }
+
+        bool push = false;
+        uint32_t kind = 0;
+        double h = 0.0;
+        if (L.active) {
+            // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
+            uint32_t term = 0;
+            const double min_step = 10.0 * ulp_of(L.t);
+            if (!L.rejected) {
+                if (L.h_abs > max_step)
+                    L.h_abs = max_step;
+                else if (L.h_abs < min_step)
+                    L.h_abs = min_step;
+            }
+            if (L.h_abs < min_step)
+                term = BHG_FLAG_STEP_TOO_SMALL_;
+            else if (L.n_att >= A.max_steps)
+                term = BHG_FLAG_MAX_STEPS_;
+            if (term == 0 && L.t == t_bound) term = BHG_FLAG_REACHED_END_;  // base.py:189-194
+            if (term) {
+                store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
+                L.active = false;
+            } else {
+                double t_new = L.t + L.h_abs;
+                if (t_new - t_bound > 0.0) t_new = t_bound;
+                h = t_new - L.t;
+                L.h_abs = fabs(h);
+                const double h2 = h * h;
+
+                double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+                dp54_stages<RHS>(L.x, L.v, L.a1, h, r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+                L.n_att++;
+
+                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components
+                double errsq = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double ev = __builtin_fma(
+                        TB.e[7], a7[c],
+                        __builtin_fma(TB.e[6], a6[c],
+                                      __builtin_fma(TB.e[5], a5[c],
+                                                    __builtin_fma(TB.e[4], a4[c],
+                                                                  __builtin_fma(TB.e[3], a3[c], TB.e[1] * L.a1[c])))));
+                    ev *= h;
+                    double ex = __builtin_fma(
+                        TB.et[6], a6[c],
+                        __builtin_fma(TB.et[5], a5[c],
+                                      __builtin_fma(TB.et[4], a4[c],
+                                                    __builtin_fma(TB.et[3], a3[c],
+                                                                  __builtin_fma(TB.et[2], a2[c], TB.et[1] * L.a1[c])))));
+                    ex *= h2;
+                    double scv = __builtin_fma(fmax(fabs(L.v[c]), fabs(vn[c])), rtol, atol);
+                    double scx = __builtin_fma(fmax(fabs(L.x[c]), fabs(xn[c])), rtol, atol);
+                    double qv = ev * rcp_nr(scv);
+                    double qx = ex * rcp_nr(scx);
+                    errsq = __builtin_fma(qv, qv, __builtin_fma(qx, qx, errsq));
+                }
+                errsq *= (1.0 / 6.0);
+                // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
+                if (!(r_new == r_new)) errsq = __builtin_nan("");
+
+                // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
+                double fac;
+                if (errsq < 3.4e6) {
+                    fac = 0.9 * pow_m0p1(fmax(errsq, 1e-11));
+                } else {
+                    fac = 0.2;  // also the NaN case: python max(0.2, nan) == 0.2
+                }
+                if (errsq < 1.0) {
+                    fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
+                    if (L.rejected) fac = fmin(1.0, fac);
+                    L.h_abs *= fac;
+                    L.rejected = false;
+                    L.n_acc++;
+
+                    // events between step ends (ivp.py:109-126): horizon any direction, exit outward
+                    const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
+                                      ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+                    const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                    if (ev_h || ev_e) {
+                        push = true;  // keep x, v, a1, t: the drain recomputes this step
+                        kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u);
+                        L.active = false;
+                    } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
+                        store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
+                        L.active = false;
+                    } else {
+                        L.t = t_new;
+                        L.r_cur = r_new;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            L.x[c] = xn[c];
+                            L.v[c] = vn[c];
+                            L.a1[c] = a7[c];
+                        }
+                    }
+                } else {
+                    L.h_abs *= fmax(0.2, fac);
+                    L.rejected = true;
+                }
+            }
+        }
+        push_events<RHS, true>(A, Q, W, L, lane, push, h, kind);
+    }
+    if (W.e_count) drain_events<RHS, true>(A, Q, W, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fixed-step classic RK4 ("R-fine" regime, SURVEY.md 8d).  Same persistent lane-refill wave.
+// ------------------------------------------------------------------------------------------
 template <int RHS, bool HAS_EXIT>
 __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 {
-    __shared__ WaveQueue Q;
+    __shared__ WaveLds Q;
     const uint32_t lane = threadIdx.x;
     const double r_s = A.r_s, t_bound = A.lambda_end, hf = A.h_fixed;
-    const uint64_t n = A.n;
 
-    bool active = false;
-    double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a1[3] = {0, 0, 0};
-    double t = 0.0, r_cur = 0.0;
-    uint32_t idx = 0, n_att = 0;
-
-    int q_head = 0, q_count = 0;
-    bool exhausted = false;
-    uint64_t next_base;
-    {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(A.counter, 64ull);
-        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
-                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
-    }
+    Lane L;
+#pragma unroll
+    for (int c = 0; c < 3; c++) L.x[c] = L.v[c] = L.a1[c] = 0.0;
+    L.t = L.h_abs = L.r_cur = 0.0;
+    L.idx = L.n_att = L.n_acc = 0;
+    L.active = L.rejected = false;
+    Wave W;
+    W.q_head = W.q_count = W.e_count = 0;
+    W.exhausted = false;
+    W.next_base = fetch_batch(A, lane);
 
     for (;;) {
-        uint64_t idle = __ballot(!active);
+        uint64_t idle = __ballot(!L.active);
         if (idle) {
-            for (;;) {
-                if (q_count == 0) {
-                    if (exhausted) break;
-                    const uint64_t base = next_base;
-                    if (base >= n) {
-                        exhausted = true;
-                        break;
-                    }
-                    {
-                        unsigned long long b = 0;
-                        if (lane == 0) b = atomicAdd(A.counter, 64ull);
-                        next_base = __builtin_amdgcn_readfirstlane((uint32_t)b) |
-                                    ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
-                    }
-                    const uint64_t i = base + lane;
-                    double px[3], pk[3], pa[3], pr = 0.0;
-                    bool valid = false;
-                    if (i < n) {
-                        pk[0] = A.k0[i * 3 + 0];
-                        pk[1] = A.k0[i * 3 + 1];
-                        pk[2] = A.k0[i * 3 + 2];
-                        if (A.x0) {
-                            px[0] = A.x0[i * 3 + 0];
-                            px[1] = A.x0[i * 3 + 1];
-                            px[2] = A.x0[i * 3 + 2];
-                        } else {
-                            px[0] = A.x0s[0];
-                            px[1] = A.x0s[1];
-                            px[2] = A.x0s[2];
-                        }
-                        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
-                        if (r0 <= r_s) {
-                            store_result(A, (uint32_t)i, px, pk,
-                                         BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
-                        } else {
-                            valid = true;
-                            accel<RHS>(px, pk, r_s, pa, pr);
-                        }
-                    }
-                    const uint64_t vmask = __ballot(valid);
-                    if (valid) {
-                        const uint32_t s = lane_rank(vmask);
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            Q.x[c][s] = px[c];
-                            Q.k[c][s] = pk[c];
-                            Q.a[c][s] = pa[c];
-                        }
-                        Q.r[s] = pr;
-                        Q.idx[s] = (uint32_t)i;
-                    }
-                    wave_lds_sync();
-                    q_head = 0;
-                    q_count = __builtin_popcountll(vmask);
-                    if (q_count == 0) continue;
-                }
-                const int n_idle = __builtin_popcountll(idle);
-                const int take = n_idle < q_count ? n_idle : q_count;
-                if (!active) {
-                    const int rk = (int)lane_rank(idle);
-                    if (rk < take) {
-                        const int s = q_head + rk;
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            x[c] = Q.x[c][s];
-                            v[c] = Q.k[c][s];
-                            a1[c] = Q.a[c][s];
-                        }
-                        r_cur = Q.r[s];
-                        idx = Q.idx[s];
-                        t = 0.0;
-                        n_att = 0;
-                        active = true;
-                    }
-                }
-                wave_lds_sync();
-                q_head += take;
-                q_count -= take;
-                idle = __ballot(!active);
-                if (!idle) break;
-            }
+            idle = refill<RHS, false>(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;
         }
-
-        if (active) {
+        bool push = false;
+        uint32_t kind = 0;
+        double h = 0.0;
+        if (L.active) {
             uint32_t term = 0;
-            if (t >= t_bound) term = BHG_FLAG_REACHED_END_;
-            else if (n_att >= A.max_steps) term = BHG_FLAG_MAX_STEPS_;
+            if (L.t >= t_bound)
+                term = BHG_FLAG_REACHED_END_;
+            else if (L.n_att >= A.max_steps)
+                term = BHG_FLAG_MAX_STEPS_;
             if (term) {
-                store_result(A, idx, x, v, term, n_att, n_att);
-                active = false;
+                store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_att);
+                L.active = false;
             } else {
-                double t_new = t + hf;
+                double t_new = L.t + hf;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
-                const double h = t_new - t;
-                const double hh = 0.5 * h;
-                double a2[3], a3[3], a4[3], a5[3], xs[3], vs[3], rr, r_new;
-                // k2 = f(y + h/2 k1): position slope = v, velocity slope = a1
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    xs[c] = __builtin_fma(hh, v[c], x[c]);
-                    vs[c] = __builtin_fma(hh, a1[c], v[c]);
-                }
-                double v2[3] = {vs[0], vs[1], vs[2]};
-                accel<RHS>(xs, vs, r_s, a2, rr);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    xs[c] = __builtin_fma(hh, v2[c], x[c]);
-                    vs[c] = __builtin_fma(hh, a2[c], v[c]);
-                }
-                double v3[3] = {vs[0], vs[1], vs[2]};
-                accel<RHS>(xs, vs, r_s, a3, rr);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    xs[c] = __builtin_fma(h, v3[c], x[c]);
-                    vs[c] = __builtin_fma(h, a3[c], v[c]);
-                }
-                double v4[3] = {vs[0], vs[1], vs[2]};
-                accel<RHS>(xs, vs, r_s, a4, rr);
-                double xn[3], vn[3];
-                const double h6 = h * (1.0 / 6.0);
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    xn[c] = __builtin_fma(h6, __builtin_fma(2.0, v3[c], __builtin_fma(2.0, v2[c], v[c])) + v4[c], x[c]);
-                    vn[c] = __builtin_fma(h6, __builtin_fma(2.0, a3[c], __builtin_fma(2.0, a2[c], a1[c])) + a4[c], v[c]);
-                }
-                accel<RHS>(xn, vn, r_s, a5, r_new);
-                n_att++;
-                const bool ev_h = ((r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
-                                  ((r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
-                const bool ev_e = HAS_EXIT && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                h = t_new - L.t;
+                double xn[3], vn[3], an[3], r_new;
+                rk4_step<RHS>(L.x, L.v, L.a1, h, r_s, xn, vn, an, r_new);
+                L.n_att++;
+                const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
+                                  ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+                const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                 if (ev_h || ev_e) {
-                    Hermite d;
-                    d.t0 = t;
-                    d.h = h;
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        d.x0[c] = x[c];
-                        d.x1[c] = xn[c];
-                        d.v0[c] = v[c];
-                        d.v1[c] = vn[c];
-                        d.a0[c] = a1[c];
-                        d.a1[c] = a5[c];
-                    }
-                    double rh = 0.0, re = 0.0;
-                    if (ev_h) rh = brent_root([&](double tt) { return hermite_g(d, tt, r_s); }, t, t_new);
-                    if (ev_e) re = brent_root([&](double tt) { return hermite_g(d, tt, A.r_exit); }, t, t_new);
-                    double t_root;
-                    uint32_t fl;
-                    if (ev_h && (!ev_e || rh <= re)) {
-                        t_root = rh;
-                        fl = BHG_FLAG_HIT_HORIZON_;
-                    } else {
-                        t_root = re;
-                        fl = BHG_FLAG_EXITED_SPHERE_;
-                    }
-                    double xe[3], ve[3];
-                    hermite_eval(d, t_root, xe, ve);
-                    store_result(A, idx, xe, ve, fl, n_att, n_att);
-                    active = false;
+                    push = true;
+                    kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u);
+                    L.n_acc = L.n_att;
+                    L.active = false;
                 } else if (!(r_new == r_new)) {
-                    store_result(A, idx, xn, vn, 0, n_att, n_att);  // NaN flag added by store_result
-                    active = false;
+                    store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
+                    L.active = false;
                 } else {
-                    t = t_new;
-                    r_cur = r_new;
+                    L.t = t_new;
+                    L.r_cur = r_new;
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        x[c] = xn[c];
-                        v[c] = vn[c];
-                        a1[c] = a5[c];
+                        L.x[c] = xn[c];
+                        L.v[c] = vn[c];
+                        L.a1[c] = an[c];
                     }
                 }
             }
         }
+        push_events<RHS, false>(A, Q, W, L, lane, push, h, kind);
     }
+    if (W.e_count) drain_events<RHS, false>(A, Q, W, lane);
 }
 
 // ------------------------------------------------------------------------------------------
