@@ -37,7 +37,8 @@ RHS_REDUCED = 1
 EXPORTS = (
     "bhg_version", "bhg_device_count", "bhg_last_error", "bhg_default_params", "bhg_create",
     "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
-    "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream",
+    "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
+    "bhg_shade_device",
 )
 
 
@@ -109,6 +110,12 @@ def load():
     L.bhg_trace_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
+    L.bhg_raygen_device.restype = C.c_int
+    L.bhg_raygen_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.bhg_shade_device.restype = C.c_int
+    L.bhg_shade_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.bhg_acceleration.restype = C.c_int
     L.bhg_acceleration.argtypes = [C.c_void_p, C.POINTER(Params), _dp, _dp, C.c_size_t, _dp]
     L.bhg_synchronize.restype = C.c_int
@@ -225,6 +232,20 @@ class Context:
                                        C.c_void_p(d_k0), int(n), C.c_void_p(d_end),
                                        C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),
                                        C.c_void_p(d_n_accepted or None), C.c_void_p(stream or None)))
+
+    def raygen_device(self, width, height, samples, fov_x, fov_y, d_jitter, d_k0, n_pixels, d_pixels=0,
+                      rot=None, stream=0):
+        r9 = None
+        if rot is not None:
+            r9 = (C.c_double * 9)(*[float(v) for v in np.asarray(rot, dtype=np.float64).reshape(9)])
+        _check(load().bhg_raygen_device(self._h, int(width), int(height), int(samples), float(fov_x), float(fov_y),
+                                        r9, C.c_void_p(d_jitter), C.c_void_p(d_pixels or None), int(n_pixels),
+                                        C.c_void_p(d_k0), C.c_void_p(stream or None)))
+
+    def shade_device(self, d_end, d_flags, n_pixels, samples, d_sky, sky_w, sky_h, d_rgba, stream=0):
+        _check(load().bhg_shade_device(self._h, C.c_void_p(d_end), C.c_void_p(d_flags), int(n_pixels), int(samples),
+                                       C.c_void_p(d_sky), int(sky_w), int(sky_h), C.c_void_p(d_rgba),
+                                       C.c_void_p(stream or None)))
 
     def acceleration(self, x, k, params: Params):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)

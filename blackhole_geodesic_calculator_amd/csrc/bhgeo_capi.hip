@@ -300,6 +300,60 @@ int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_s
     return BHG_OK;
 }
 
+int bhg_raygen_device(bhg_context *c, int32_t width, int32_t height, int32_t samples, double fov_x, double fov_y,
+                      const double *rot9, const double *d_jitter, const int64_t *d_pixels, size_t n_pixels,
+                      double *d_k0, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    if (width <= 0 || height <= 0 || samples <= 0) return fail(BHG_E_INVALID, "width, height, samples must be > 0");
+    if (n_pixels == 0) return BHG_OK;
+    if (!d_jitter || !d_k0) return fail(BHG_E_INVALID, "jitter / k0 is NULL");
+    if (!d_pixels && n_pixels != (size_t)width * (size_t)height)
+        return fail(BHG_E_INVALID, "n_pixels must be width*height when no pixel list is given");
+    HIP_TRY(hipSetDevice(c->device));
+    bhg::RaygenArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.jitter = d_jitter;
+    a.pixels = d_pixels;
+    a.k0 = d_k0;
+    a.n_pixels = n_pixels;
+    a.width = width;
+    a.height = height;
+    a.samples = samples;
+    a.fov_x = fov_x;
+    a.fov_y = fov_y;
+    a.rotate = 0;
+    if (rot9) {
+        static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        a.rotate = std::memcmp(rot9, eye, sizeof(eye)) != 0;
+        std::memcpy(a.rot, rot9, sizeof(a.rot));
+    }
+    HIP_TRY(bhg::launch_raygen(a, (hipStream_t)stream));
+    return BHG_OK;
+}
+
+int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags, size_t n_pixels, int32_t samples,
+                     const float *d_sky, int32_t sky_w, int32_t sky_h, double *d_rgba, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    if (samples <= 0 || sky_w <= 0 || sky_h <= 0) return fail(BHG_E_INVALID, "samples, sky_w, sky_h must be > 0");
+    if (n_pixels == 0) return BHG_OK;
+    if (!d_end || !d_flags || !d_sky || !d_rgba) return fail(BHG_E_INVALID, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    bhg::ShadeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.end = d_end;
+    a.flags = d_flags;
+    a.sky = d_sky;
+    a.rgba = d_rgba;
+    a.n_pixels = n_pixels;
+    a.samples = samples;
+    a.sky_w = sky_w;
+    a.sky_h = sky_h;
+    HIP_TRY(bhg::launch_shade(a, (hipStream_t)stream));
+    return BHG_OK;
+}
+
 int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const double *k, size_t n, double *acc)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");

@@ -1,0 +1,128 @@
+// frame_kernels.hip -- the data-parallel stages either side of the geodesic solve, on device:
+//   * camera-ray generation with the reference's multisample jitter
+//     (raytracer/RelativisticRenderEngine.py:185-188, :224-230), from a device-resident MT19937
+//     jitter stream (produced once on the host from Python's own seeded state, bit-identical);
+//   * escaping-ray shading against an equirectangular sky (background_hit, :366-378) and the
+//     per-pixel multisample mean (sbuf += colour; buf = sbuf/(s+1), :242-250).
+// Both are HBM-bound element-wise kernels: coalesced loads/stores, no LDS needed -- the S
+// samples of a pixel are accumulated in registers in sample order (the reference's order), so
+// the result is deterministic; there is no cross-lane reduction to stage.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geodesic_kernels.h"
+
+namespace bhg {
+
+// d = (x_r + dx (u1 - 1/2), y_r + dy (u2 - 1/2), -1), rotated, normalised.  Operation order follows
+// the host restatement (raygen.py) so that an unrotated camera gives bit-identical directions
+// (the library is built with -ffp-contract=off).
+__global__ void __launch_bounds__(256) raygen_kernel(const RaygenArgs A)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t P = A.n_pixels;
+    if (i >= P * (uint64_t)A.samples) return;
+    const uint64_t s = i / P, p = i - s * P;
+    const int64_t pix = A.pixels ? A.pixels[p] : (int64_t)p;
+    const int64_t py = pix / A.width, px = pix - py * A.width;
+    const double W = (double)A.width, H = (double)A.height;
+    const double aspect = H / W;
+    const double dy = aspect / H, dx = 1.0 / W;
+    const uint64_t j = (s * (uint64_t)A.width * (uint64_t)A.height + (uint64_t)pix) * 2;
+    const double u1 = A.jitter[j], u2 = A.jitter[j + 1];
+    const double x_render = A.fov_x * (double)(px - (int64_t)(A.width / 2)) / W;
+    const double y_render = A.fov_y * (double)(py - (int64_t)(A.height / 2)) / H * aspect;
+    double d0 = x_render + dx * (u1 - 0.5);
+    double d1 = y_render + dy * (u2 - 0.5);
+    double d2 = -1.0;
+    if (A.rotate) {
+        const double e0 = A.rot[0] * d0 + A.rot[1] * d1 + A.rot[2] * d2;
+        const double e1 = A.rot[3] * d0 + A.rot[4] * d1 + A.rot[5] * d2;
+        const double e2 = A.rot[6] * d0 + A.rot[7] * d1 + A.rot[8] * d2;
+        d0 = e0;
+        d1 = e1;
+        d2 = e2;
+    }
+    const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    double *o = A.k0 + i * 3;
+    o[0] = d0 / nrm;
+    o[1] = d1 / nrm;
+    o[2] = d2 / nrm;
+}
+
+// Bilinear lookup in an equirectangular RGBA float32 image.  Texture coordinates (u, v) in
+// [-1, 1]^2 as background_hit passes them to Texture.evaluate (:375): u wraps, v clamps.
+// (Blender's own texture filter cannot be reproduced outside Blender; this definition is the
+// build's own and is restated in numpy in device_frame.py for the parity test.)
+__device__ __forceinline__ void sky_lookup(const float *sky, int TW, int TH, double u, double v, double rgb[3])
+{
+    double fx = (u + 1.0) * 0.5 * (double)TW - 0.5;
+    double fy = (v + 1.0) * 0.5 * (double)TH - 0.5;
+    double x0f = floor(fx), y0f = floor(fy);
+    double ax = fx - x0f, ay = fy - y0f;
+    long x0 = (long)x0f, y0 = (long)y0f;
+    long x1 = x0 + 1, y1 = y0 + 1;
+    x0 %= TW;
+    if (x0 < 0) x0 += TW;
+    x1 %= TW;
+    if (x1 < 0) x1 += TW;
+    y0 = y0 < 0 ? 0 : (y0 > TH - 1 ? TH - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > TH - 1 ? TH - 1 : y1);
+    const float4 t00 = reinterpret_cast<const float4 *>(sky)[y0 * TW + x0];
+    const float4 t01 = reinterpret_cast<const float4 *>(sky)[y0 * TW + x1];
+    const float4 t10 = reinterpret_cast<const float4 *>(sky)[y1 * TW + x0];
+    const float4 t11 = reinterpret_cast<const float4 *>(sky)[y1 * TW + x1];
+    const double w00 = (1.0 - ax) * (1.0 - ay), w01 = ax * (1.0 - ay), w10 = (1.0 - ax) * ay, w11 = ax * ay;
+    rgb[0] = w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x;
+    rgb[1] = w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y;
+    rgb[2] = w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z;
+}
+
+// One thread per pixel; samples accumulated in sample order (:242-250).  Rays are laid out
+// [S][P] so every load is coalesced across the pixels of a wavefront.
+__global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n_pixels) return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int s = 0; s < A.samples; s++) {
+        const uint64_t i = (uint64_t)s * A.n_pixels + p;
+        const uint8_t fl = A.flags[i];
+        if (fl & BHG_FLAG_HIT_HORIZON_) continue;  // black (:242-244)
+        const double *e = A.end + i * 6;
+        double d0 = e[3], d1 = e[4], d2 = e[5];
+        // exit directions are not unit vectors; normalise like the Cam edition (CamEdition.py:433-437)
+        const double inv = 1.0 / sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        d0 *= inv;
+        d1 *= inv;
+        d2 *= inv;
+        const double theta = 1.0 - acos(d2) / M_PI;   // :373
+        const double phi = atan2(d1, d0) / M_PI;      // :374
+        double rgb[3];
+        sky_lookup(A.sky, A.sky_w, A.sky_h, -phi, 2.0 * theta - 1.0, rgb);  // :375
+        acc[0] += rgb[0];
+        acc[1] += rgb[1];
+        acc[2] += rgb[2];
+    }
+    const double inv_s = 1.0 / (double)A.samples;  // buf = sbuf / (s+1) after the last sample (:250)
+    double *o = A.rgba + p * 4;
+    reinterpret_cast<double2 *>(o)[0] = make_double2(acc[0] * inv_s, acc[1] * inv_s);
+    reinterpret_cast<double2 *>(o)[1] = make_double2(acc[2] * inv_s, 1.0);
+}
+
+hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s)
+{
+    const uint64_t n = a.n_pixels * (uint64_t)a.samples;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const ShadeArgs &a, hipStream_t s)
+{
+    if (a.n_pixels == 0) return hipSuccess;
+    hipLaunchKernelGGL(shade_reduce_kernel, dim3((unsigned)((a.n_pixels + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace bhg

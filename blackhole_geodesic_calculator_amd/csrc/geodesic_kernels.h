@@ -34,6 +34,30 @@ struct TraceArgs {
     uint32_t max_steps;
 };
 
+// camera-ray generation (frame_kernels.hip)
+struct RaygenArgs {
+    const double *jitter;   // [S*H*W*2] MT19937 doubles, sample-major then row-major pixels, (u1, u2)
+    const int64_t *pixels;  // [n_pixels] flat pixel ids y*W+x, or nullptr = all pixels in order
+    double *k0;             // [S*n_pixels][3], ray i = s*n_pixels + p
+    uint64_t n_pixels;
+    int32_t width, height, samples, rotate;
+    double fov_x, fov_y;
+    double rot[9];          // row-major camera rotation
+};
+
+// shading + per-pixel multisample mean (frame_kernels.hip)
+struct ShadeArgs {
+    const double *end;     // [S*n_pixels][6]
+    const uint8_t *flags;  // [S*n_pixels]
+    const float *sky;      // [sky_h][sky_w][4] RGBA float32, equirectangular
+    double *rgba;          // [n_pixels][4]
+    uint64_t n_pixels;
+    int32_t samples, sky_w, sky_h;
+};
+
+hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
+hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
+
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s);
 hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu);
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,

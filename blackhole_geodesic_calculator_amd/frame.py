@@ -1,0 +1,107 @@
+"""Frame driver: the reference's per-sample / per-row / per-pixel loops, batched.
+
+Restates the data flow of raytracer/RelativisticRenderEngine.py:172-267 (`ray_trace`):
+    random.seed(sampling_seed)                                        :189
+    for s in samples: for y in rows: for x in columns:                :195-218
+        direction = pinhole + jitter, rotate, normalise               :224-230
+        hit, hit_bh, end_dir, end_loc = spacetime_ray_cast(...)       :237   <- the hot path
+        sbuf[y, x, 0:3] += black if hit_bh else background_hit(end_dir)   :242-246
+      buf[y, :, 0:3] = sbuf[y, :, 0:3] / (s + 1)                      :250
+      if y < H-1: buf[y+1, :, 0:3] = 1 - buf[y+1, :, 0:3]             :251-252 (progress cue)
+      yield (s*W*H + W*y) / N                                         :261
+with ONE batched GPU trace per sample instead of W*H Python calls.  The generator protocol, the
+in-place mutation of `buf`, the yielded values and the final image are the same.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .raygen import camera_directions, python_random_stream
+
+
+def spacetime_ray_cast_batch(integrator, origin, directions, bh_loc=(0.0, 0.0, 0.0), max_step=np.inf,
+                             curve_end=50.0):
+    """Batched form of spacetime_ray_cast (RelativisticRenderEngine.py:271-313).
+
+    origin: camera world position [3]; directions [..., 3] unit vectors.
+    Returns (hit, hit_bh, end_dir, end_loc) with hit == False everywhere (:305), hit_bh a bool
+    array, end_dir/end_loc [..., 3].  A camera inside the hole gives hit_bh == True for every ray
+    (:311-313); end_dir/end_loc then hold the start values.
+    """
+    origin = np.asarray(origin, dtype=np.float64) - np.asarray(bh_loc, dtype=np.float64)  # :278
+    out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end)
+    end = out["ray_end"]
+    hit_bh = out["ray_blackhole_hit"].astype(bool)
+    hit = np.zeros(hit_bh.shape, dtype=bool)
+    return hit, hit_bh, end[..., 3:6], end[..., 0:3]
+
+
+class FrameTracer:
+    """One frame = S batched traces of W*H rays each, accumulated exactly like the reference."""
+
+    def __init__(self, integrator, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
+                 origin=(0.0, 0.0, 0.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0),
+                 max_step=np.inf, curve_end=50.0, mark=None):
+        self.integrator = integrator
+        self.width, self.height, self.samples = int(width), int(height), int(samples)
+        self.fov_x, self.fov_y = float(fov_x), float(fov_y)
+        self.sampling_seed = sampling_seed
+        self.origin = np.asarray(origin, dtype=np.float64)
+        self.rotation_euler = tuple(float(e) for e in rotation_euler)
+        self.bh_loc = np.asarray(bh_loc, dtype=np.float64)
+        self.max_step, self.curve_end = max_step, curve_end
+        self.mark = mark  # (y_min, y_max, x_min, x_max), inclusive, or None
+        self.last_counters = None
+
+    # the jitter stream depends only on (seed, window, S): cache it across frames (:189 re-seeds
+    # identically on every render())
+    def directions(self):
+        return camera_directions(self.width, self.height, self.samples, self.fov_x, self.fov_y,
+                                 self.sampling_seed, self.rotation_euler, self.mark)
+
+    def ray_trace(self, buf, background_hit):
+        """Generator with the reference's protocol: mutates buf[H, W, 4] in place, yields the
+        progress fraction once per rendered row.  `background_hit(directions[n,3]) -> rgb[n,3]`
+        shades the escaping rays (vectorised counterpart of :366-378)."""
+        W, H, S = self.width, self.height, self.samples
+        N = S * W * H
+        y_min, y_max, x_min, x_max = self.mark if self.mark is not None else (0, H, 0, W)
+        rows = [y for y in range(H) if y_min <= y <= y_max]
+        cols = np.array([x for x in range(W) if x_min <= x <= x_max], dtype=np.int64)
+        sbuf = np.zeros((H, W, 4))
+        dirs = self.directions()  # [S, H, W, 3], NaN outside the window
+        steps = 0
+        rays = 0
+        colour = np.zeros((len(rows), len(cols), 3))
+        for s in range(S):
+            if rows and len(cols):
+                d = dirs[s][np.ix_(rows, cols)]  # [R, C, 3]
+                _, hit_bh, end_dir, _ = spacetime_ray_cast_batch(
+                    self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end)
+                colour = np.zeros(d.shape)
+                esc = ~hit_bh
+                if esc.any():
+                    colour[esc] = np.asarray(background_hit(end_dir[esc]), dtype=np.float64)
+                rays += hit_bh.size
+            for ri, y in enumerate(rows):
+                sbuf[y, cols, 0:3] += colour[ri]
+                buf[y, :, 0:3] = sbuf[y, :, 0:3] / (s + 1)
+                if y < H - 1:
+                    buf[y + 1, :, 0:3] = 1 - buf[y + 1, :, 0:3]
+                yield (s * W * H + W * y) / N
+        self.last_counters = {"rays": rays}
+
+
+def equirect_uv(direction, normalise=True):
+    """(u, v) texture coordinates of background_hit (RelativisticRenderEngine.py:373-375):
+    theta = 1 - acos(d_z)/pi, phi = atan2(d_y, d_x)/pi, evaluate((-phi, 2*theta - 1, 0)).
+
+    The solver's exit directions are not unit vectors in general; the Cam edition renormalises
+    before the lookup (RelativisticRenderEngineCamEdition.py:433-437) and so does this function by
+    default (the main engine does not and gets NaN for |d_z| > 1)."""
+    d = np.asarray(direction, dtype=np.float64)
+    if normalise:
+        d = d / np.sqrt((d * d).sum(-1))[..., None]
+    theta = 1 - np.arccos(d[..., 2]) / np.pi
+    phi = np.arctan2(d[..., 1], d[..., 0]) / np.pi
+    return -phi, 2 * theta - 1

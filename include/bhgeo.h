@@ -119,6 +119,25 @@ int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_sha
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
 
+/* --- the stages either side of the solve, on device ---------------------------------------- */
+/* Camera rays with the reference's multisample jitter (RelativisticRenderEngine.py:185-188,
+ * :224-230).  d_jitter [samples*height*width*2]: the random.random() stream after
+ * random.seed(sampling_seed) (:189), sample-major, then rows, then columns, (u1, u2) per pixel.
+ * d_pixels [n_pixels]: flat pixel ids y*width+x to generate (a GPU's tile shard), or NULL for all
+ * pixels in order.  rot9: row-major camera rotation (HOST, may be NULL = identity).
+ * Output d_k0 [samples*n_pixels][3], ray index = s*n_pixels + p. */
+int bhg_raygen_device(bhg_context *ctx, int32_t width, int32_t height, int32_t samples, double fov_x,
+                      double fov_y, const double *rot9, const double *d_jitter, const int64_t *d_pixels,
+                      size_t n_pixels, double *d_k0, void *stream);
+
+/* Shade escaping rays against an equirectangular RGBA float32 sky (background_hit, :366-378;
+ * horizon rays are black, :242-244) and take the per-pixel mean over the samples (:250).
+ * d_end/d_flags are bhg_trace_device outputs for rays laid out [samples][n_pixels];
+ * d_rgba [n_pixels][4] fp64, alpha = 1 (:154-155). */
+int bhg_shade_device(bhg_context *ctx, const double *d_end, const uint8_t *d_flags, size_t n_pixels,
+                     int32_t samples, const float *d_sky, int32_t sky_w, int32_t sky_h, double *d_rgba,
+                     void *stream);
+
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term. */
 int bhg_acceleration(bhg_context *ctx, const bhg_params *p, const double *x, const double *k,

@@ -1,0 +1,144 @@
+"""CPU tests of the frame driver and the Blender plugin surface with a fake bpy and a STUB tracer
+(flat-space straight lines computed in the test): checks the generator protocol, accumulation,
+mark-window and registration logic.  No geodesic is computed here; the GPU counterpart is
+tests/test_gpu_frame.py."""
+import numpy as np
+import pytest
+
+import fake_bpy
+from conftest import CAM
+
+
+class StubIntegrator:
+    """Flat space: straight rays; 'horizon' = rays aimed inside a small cone around -z."""
+    def __init__(self, cone=0.05):
+        self.cone, self.calls = cone, 0
+
+    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0):
+        self.calls += 1
+        k0 = np.asarray(k0, float)
+        end = np.concatenate([np.asarray(x0) + curve_end * k0, k0], axis=-1)
+        hit = (np.hypot(k0[..., 0], k0[..., 1]) < self.cone).astype(np.uint8)
+        return {"ray_end": end, "ray_blackhole_hit": hit, "flags": hit, "n_steps": hit * 0, "n_accepted": hit * 0}
+
+
+def sky(d):
+    d = np.asarray(d)
+    return np.stack([0.5 + 0.5 * d[..., 0], 0.5 + 0.5 * d[..., 1], np.abs(d[..., 2])], -1)
+
+
+def reference_accumulate(W, H, S, fov, seed, stub, mark=None):
+    """Pixel-by-pixel restatement of RelativisticRenderEngine.py:195-261 on the same stub."""
+    from blackhole_geodesic_calculator_amd import camera_directions
+    d = camera_directions(W, H, S, fov, fov, seed, mark=mark)
+    buf = np.ones((H, W, 4))
+    sbuf = np.zeros((H, W, 4))
+    y0, y1, x0, x1 = mark if mark else (0, H, 0, W)
+    prog = []
+    for s in range(S):
+        for y in range(H):
+            if y0 <= y <= y1:
+                for x in range(W):
+                    if x0 <= x <= x1:
+                        out = stub.trace(d[s, y, x][None], CAM)
+                        if not out["ray_blackhole_hit"][0]:
+                            sbuf[y, x, 0:3] += sky(out["ray_end"][0, 3:6])
+                buf[y, :, 0:3] = sbuf[y, :, 0:3] / (s + 1)
+                if y < H - 1:
+                    buf[y + 1, :, 0:3] = 1 - buf[y + 1, :, 0:3]
+                prog.append((s * W * H + W * y) / (S * W * H))
+    return buf, prog
+
+
+@pytest.mark.parametrize("mark", [None, (2, 6, 3, 9)])
+def test_frame_tracer_matches_per_pixel_loop(mark):
+    from blackhole_geodesic_calculator_amd.frame import FrameTracer
+    W, H, S = 14, 10, 3
+    stub = StubIntegrator()
+    ft = FrameTracer(stub, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM, mark=mark)
+    buf = np.ones((H, W, 4))
+    prog = list(ft.ray_trace(buf, sky))
+    assert stub.calls == S  # one batched trace per sample
+    want, wprog = reference_accumulate(W, H, S, 0.6, 42.0, StubIntegrator(), mark)
+    assert prog == wprog
+    assert np.array_equal(buf, want)
+    assert np.all(buf[..., 3] == 1.0)
+
+
+def test_bh_location_is_subtracted():
+    from blackhole_geodesic_calculator_amd.frame import spacetime_ray_cast_batch
+    stub = StubIntegrator()
+    d = np.array([[0.0, 0.0, -1.0], [0.6, 0.0, -0.8]])
+    hit, hit_bh, end_dir, end_loc = spacetime_ray_cast_batch(stub, [1.0, 2.0, 33.0], d, bh_loc=[1.0, 2.0, 3.0], curve_end=10.0)
+    assert not hit.any() and hit_bh.tolist() == [True, False]
+    assert np.allclose(end_loc, np.array([0.0, 0.0, 30.0]) + 10.0 * d) and np.array_equal(end_dir, d)
+
+
+def test_equirect_uv_matches_reference_formula():
+    from blackhole_geodesic_calculator_amd.frame import equirect_uv
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(100, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    u, v = equirect_uv(d, normalise=False)
+    theta = 1 - np.arccos(d[:, 2]) / np.pi
+    phi = np.arctan2(d[:, 1], d[:, 0]) / np.pi
+    assert np.array_equal(u, -phi) and np.array_equal(v, 2 * theta - 1)
+    u2, v2 = equirect_uv(3.7 * d)
+    assert np.allclose(u2, u) and np.allclose(v2, v)
+
+
+def test_addon_plugin_surface_with_fake_bpy(monkeypatch):
+    bpy, depsgraph = fake_bpy.install(width=12, height=8, samples=2)
+    import importlib
+    addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+    # the surface the reference exposes (RelativisticRenderEngine.py:40-45, :466-468, :504-517)
+    assert addon.RelativisticRenderEngine.bl_idname == "RelRenEn"
+    assert addon.RelativisticRenderEngine.bl_label == "Relativistic" and addon.RelativisticRenderEngine.bl_use_preview
+    assert addon.CUSTOM_RENDER_PT_blackhole.bl_label == "Blackhole Settings"
+    names = [n for n, _ in addon.PROPS]
+    assert names == ["blackhole_obj", "mass", "max_integration_step", "integration_depth", "sampling_seed",
+                     "field_of_view_x", "field_of_view_y", "sky_image", "mark_y_min", "mark_y_max", "mark_x_min", "mark_x_max"]
+    defaults = {n: p[1].get("default") for n, p in addon.PROPS}
+    assert defaults["mass"] == 0.5 and defaults["max_integration_step"] == 10000 and defaults["integration_depth"] == 50
+    assert defaults["sampling_seed"] == 42 and defaults["mark_x_min"] == -1.0
+
+    addon.register()
+    assert addon.RelativisticRenderEngine in bpy._registered and hasattr(bpy.types.Scene, "mass")
+    assert "RelRenEn" in addon.CUSTOM_RENDER_PT_blackhole.COMPAT_ENGINES
+    import bl_ui
+    assert "RelRenEn" in bl_ui.properties_render.RENDER_PT_eevee_sampling.COMPAT_ENGINES
+
+    # render() end to end with the solver replaced by the stub (no GPU in this test)
+    stub = StubIntegrator()
+    monkeypatch.setattr(addon, "GeodesicIntegratorSchwarzschild", lambda **kw: stub)
+    eng = addon.RelativisticRenderEngine()
+    eng.render(depsgraph)
+    assert stub.calls == 2 and eng.ended == 1 and eng.updates >= 2
+    assert len(eng.progress) == 2 * 8 and eng.progress == sorted(eng.progress) and eng.progress[-1] < 1.0
+    rect = np.array(eng.result.layers[0].passes["Combined"].rect)
+    assert rect.shape == (12 * 8, 4) and np.all(rect[:, 3] == 1.0)
+    assert eng.max_integration_step == np.inf  # -1 -> inf (:59-60)
+    assert (eng.mark_y_min, eng.mark_y_max, eng.mark_x_min, eng.mark_x_max) == (0, 8, 0, 12)
+    # shading goes through Blender's texture evaluate with the reference's (u, v)
+    col = eng.background_hit(np.array([0.0, 1.0, 0.0]))
+    assert np.allclose(col, [0.5 + 0.5 * np.sin(np.pi * -0.5), 0.5, 0.25 + 0.25 * np.cos(-np.pi)])
+
+    addon.unregister()
+    assert addon.RelativisticRenderEngine not in bpy._registered and not hasattr(bpy.types.Scene, "mass")
+    assert "RelRenEn" not in addon.CUSTOM_RENDER_PT_blackhole.COMPAT_ENGINES
+
+
+def test_camera_pixel_directions_and_pickle(tmp_path):
+    from blackhole_geodesic_calculator_amd.camera import RelativisticCamera
+    cam = RelativisticCamera(resolution=[6, 8], field_of_view=[0.6, 0.6], integrator=StubIntegrator())
+    d = cam.pixel_directions()
+    assert d.shape == (6, 8, 3) and np.allclose(np.linalg.norm(d, axis=-1), 1.0)
+    assert np.allclose(d[3, 4], [0.0, 0.0, -1.0])  # x - int(W/2), y - int(H/2)
+    cam.run()
+    assert cam.ray_end.shape == (6, 8, 6) and cam.ray_blackhole_hit.shape == (6, 8) and cam.ray_blackhole_hit[3, 4] == 1
+    p = tmp_path / "cam.pkl"
+    cam.save(p)
+    cam2 = RelativisticCamera().load(p)
+    assert np.array_equal(cam2.ray_end, cam.ray_end) and np.array_equal(cam2.ray_blackhole_hit, cam.ray_blackhole_hit)
+    with pytest.raises(NotImplementedError):
+        RelativisticCamera(a=0.9)
