@@ -13,7 +13,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbhgeo.so")
+LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
 ABI_VERSION = 1
 
@@ -38,7 +38,7 @@ EXPORTS = (
     "bhg_version", "bhg_device_count", "bhg_last_error", "bhg_default_params", "bhg_create",
     "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
-    "bhg_shade_device",
+    "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms",
 )
 
 
@@ -116,6 +116,10 @@ def load():
     L.bhg_shade_device.restype = C.c_int
     L.bhg_shade_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.bhg_set_profiling.restype = C.c_int
+    L.bhg_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.bhg_last_pass_ms.restype = C.c_int
+    L.bhg_last_pass_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bhg_acceleration.restype = C.c_int
     L.bhg_acceleration.argtypes = [C.c_void_p, C.POINTER(Params), _dp, _dp, C.c_size_t, _dp]
     L.bhg_synchronize.restype = C.c_int
@@ -195,6 +199,15 @@ class Context:
     def stream(self) -> int:
         """The context's own hipStream_t as an integer handle."""
         return load().bhg_context_stream(self._h) or 0
+
+    def set_profiling(self, enable=True):
+        _check(load().bhg_set_profiling(self._h, 1 if enable else 0))
+
+    def last_pass_ms(self):
+        """{prepare, trace, resolve} milliseconds of the last profiled trace call (waits for it)."""
+        out = (C.c_float * 3)()
+        _check(load().bhg_last_pass_ms(self._h, out))
+        return {"prepare": out[0], "trace": out[1], "resolve": out[2]}
 
     def synchronize(self):
         _check(load().bhg_synchronize(self._h))

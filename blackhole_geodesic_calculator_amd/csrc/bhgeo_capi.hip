@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -61,7 +62,14 @@ struct bhg_context {
     size_t d_in_bytes = 0;
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
+    // per-ray workspace of the three-pass trace (prepare / event records, internal flags)
+    void *d_ws = nullptr;
+    size_t d_ws_bytes = 0;
     int32_t last_launch[4] = {0, 0, 0, 0};
+    // optional per-pass timing (bhg_set_profiling)
+    bool profiling = false;
+    bool ev_valid = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace {
@@ -161,7 +169,7 @@ int bhg_create(int device, bhg_context **out)
         delete c;
         return fail_hip(e, "hipStreamCreate");
     }
-    e = hipMalloc((void **)&c->counter, 256);
+    e = hipMalloc((void **)&c->counter, 8 * 256);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -178,7 +186,10 @@ void bhg_destroy(bhg_context *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->counter) (void)hipFree(c->counter);
+    for (int i = 0; i < 4; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -197,6 +208,27 @@ int bhg_synchronize(bhg_context *c)
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BHG_OK;
+}
+
+int bhg_set_profiling(bhg_context *c, int enable)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->ev[0])
+        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    c->profiling = enable != 0;
+    c->ev_valid = false;
+    return BHG_OK;
+}
+
+int bhg_last_pass_ms(bhg_context *c, float out_ms[3])
+{
+    if (!c || !out_ms) return fail(BHG_E_INVALID, "bad argument");
+    if (!c->ev_valid) return fail(BHG_E_INVALID, "no profiled trace call yet (bhg_set_profiling)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
     return BHG_OK;
 }
 
@@ -223,12 +255,19 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
 
+    // workspace: 40 B/ray records (+ n bytes of flags when the caller does not want them).  Grown on
+    // demand: the first call at a new size allocates (not capturable); steady-state calls do not.
+    const size_t ws_rec = n * 5 * sizeof(double);
+    rc = ensure(&c->d_ws, &c->d_ws_bytes, ws_rec + (d_flags ? 0 : n));
+    if (rc != BHG_OK) return rc;
+
     bhg::TraceArgs a;
     std::memset(&a, 0, sizeof(a));
     a.k0 = d_k0;
     a.x0 = d_x0;
     a.end = d_end;
-    a.flags = d_flags;
+    a.ws = (double *)c->d_ws;
+    a.flags = d_flags ? d_flags : (uint8_t *)c->d_ws + ws_rec;
     a.n_steps = d_n_steps;
     a.n_accepted = d_n_accepted;
     a.counter = c->counter;
@@ -252,12 +291,35 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, has_exit, &per_cu));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 32) per_cu = 32;
+    if (const char *ov = std::getenv("BHGEO_WAVES_PER_CU")) {  // tuning/diagnostic override
+        int v = std::atoi(ov);
+        if (v >= 1 && v <= 64) per_cu = v;
+    }
     // persistent waves: fill every resident wave slot once; never more waves than 64-ray batches
     size_t batches = (n + 63) / 64;
     size_t grid = (size_t)per_cu * (size_t)c->num_cus;
     if (grid > batches) grid = batches;
-    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), s));
-    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, has_exit, (int)grid, s));
+#ifdef BHG_DIAG
+    {
+        static unsigned long long *dbuf = nullptr;
+        if (!dbuf) HIP_TRY(hipMalloc((void **)&dbuf, 65536 * 8 * sizeof(unsigned long long)));
+        a.diag = dbuf;
+        if (const char *path = std::getenv("BHGEO_DIAG_DUMP")) {
+            // dump the PREVIOUS launch's stamps
+            static unsigned long long host[65536 * 8];
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(path, "wb")) {
+                std::fwrite(host, 1, sizeof(host), f);
+                std::fclose(f);
+            }
+        }
+    }
+#endif
+    a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));  // 8 slice counters, one 256-byte line each
+    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, has_exit, (int)grid, s, c->profiling ? c->ev : nullptr));
+    c->ev_valid = c->profiling;
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;

@@ -24,14 +24,17 @@ struct TraceArgs {
     const double *k0;            // [n][3]
     const double *x0;            // [n][3] or nullptr -> x0s
     double *end;                 // [n][6]
-    uint8_t *flags;              // [n] or nullptr
+    uint8_t *flags;              // [n] (never null inside the kernels: the C-ABI layer substitutes a workspace)
     uint32_t *n_steps;           // [n] or nullptr
     uint32_t *n_accepted;        // [n] or nullptr
-    unsigned long long *counter; // work counter, zeroed before launch
+    unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
+    double *ws;                  // [n][5] per-ray workspace: prepare record {a0, h0, r0}, later event record {a1, t, h}
     uint64_t n;
     double x0s[3];
     double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit;
     uint32_t max_steps;
+    double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
+    unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
 };
 
 // camera-ray generation (frame_kernels.hip)
@@ -58,7 +61,9 @@ struct ShadeArgs {
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
 
-hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s);
+// ev: nullptr, or 4 events recorded around prepare | trace | resolve on stream s
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s,
+                        hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu);
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
                         hipStream_t s);

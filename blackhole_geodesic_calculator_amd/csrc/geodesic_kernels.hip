@@ -17,9 +17,13 @@
 //     filled 64 rays at a time by ALL lanes together (coalesced k0 loads, the scipy initial-step
 //     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
 //     always runs converged and the integrate loop always runs (nearly) full;
-//   * a lane whose accepted step crosses the horizon / exit sphere parks the step in a per-wave
-//     LDS event queue and refills at once; the wave drains that queue converged (recompute the
-//     step, quartic dense output, Brent root) so the rare root search never runs one lane wide;
+//   * three passes per call, all on one stream: PREPARE (one thread per ray, converged: f0, r0,
+//     scipy's initial step) -> TRACE (persistent lane-refill waves, the hot loop, ~110 VGPRs) ->
+//     RESOLVE (rays whose last step crossed the horizon / exit sphere: recompute that step,
+//     quartic dense output, Brent root).  Keeping setup and root search out of the hot kernel
+//     halves its register footprint (248 -> ~110 VGPRs: 4 waves per SIMD instead of 2);
+//   * a lane whose accepted step crosses an event parks the step's start state in its own
+//     output slots and refills at once, so the rare root search never runs one lane wide;
 //   * work is handed out in 64-ray batches from one device counter, fetched one batch ahead;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
 //     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
@@ -350,27 +354,18 @@ __device__ __forceinline__ double pow_0p2(double x)
 // Per-wave LDS: a queue of prepared rays (filled converged, drained lane by lane) and a queue
 // of steps that crossed the horizon / exit sphere (filled lane by lane, drained converged).
 // ------------------------------------------------------------------------------------------
-constexpr int EVQ_CAP = 32;
-
 struct WaveLds {
-    // prepared rays
+    // prepared rays (filled converged from the prepare pass's records, drained lane by lane)
     double qx[3][64];
     double qk[3][64];
     double qa[3][64];  // FSAL acceleration at the start point
     double qh[64];     // initial |h| (common.py:68-134)
     double qr[64];     // r at the start point
     uint32_t qidx[64];
-    // pending terminal events: the step's start state; the step is recomputed when drained
-    double ex[3][EVQ_CAP];
-    double ev[3][EVQ_CAP];
-    double ea[3][EVQ_CAP];
-    double et[EVQ_CAP];
-    double eh[EVQ_CAP];
-    uint32_t eidx[EVQ_CAP];
-    uint32_t enatt[EVQ_CAP];
-    uint32_t enacc[EVQ_CAP];
-    uint32_t ekind[EVQ_CAP];
 };
+
+// flag value of a ray whose terminal event still has to be located by the resolve pass
+constexpr uint32_t EV_PENDING = 0x80u, EV_HORIZON = 1u, EV_EXIT = 2u;
 
 struct Lane {
     double x[3], v[3], a1[3];
@@ -380,9 +375,11 @@ struct Lane {
 };
 
 struct Wave {
-    int q_head, q_count, e_count;
+    int q_head, q_count;
     bool exhausted;
-    uint64_t next_base;
+    uint32_t slice, dry;         // current slice, number of slices found dry so far
+    bool have_pending;
+    unsigned long long pending;  // in-flight work-counter fetch on `slice` (valid in lane 0)
 };
 
 __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
@@ -402,25 +399,58 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     if (A.n_accepted) A.n_accepted[idx] = n_acc;
 }
 
-__device__ __forceinline__ uint64_t fetch_batch(const TraceArgs &A, uint32_t lane)
+// final state of a ray whose event the resolve pass located (step counts were stored when parked)
+__device__ __forceinline__ void store_event_result(const TraceArgs &A, uint32_t idx, const double x[3],
+                                                   const double v[3], uint32_t flags)
 {
-    unsigned long long b = 0;
-    if (lane == 0) b = atomicAdd(A.counter, 64ull);
-    return __builtin_amdgcn_readfirstlane((uint32_t)b) |
-           ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    bool bad = !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(v[0]) &&
+                 isfinite(v[1]) && isfinite(v[2]));
+    if (bad) flags |= BHG_FLAG_NAN_;
+    double *e = A.end + (size_t)idx * 6;
+    reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
+    reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
+    reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
+    A.flags[idx] = (uint8_t)flags;
 }
 
-// Converged setup of rays base .. base+63: coalesced loads, start-inside test, f0, and (DP54)
-// the Hairer initial step; survivors are compacted into the LDS ray queue with ballot/mbcnt.
-template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ void prepare_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane,
-                                              uint64_t base)
+// Work distribution.  One device-wide counter saturates near 90 fetches/us, and this kernel
+// wants 50+/us at config 2; so the 64-ray batches are dealt into NSLICE interleaved slices
+// (batch b belongs to slice b % NSLICE), each with its own counter on its own 256-byte line.  A
+// wave starts on the slice blockIdx % NSLICE -- the blocks that share an XCD under round-robin
+// placement, so a slice's counter is mostly touched from one XCD (speed only, never correctness)
+// -- and moves on to the next slice when its own runs dry (work stealing), until all are dry.
+constexpr int NSLICE = 8;
+constexpr int SLICE_STRIDE = 32;  // in unsigned long long: 256 bytes
+
+__device__ __forceinline__ unsigned long long issue_fetch(const TraceArgs &A, uint32_t lane, uint32_t slice)
 {
-    const double r_s = A.r_s;
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd(A.counter + slice * SLICE_STRIDE, 1ull);
+    return b;
+}
+
+// broadcast lane 0's fetched local batch id and turn it into a ray index
+__device__ __forceinline__ uint64_t take_fetch(unsigned long long b, uint32_t slice)
+{
+    const uint64_t local = __builtin_amdgcn_readfirstlane((uint32_t)b) |
+                           ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32);
+    return (local * NSLICE + slice) * 64ull;
+}
+
+// Fill the LDS ray queue with rays base .. base+63: coalesced loads of k0, x0 and the prepare
+// pass's record {a0, h0, r0}; rays that pass (h0 >= 0: not start-inside) are compacted with
+// ballot/mbcnt.
+__device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane, uint64_t base)
+{
     const uint64_t i = base + lane;
-    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = 0.0;
-    bool valid = false;
+    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0;
     if (i < A.n) {
+        const double *w = A.ws + i * 5;
+        pa[0] = w[0];
+        pa[1] = w[1];
+        pa[2] = w[2];
+        ph = w[3];
+        pr = w[4];
         pk[0] = A.k0[i * 3 + 0];
         pk[1] = A.k0[i * 3 + 1];
         pk[2] = A.k0[i * 3 + 2];
@@ -433,60 +463,12 @@ __device__ __forceinline__ void prepare_batch(const TraceArgs &A, WaveLds &Q, Wa
             px[1] = A.x0s[1];
             px[2] = A.x0s[2];
         }
-        double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
-        if (r0 <= r_s) {
-            // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
-            store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
-        } else {
-            valid = true;
-            accel<RHS>(px, pk, r_s, pa, pr);
-            if (ADAPTIVE) {
-                // select_initial_step (common.py:68-134) with order = 4
-                const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
-                double isc[6];
-                double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
-                    double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
-                    isc[c] = sk;
-                    isc[3 + c] = sx;
-                    double y0k = pk[c] * sk, y0x = px[c] * sx;
-                    double f0k = pa[c] * sk, f0x = pk[c] * sx;
-                    d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
-                    d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
-                }
-                d0 = sqrt(d0 * (1.0 / 6.0));
-                d1 = sqrt(d1 * (1.0 / 6.0));
-                double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-                h0 = fmin(h0, t_bound);
-                double x1[3], k1[3], f1[3], r1;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    x1[c] = __builtin_fma(h0, pk[c], px[c]);
-                    k1[c] = __builtin_fma(h0, pa[c], pk[c]);
-                }
-                accel<RHS>(x1, k1, r_s, f1, r1);
-                double d2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double dk = (f1[c] - pa[c]) * isc[c];
-                    double dx = (k1[c] - pk[c]) * isc[3 + c];
-                    d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
-                }
-                d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
-                double h1;
-                if (d1 <= 1e-15 && d2 <= 1e-15) {
-                    h1 = fmax(1e-6, h0 * 1e-3);
-                } else {
-                    double q = 0.01 / fmax(d1, d2);
-                    // the fast path needs a normal fp32 range; outside it (degenerate inputs) use libm
-                    h1 = (q > 1e-30 && q < 1e30) ? pow_0p2(q) : pow(q, 0.2);
-                }
-                ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, A.max_step));
-            }
-        }
     }
+    // All of this batch's loads must have landed HERE, for every lane: otherwise the compiler has
+    // to assume they may still be in flight on the not-valid path and puts a vmcnt(0) in front of
+    // the step code, which then waits for the previous iteration's result stores every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+    const bool valid = ph >= 0.0;
     const uint64_t vmask = __ballot(valid);
     if (valid) {
         const uint32_t s = lane_rank(vmask);
@@ -506,20 +488,22 @@ __device__ __forceinline__ void prepare_batch(const TraceArgs &A, WaveLds &Q, Wa
 }
 
 // Give idle lanes new rays.  Returns the idle mask afterwards (all ones: nothing left at all).
-template <int RHS, bool ADAPTIVE>
 __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave &W, Lane &L, uint32_t lane,
                                            uint64_t idle)
 {
     for (;;) {
         if (W.q_count == 0) {
             if (W.exhausted) break;
-            const uint64_t base = W.next_base;
+            if (!W.have_pending) W.pending = issue_fetch(A, lane, W.slice);
+            W.have_pending = false;
+            const uint64_t base = take_fetch(W.pending, W.slice);
             if (base >= A.n) {
-                W.exhausted = true;
-                break;
+                // this slice is dry: steal from the next one
+                W.slice = (W.slice + 1) % NSLICE;
+                if (++W.dry == NSLICE) W.exhausted = true;
+                continue;
             }
-            W.next_base = fetch_batch(A, lane);  // one batch ahead: latency hidden behind the setup
-            prepare_batch<RHS, ADAPTIVE>(A, Q, W, lane, base);
+            fill_batch(A, Q, W, lane, base);
             if (W.q_count == 0) continue;
         }
         const int n_idle = __builtin_popcountll(idle);
@@ -549,6 +533,12 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
         W.q_count -= take;
         idle = __ballot(!L.active);
         if (!idle) break;
+    }
+    // claim the next batch just before it is needed: the fetch is in flight while the last few
+    // queued rays are handed out, and no wave sits on unstarted batches at the end of the kernel
+    if (!W.have_pending && !W.exhausted && W.q_count <= 8) {
+        W.pending = issue_fetch(A, lane, W.slice);
+        W.have_pending = true;
     }
     return idle;
 }
@@ -627,14 +617,13 @@ __device__ __forceinline__ void dp54_stages(const double x[3], const double v[3]
     accel<RHS>(xn, vn, r_s, a7, r_new);
 }
 
-constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u;
 
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
 template <int RHS>
 __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                    const double a1[3], double t, double h, uint32_t kind,
-                                                   uint32_t idx, uint32_t n_att, uint32_t n_acc)
+                                                   uint32_t idx)
 {
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
     dp54_stages<RHS>(x, v, a1, h, A.r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
@@ -671,7 +660,7 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
     double xe[3], ve[3];
     dense_pos(d, t_root, xe);
     dense_dir(d, t_root, ve);
-    store_result(A, idx, xe, ve, fl, n_att, n_acc);
+    store_event_result(A, idx, xe, ve, fl);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -737,7 +726,7 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
 template <int RHS>
 __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                   const double a1[3], double t, double h, uint32_t kind,
-                                                  uint32_t idx, uint32_t n_att, uint32_t n_acc)
+                                                  uint32_t idx)
 {
     Hermite d;
     double r_new;
@@ -765,75 +754,39 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
     }
     double xe[3], ve[3];
     hermite_eval(d, t_root, xe, ve);
-    store_result(A, idx, xe, ve, fl, n_att, n_acc);
+    store_event_result(A, idx, xe, ve, fl);
 }
 
 // ------------------------------------------------------------------------------------------
-// Event queue: lanes whose accepted step crossed the horizon / exit sphere park the step's
-// start state in LDS and go straight back to work; the wave drains the queue converged.
+// A lane whose accepted step crossed the horizon / exit sphere parks the step's START state in
+// global memory (its own end[] slot and its prepare-record slot, both free by now) and refills at
+// once; the resolve pass recomputes that step converged and locates the root.
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane)
+__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, uint32_t kind)
 {
-    if ((int)lane < W.e_count) {
-        double x[3], v[3], a1[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            x[c] = Q.ex[c][lane];
-            v[c] = Q.ev[c][lane];
-            a1[c] = Q.ea[c][lane];
-        }
-        const double t = Q.et[lane], h = Q.eh[lane];
-        const uint32_t idx = Q.eidx[lane], natt = Q.enatt[lane], nacc = Q.enacc[lane], kind = Q.ekind[lane];
-        if (ADAPTIVE)
-            dp54_resolve_event<RHS>(A, x, v, a1, t, h, kind, idx, natt, nacc);
-        else
-            rk4_resolve_event<RHS>(A, x, v, a1, t, h, kind, idx, natt, nacc);
-    }
-    wave_lds_sync();
-    W.e_count = 0;
-}
-
-template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ void push_events(const TraceArgs &A, WaveLds &Q, Wave &W, const Lane &L, uint32_t lane,
-                                            bool push, double h, uint32_t kind)
-{
-    uint64_t pm = __ballot(push);
-    while (pm) {
-        if (W.e_count == EVQ_CAP) drain_events<RHS, ADAPTIVE>(A, Q, W, lane);
-        const int free_ = EVQ_CAP - W.e_count;
-        const int want = __builtin_popcountll(pm);
-        const int take = want < free_ ? want : free_;
-        if (push) {
-            const int rk = (int)lane_rank(pm);
-            if (rk < take) {
-                const int s = W.e_count + rk;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    Q.ex[c][s] = L.x[c];
-                    Q.ev[c][s] = L.v[c];
-                    Q.ea[c][s] = L.a1[c];
-                }
-                Q.et[s] = L.t;
-                Q.eh[s] = h;
-                Q.eidx[s] = L.idx;
-                Q.enatt[s] = L.n_att;
-                Q.enacc[s] = L.n_acc;
-                Q.ekind[s] = kind;
-                push = false;
-            }
-        }
-        wave_lds_sync();
-        W.e_count += take;
-        pm = __ballot(push);
-    }
+    double *e = A.end + (size_t)L.idx * 6;
+    reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
+    reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
+    reinterpret_cast<double2 *>(e)[2] = make_double2(L.v[1], L.v[2]);
+    double *w = A.ws + (size_t)L.idx * 5;
+    w[0] = L.a1[0];
+    w[1] = L.a1[1];
+    w[2] = L.a1[2];
+    w[3] = L.t;
+    w[4] = h;
+    A.flags[L.idx] = (uint8_t)(EV_PENDING | kind);
+    if (A.n_steps) A.n_steps[L.idx] = L.n_att;
+    if (A.n_accepted) A.n_accepted[L.idx] = L.n_acc;
 }
 
 // ------------------------------------------------------------------------------------------
 // Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
 // ------------------------------------------------------------------------------------------
+#ifndef BHG_DP54_WAVES_PER_SIMD
+#define BHG_DP54_WAVES_PER_SIMD 2
+#endif
 template <int RHS, bool HAS_EXIT>
-__global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
+__global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel(const TraceArgs A)
 {
     __shared__ WaveLds Q;
     const uint32_t lane = threadIdx.x;
@@ -847,24 +800,35 @@ __global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
     L.idx = L.n_att = L.n_acc = 0;
     L.active = L.rejected = false;
     Wave W;
-    W.q_head = W.q_count = W.e_count = 0;
+    W.q_head = W.q_count = 0;
     W.exhausted = false;
-    W.next_base = fetch_batch(A, lane);
+#ifdef BHG_DIAG
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long diag_iters = 0, diag_lanes = 0;
+#endif
+    W.slice = blockIdx.x % NSLICE;
+    W.dry = 0;
+    W.have_pending = false;
+    W.pending = 0;
 
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
-            idle = refill<RHS, true>(A, Q, W, L, lane, idle);
+            idle = refill(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
         }
+#ifdef BHG_DIAG
+        diag_iters++;
+        diag_lanes += __builtin_popcountll(__ballot(L.active));
+#endif
 
-        bool push = false;
-        uint32_t kind = 0;
-        double h = 0.0;
         if (L.active) {
             // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
             uint32_t term = 0;
-            const double min_step = 10.0 * ulp_of(L.t);
+            // 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound]: skip the exact value (rk.py:119)
+            // unless the step is already that small
+            const double min_step = (L.h_abs > A.min_step_cap) ? 0.0 : 10.0 * ulp_of(L.t);
             if (!L.rejected) {
                 if (L.h_abs > max_step)
                     L.h_abs = max_step;
@@ -882,7 +846,7 @@ __global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
             } else {
                 double t_new = L.t + L.h_abs;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
-                h = t_new - L.t;
+                const double h = t_new - L.t;
                 L.h_abs = fabs(h);
                 const double h2 = h * h;
 
@@ -937,8 +901,8 @@ __global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                     const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                     if (ev_h || ev_e) {
-                        push = true;  // keep x, v, a1, t: the drain recomputes this step
-                        kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u);
+                        // x, v, a1, t still hold the step's start: the resolve pass recomputes it
+                        park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u));
                         L.active = false;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
@@ -959,9 +923,17 @@ __global__ void __launch_bounds__(64) trace_dp54_kernel(const TraceArgs A)
                 }
             }
         }
-        push_events<RHS, true>(A, Q, W, L, lane, push, h, kind);
     }
-    if (W.e_count) drain_events<RHS, true>(A, Q, W, lane);
+#ifdef BHG_DIAG
+    if (lane == 0 && A.diag) {
+        unsigned long long *d = A.diag + (size_t)blockIdx.x * 8;
+        d[0] = diag_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = diag_iters;
+        d[3] = diag_lanes;
+        d[4] = __builtin_amdgcn_s_memtime() - diag_c0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -981,19 +953,19 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     L.idx = L.n_att = L.n_acc = 0;
     L.active = L.rejected = false;
     Wave W;
-    W.q_head = W.q_count = W.e_count = 0;
+    W.q_head = W.q_count = 0;
     W.exhausted = false;
-    W.next_base = fetch_batch(A, lane);
+    W.slice = blockIdx.x % NSLICE;
+    W.dry = 0;
+    W.have_pending = false;
+    W.pending = 0;
 
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
-            idle = refill<RHS, false>(A, Q, W, L, lane, idle);
+            idle = refill(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;
         }
-        bool push = false;
-        uint32_t kind = 0;
-        double h = 0.0;
         if (L.active) {
             uint32_t term = 0;
             if (L.t >= t_bound)
@@ -1006,7 +978,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
             } else {
                 double t_new = L.t + hf;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
-                h = t_new - L.t;
+                const double h = t_new - L.t;
                 double xn[3], vn[3], an[3], r_new;
                 rk4_step<RHS>(L.x, L.v, L.a1, h, r_s, xn, vn, an, r_new);
                 L.n_att++;
@@ -1014,9 +986,8 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                 const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                 if (ev_h || ev_e) {
-                    push = true;
-                    kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u);
                     L.n_acc = L.n_att;
+                    park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u));
                     L.active = false;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1033,9 +1004,113 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 }
             }
         }
-        push_events<RHS, false>(A, Q, W, L, lane, push, h, kind);
     }
-    if (W.e_count) drain_events<RHS, false>(A, Q, W, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Prepare pass (converged, one thread per ray): start-inside test, f0 = a(x0, k0), r0 and, for
+// DP5(4), scipy's initial step (common.py:68-134, order = 4).  Record ws[i] = {a0, h0, r0};
+// h0 = -1 marks a ray that is already final (start inside the hole).
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool ADAPTIVE>
+__global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const double r_s = A.r_s;
+    double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
+    pk[0] = A.k0[i * 3 + 0];
+    pk[1] = A.k0[i * 3 + 1];
+    pk[2] = A.k0[i * 3 + 2];
+    if (A.x0) {
+        px[0] = A.x0[i * 3 + 0];
+        px[1] = A.x0[i * 3 + 1];
+        px[2] = A.x0[i * 3 + 2];
+    } else {
+        px[0] = A.x0s[0];
+        px[1] = A.x0s[1];
+        px[2] = A.x0s[2];
+    }
+    double *w = A.ws + i * 5;
+    const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+    if (r0 <= r_s) {
+        // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
+        store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+        w[3] = -1.0;
+        return;
+    }
+    accel<RHS>(px, pk, r_s, pa, pr);
+    if (ADAPTIVE) {
+        const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+        double isc[6];
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
+            double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
+            isc[c] = sk;
+            isc[3 + c] = sx;
+            double y0k = pk[c] * sk, y0x = px[c] * sx;
+            double f0k = pa[c] * sk, f0x = pk[c] * sx;
+            d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
+            d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
+        }
+        d0 = sqrt(d0 * (1.0 / 6.0));
+        d1 = sqrt(d1 * (1.0 / 6.0));
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, t_bound);
+        double x1[3], k1[3], f1[3], r1;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            x1[c] = __builtin_fma(h0, pk[c], px[c]);
+            k1[c] = __builtin_fma(h0, pa[c], pk[c]);
+        }
+        accel<RHS>(x1, k1, r_s, f1, r1);
+        double d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double dk = (f1[c] - pa[c]) * isc[c];
+            double dx = (k1[c] - pk[c]) * isc[3 + c];
+            d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
+        }
+        d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) {
+            h1 = fmax(1e-6, h0 * 1e-3);
+        } else {
+            double q = 0.01 / fmax(d1, d2);
+            // the fast path needs a normal fp32 range; outside it (degenerate inputs) use libm
+            h1 = (q > 1e-30 && q < 1e30) ? pow_0p2(q) : pow(q, 0.2);
+        }
+        ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, A.max_step));
+        if (!(ph >= 0.0)) ph = 0.0;  // NaN input: let the step loop fail it (STEP_TOO_SMALL / NaN flag)
+    }
+    w[0] = pa[0];
+    w[1] = pa[1];
+    w[2] = pa[2];
+    w[3] = ph;
+    w[4] = pr;
+}
+
+// ------------------------------------------------------------------------------------------
+// Resolve pass (one thread per ray, almost all exit at once): rays parked with EV_PENDING get
+// their crossing step recomputed, the quartic dense output built and the root located by Brent.
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool ADAPTIVE>
+__global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const uint32_t fl = A.flags[i];
+    if (!(fl & EV_PENDING)) return;
+    const double *e = A.end + i * 6;
+    const double *w = A.ws + i * 5;
+    double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
+    const double t = w[3], h = w[4];
+    if (ADAPTIVE)
+        dp54_resolve_event<RHS>(A, x, v, a1, t, h, fl & 3u, (uint32_t)i);
+    else
+        rk4_resolve_event<RHS>(A, x, v, a1, t, h, fl & 3u, (uint32_t)i);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1059,12 +1134,25 @@ __global__ void accel_kernel(const double *x, const double *k, double r_s, uint6
 // Launchers
 // ------------------------------------------------------------------------------------------
 template <int RHS, bool EX>
-static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipStream_t s)
+static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev)
 {
+    const unsigned gp = (unsigned)((a.n + 255) / 256), gr = (unsigned)((a.n + 63) / 64);
+    if (ev) (void)hipEventRecord(ev[0], s);
+    if (method == BHG_METHOD_RK4_)
+        hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
+    if (ev) (void)hipEventRecord(ev[1], s);
     if (method == BHG_METHOD_RK4_)
         hipLaunchKernelGGL((trace_rk4_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((trace_dp54_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
+    if (ev) (void)hipEventRecord(ev[2], s);
+    if (method == BHG_METHOD_RK4_)
+        hipLaunchKernelGGL((resolve_kernel<RHS, false>), dim3(gr), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL((resolve_kernel<RHS, true>), dim3(gr), dim3(64), 0, s, a);
+    if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }
 
@@ -1076,13 +1164,14 @@ static hipError_t occupancy_variant(int method, int *blocks_per_cu)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_dp54_kernel<RHS, EX>, 64, 0);
 }
 
-hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s)
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s,
+                        hipEvent_t *ev)
 {
     if (rhs == BHG_RHS_REDUCED_)
-        return has_exit ? launch_variant<BHG_RHS_REDUCED_, true>(a, method, grid, s)
-                        : launch_variant<BHG_RHS_REDUCED_, false>(a, method, grid, s);
-    return has_exit ? launch_variant<BHG_RHS_CHRISTOFFEL_, true>(a, method, grid, s)
-                    : launch_variant<BHG_RHS_CHRISTOFFEL_, false>(a, method, grid, s);
+        return has_exit ? launch_variant<BHG_RHS_REDUCED_, true>(a, method, grid, s, ev)
+                        : launch_variant<BHG_RHS_REDUCED_, false>(a, method, grid, s, ev);
+    return has_exit ? launch_variant<BHG_RHS_CHRISTOFFEL_, true>(a, method, grid, s, ev)
+                    : launch_variant<BHG_RHS_CHRISTOFFEL_, false>(a, method, grid, s, ev);
 }
 
 hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu)

@@ -149,6 +149,14 @@ int bhg_synchronize(bhg_context *ctx);
 /* The context's own non-blocking stream (a hipStream_t), used by the host-buffer calls. */
 void *bhg_context_stream(bhg_context *ctx);
 
+/* Per-pass timing of the trace calls.  A trace call runs three passes on the caller's stream:
+ * PREPARE (per-ray setup: f0, initial step), TRACE (the integrate loop; the dominant kernel) and
+ * RESOLVE (root search for rays that ended on an event).  With profiling enabled the library
+ * records HIP events around each pass on that stream; bhg_last_pass_ms() waits for the last call's
+ * events and returns {prepare, trace, resolve} in milliseconds. */
+int bhg_set_profiling(bhg_context *ctx, int enable);
+int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
+
 /* Kernel launch geometry chosen for the last bhg_trace* call (for DESIGN/bench reporting):
  * out[0] = workgroups, out[1] = threads per workgroup, out[2] = resident waves per CU,
  * out[3] = 1 if the persistent lane-refill kernel ran. */

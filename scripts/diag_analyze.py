@@ -1,0 +1,13 @@
+import numpy as np, sys
+d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+d = d[d[:, 1] > 0]
+t0, t1, it, ln = d[:, 0].astype(np.int64), d[:, 1].astype(np.int64), d[:, 2], d[:, 3]
+T0 = t0.min()
+life = (t1 - t0) / 100.0  # us (100 MHz)
+print("waves", len(d), "kernel span us", (t1.max() - T0) / 100.0)
+print("start spread us: p50 %.1f max %.1f" % (np.median(t0 - T0) / 100, (t0 - T0).max() / 100))
+print("end   time us: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile((t1 - T0) / 100.0, [0, 10, 50, 90, 100])))
+print("lifetime us: mean %.1f" % life.mean(), "iters/wave mean %.1f min %d max %d" % (it.mean(), it.min(), it.max()))
+print("lane utilisation %.4f" % (ln.sum() / (64.0 * it.sum())), "total lane-steps", ln.sum())
+print("shader clock GHz: mean %.3f" % np.mean(d[:, 4].astype(np.float64) / ((t1 - t0) * 10.0) / 1e3 * 1e3 / 1e3))
+print("us per iteration: %.3f" % (life.sum() / it.sum()))

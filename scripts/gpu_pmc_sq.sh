@@ -12,6 +12,6 @@ python3 - <<PY
 import csv, collections
 d=collections.defaultdict(list)
 for r in csv.DictReader(open("$R/gpurun_out/sq_$tag.csv")):
-    d[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k,v in d.items(): print(k, sum(v)/len(v))
+    if "trace_" in r["Kernel_Name"]: d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in sorted(d.items()): print(k, sum(v)/len(v))
 PY
