@@ -7,7 +7,7 @@ gfx950).  Nothing here computes geodesics on the CPU: without the built library 
 compute calls raise.
 """
 from . import _ffi
-from ._ffi import (FLAG_EXITED_SPHERE, FLAG_HIT_HORIZON, FLAG_MAX_STEPS, FLAG_NAN, FLAG_REACHED_END,
+from ._ffi import (FLAG_EXITED_SPHERE, FLAG_HIT_DISK, FLAG_HIT_HORIZON, FLAG_MAX_STEPS, FLAG_NAN, FLAG_REACHED_END,
                    FLAG_START_INSIDE, FLAG_STEP_TOO_SMALL, METHOD_DP54, METHOD_RK4, RHS_CHRISTOFFEL,
                    RHS_REDUCED, BhgError)
 from .integrator import GeodesicIntegratorSchwarzschild
@@ -15,7 +15,7 @@ from .raygen import camera_directions, python_random_stream
 
 __all__ = [
     "GeodesicIntegratorSchwarzschild", "camera_directions", "python_random_stream", "BhgError",
-    "FLAG_HIT_HORIZON", "FLAG_START_INSIDE", "FLAG_REACHED_END", "FLAG_EXITED_SPHERE",
+    "FLAG_HIT_HORIZON", "FLAG_HIT_DISK", "FLAG_START_INSIDE", "FLAG_REACHED_END", "FLAG_EXITED_SPHERE",
     "FLAG_MAX_STEPS", "FLAG_STEP_TOO_SMALL", "FLAG_NAN", "METHOD_DP54", "METHOD_RK4",
     "RHS_CHRISTOFFEL", "RHS_REDUCED",
 ]

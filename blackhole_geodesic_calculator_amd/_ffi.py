@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -27,6 +27,7 @@ FLAG_EXITED_SPHERE = 8
 FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
+FLAG_HIT_DISK = 128
 
 METHOD_DP54 = 0
 METHOD_RK4 = 1
@@ -62,6 +63,8 @@ class Params(C.Structure):
         ("rhs_form", C.c_int32),
         ("max_steps", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("disk_r_in", C.c_double),
+        ("disk_r_out", C.c_double),
     ]
 
 
@@ -146,9 +149,11 @@ def default_params() -> Params:
 
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
-                r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0) -> Params:
+                r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
+                disk_r_out=0.0) -> Params:
     return Params(float(r_s), float(lambda_end), float(max_step), float(rtol), float(atol),
-                  float(h_fixed), float(r_exit), int(method), int(rhs_form), int(max_steps), 0)
+                  float(h_fixed), float(r_exit), int(method), int(rhs_form), int(max_steps), 0,
+                  float(disk_r_in), float(disk_r_out))
 
 
 def device_count() -> int:
@@ -193,7 +198,7 @@ class Context:
     def last_launch(self):
         out = (C.c_int32 * 4)()
         _check(load().bhg_last_launch(self._h, out))
-        return {"workgroups": out[0], "threads": out[1], "waves_per_cu": out[2], "persistent": bool(out[3])}
+        return {"workgroups": out[0], "threads": out[1], "waves_per_cu": out[2], "passes": out[3]}
 
     @property
     def stream(self) -> int:

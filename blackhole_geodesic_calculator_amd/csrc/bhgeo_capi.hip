@@ -25,7 +25,8 @@ static_assert(BHG_FLAG_STEP_TOO_SMALL == bhg::BHG_FLAG_STEP_TOO_SMALL_, "flag mi
 static_assert(BHG_FLAG_NAN == bhg::BHG_FLAG_NAN_, "flag mismatch");
 static_assert(BHG_METHOD_DP54 == bhg::BHG_METHOD_DP54_ && BHG_METHOD_RK4 == bhg::BHG_METHOD_RK4_, "method mismatch");
 static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_, "rhs mismatch");
-static_assert(sizeof(bhg_params) == 72, "bhg_params layout is part of the ABI");
+static_assert(sizeof(bhg_params) == 88, "bhg_params layout is part of the ABI");
+static_assert(BHG_FLAG_HIT_DISK == bhg::BHG_FLAG_HIT_DISK_, "flag mismatch");
 
 namespace {
 
@@ -107,6 +108,9 @@ int validate(const bhg_params *p)
     }
     if (p->rhs_form != BHG_RHS_CHRISTOFFEL && p->rhs_form != BHG_RHS_REDUCED)
         return fail(BHG_E_INVALID, "unknown rhs_form");
+    if (!(p->disk_r_in >= 0.0) || !(p->disk_r_out >= 0.0) || !std::isfinite(p->disk_r_in) || !std::isfinite(p->disk_r_out))
+        return fail(BHG_E_INVALID, "disk radii must be finite and >= 0");
+    if (p->disk_r_out > 0.0 && p->disk_r_in > p->disk_r_out) return fail(BHG_E_INVALID, "disk_r_in > disk_r_out");
     return BHG_OK;
 }
 
@@ -143,6 +147,8 @@ void bhg_default_params(bhg_params *p)
     p->rhs_form = BHG_RHS_CHRISTOFFEL;
     p->max_steps = 0;
     p->reserved = 0;
+    p->disk_r_in = 0.0;
+    p->disk_r_out = 0.0;  // no disk
 }
 
 int bhg_create(int device, bhg_context **out)
@@ -255,11 +261,28 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
 
-    // workspace: 40 B/ray records (+ n bytes of flags when the caller does not want them).  Grown on
-    // demand: the first call at a new size allocates (not capturable); steady-state calls do not.
-    const size_t ws_rec = n * 5 * sizeof(double);
-    rc = ensure(&c->d_ws, &c->d_ws_bytes, ws_rec + (d_flags ? 0 : n));
+    // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
+    //   ws      [n][6] doubles  per-ray records handed between the passes
+    //   flags   [n] bytes       when the caller does not want flags
+    //   with a disk: n_steps / n_accepted [n] u32 when not wanted, two resume worklists [n] u32, two counts
+    const bool has_exit = p->r_exit > 0.0;
+    const bool has_disk = p->disk_r_out > 0.0;
+    const size_t sz_ws = n * 6 * sizeof(double);
+    const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
+    const size_t sz_u32 = n * sizeof(uint32_t);
+    const size_t sz_steps = (has_disk && !d_n_steps) ? sz_u32 : 0;
+    const size_t sz_acc = (has_disk && !d_n_accepted) ? sz_u32 : 0;
+    const size_t sz_wl = has_disk ? 2 * sz_u32 + 64 : 0;
+    rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + sz_wl + 64);
     if (rc != BHG_OK) return rc;
+    char *wsb = (char *)c->d_ws;
+    uint8_t *w_flags = (uint8_t *)(wsb + sz_ws);
+    uint32_t *w_steps = (uint32_t *)(wsb + sz_ws + sz_flags);
+    uint32_t *w_acc = (uint32_t *)(wsb + sz_ws + sz_flags + sz_steps);
+    char *w_wl = wsb + sz_ws + sz_flags + sz_steps + sz_acc;
+    w_wl += (8 - ((uintptr_t)w_wl & 7)) & 7;
+    unsigned long long *w_count = (unsigned long long *)w_wl;  // two counters
+    uint32_t *w_list[2] = {(uint32_t *)(w_wl + 16), (uint32_t *)(w_wl + 16 + sz_u32)};
 
     bhg::TraceArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -267,11 +290,15 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     a.x0 = d_x0;
     a.end = d_end;
     a.ws = (double *)c->d_ws;
-    a.flags = d_flags ? d_flags : (uint8_t *)c->d_ws + ws_rec;
-    a.n_steps = d_n_steps;
-    a.n_accepted = d_n_accepted;
+    a.flags = d_flags ? d_flags : w_flags;
+    a.n_steps = d_n_steps ? d_n_steps : (has_disk ? w_steps : nullptr);
+    a.n_accepted = d_n_accepted ? d_n_accepted : (has_disk ? w_acc : nullptr);
     a.counter = c->counter;
     a.n = n;
+    a.n_items = n;
+    a.worklist = nullptr;
+    a.worklist_out = has_disk ? w_list[0] : nullptr;
+    a.work_count_out = has_disk ? &w_count[0] : nullptr;
     if (!d_x0) {
         a.x0s[0] = x0_shared[0];
         a.x0s[1] = x0_shared[1];
@@ -284,11 +311,14 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     a.atol = p->atol;
     a.h_fixed = p->h_fixed;
     a.r_exit = p->r_exit;
+    a.disk_r_in = p->disk_r_in;
+    a.disk_r_out = p->disk_r_out;
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
-    const bool has_exit = p->r_exit > 0.0;
+    a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
+    const int evt = (has_exit ? 1 : 0) | (has_disk ? 2 : 0);
 
     int per_cu = 0;
-    HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, has_exit, &per_cu));
+    HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, evt, &per_cu));
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 32) per_cu = 32;
     if (const char *ov = std::getenv("BHGEO_WAVES_PER_CU")) {  // tuning/diagnostic override
@@ -305,7 +335,6 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
         if (!dbuf) HIP_TRY(hipMalloc((void **)&dbuf, 65536 * 8 * sizeof(unsigned long long)));
         a.diag = dbuf;
         if (const char *path = std::getenv("BHGEO_DIAG_DUMP")) {
-            // dump the PREVIOUS launch's stamps
             static unsigned long long host[65536 * 8];
             HIP_TRY(hipDeviceSynchronize());
             HIP_TRY(hipMemcpy(host, dbuf, sizeof(host), hipMemcpyDeviceToHost));
@@ -316,14 +345,35 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
         }
     }
 #endif
-    a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
     HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));  // 8 slice counters, one 256-byte line each
-    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, has_exit, (int)grid, s, c->profiling ? c->ev : nullptr));
+    if (has_disk) HIP_TRY(hipMemsetAsync(w_count, 0, 16, s));
+    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
     c->ev_valid = c->profiling;
+    c->last_launch[3] = 1;
+    if (has_disk) {
+        // Rays whose step crossed the disk plane outside the annulus carry on: the resolve pass has
+        // listed them; trace + resolve again over that list until it is empty.  Reading the count
+        // synchronises the stream, so with a disk this entry point is not asynchronous.
+        for (int pass = 0; pass < 4096; pass++) {
+            unsigned long long cnt = 0;
+            HIP_TRY(hipMemcpyAsync(&cnt, &w_count[pass & 1], sizeof(cnt), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (cnt == 0) break;
+            c->last_launch[3] = pass + 2;
+            a.n_items = cnt;
+            a.worklist = w_list[pass & 1];
+            a.worklist_out = w_list[(pass + 1) & 1];
+            a.work_count_out = &w_count[(pass + 1) & 1];
+            size_t g2 = (size_t)per_cu * (size_t)c->num_cus, b2 = ((size_t)cnt + 63) / 64;
+            if (g2 > b2) g2 = b2;
+            HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));
+            HIP_TRY(hipMemsetAsync(&w_count[(pass + 1) & 1], 0, sizeof(cnt), s));
+            HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)g2, s, nullptr));
+        }
+    }
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;
-    c->last_launch[3] = 1;
     return BHG_OK;
 }
 

@@ -14,6 +14,7 @@ constexpr uint32_t BHG_FLAG_EXITED_SPHERE_ = 8u;
 constexpr uint32_t BHG_FLAG_MAX_STEPS_ = 16u;
 constexpr uint32_t BHG_FLAG_STEP_TOO_SMALL_ = 32u;
 constexpr uint32_t BHG_FLAG_NAN_ = 64u;
+constexpr uint32_t BHG_FLAG_HIT_DISK_ = 128u;
 constexpr int BHG_METHOD_DP54_ = 0;
 constexpr int BHG_METHOD_RK4_ = 1;
 constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
@@ -28,10 +29,14 @@ struct TraceArgs {
     uint32_t *n_steps;           // [n] or nullptr
     uint32_t *n_accepted;        // [n] or nullptr
     unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
-    double *ws;                  // [n][5] per-ray workspace: prepare record {a0, h0, r0}, later event record {a1, t, h}
-    uint64_t n;
+    double *ws;                  // [n][6] per-ray records: prepare {a0, h0, r0, -}, park {a1, t, h, h_next}, resume {a, h, r, t}
+    uint64_t n;                  // rays in the call
+    uint64_t n_items;            // work items of this pass: n, or the length of worklist
+    const uint32_t *worklist;    // nullptr (item j = ray j) or ray indices to resume
+    uint32_t *worklist_out;      // rays the resolve pass hands to the next pass
+    unsigned long long *work_count_out;
     double x0s[3];
-    double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit;
+    double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, disk_r_in, disk_r_out;
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
     unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
@@ -62,9 +67,9 @@ hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
 
 // ev: nullptr, or 4 events recorded around prepare | trace | resolve on stream s
-hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s,
-                        hipEvent_t *ev);
-hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu);
+// evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
+hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
                         hipStream_t s);
 

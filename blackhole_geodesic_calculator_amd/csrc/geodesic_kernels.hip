@@ -266,6 +266,13 @@ __device__ __forceinline__ void dense_dir(const Dense &d, double t, double v[3])
     }
 }
 
+__device__ __forceinline__ double dense_z(const Dense &d, double t)
+{
+    double x[3];
+    dense_pos(d, t, x);
+    return x[2];
+}
+
 __device__ __forceinline__ double dense_g(const Dense &d, double t, double R)
 {
     double x[3];
@@ -359,13 +366,21 @@ struct WaveLds {
     double qx[3][64];
     double qk[3][64];
     double qa[3][64];  // FSAL acceleration at the start point
-    double qh[64];     // initial |h| (common.py:68-134)
+    double qh[64];     // |h| to try first (initial step, common.py:68-134; or the controller's next step)
     double qr[64];     // r at the start point
+    double qt[64];     // lambda at the start point (0 unless the ray is resumed)
     uint32_t qidx[64];
+    uint32_t qnatt[64], qnacc[64];
 };
 
-// flag value of a ray whose terminal event still has to be located by the resolve pass
-constexpr uint32_t EV_PENDING = 0x80u, EV_HORIZON = 1u, EV_EXIT = 2u;
+// Internal values of flags[i] between the passes (never visible after the call returns):
+//   EV_PENDING | kind : the ray's last accepted step crossed an event surface; the resolve pass
+//                       locates the root(s) (kind bits below)
+//   EV_RESUME         : the crossing was not terminal (disk plane outside the annulus); the ray
+//                       carries on from the end of that step in the next trace pass
+// No final flag value has both of the top bits and any of the low three bits set.
+constexpr uint32_t EV_PENDING = 0xC0u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_RESUME = 0xC8u;
+constexpr int EVT_EXIT = 1, EVT_DISK = 2;  // template bitmask: which optional events are compiled in
 
 struct Lane {
     double x[3], v[3], a1[3];
@@ -437,31 +452,53 @@ __device__ __forceinline__ uint64_t take_fetch(unsigned long long b, uint32_t sl
     return (local * NSLICE + slice) * 64ull;
 }
 
-// Fill the LDS ray queue with rays base .. base+63: coalesced loads of k0, x0 and the prepare
-// pass's record {a0, h0, r0}; rays that pass (h0 >= 0: not start-inside) are compacted with
-// ballot/mbcnt.
+// Fill the LDS ray queue with work items base .. base+63: coalesced loads of k0, x0 and the
+// prepare pass's record {a0, h0, r0} -- or, in a resume pass (A.worklist set), of the records the
+// resolve pass left in the rays' own slots.  Items that pass (h >= 0) are compacted with ballot/mbcnt.
 __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane, uint64_t base)
 {
-    const uint64_t i = base + lane;
-    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0;
-    if (i < A.n) {
-        const double *w = A.ws + i * 5;
-        pa[0] = w[0];
-        pa[1] = w[1];
-        pa[2] = w[2];
-        ph = w[3];
-        pr = w[4];
-        pk[0] = A.k0[i * 3 + 0];
-        pk[1] = A.k0[i * 3 + 1];
-        pk[2] = A.k0[i * 3 + 2];
-        if (A.x0) {
-            px[0] = A.x0[i * 3 + 0];
-            px[1] = A.x0[i * 3 + 1];
-            px[2] = A.x0[i * 3 + 2];
+    const uint64_t j = base + lane;
+    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0, pt = 0.0;
+    uint32_t natt = 0, nacc = 0;
+    uint64_t i = j;
+    if (j < A.n_items) {
+        if (A.worklist) {
+            i = A.worklist[j];
+            const double *e = A.end + i * 6;
+            px[0] = e[0];
+            px[1] = e[1];
+            px[2] = e[2];
+            pk[0] = e[3];
+            pk[1] = e[4];
+            pk[2] = e[5];
+            const double *w = A.ws + i * 6;
+            pa[0] = w[0];
+            pa[1] = w[1];
+            pa[2] = w[2];
+            ph = w[3];
+            pr = w[4];
+            pt = w[5];
+            natt = A.n_steps[i];
+            nacc = A.n_accepted[i];
         } else {
-            px[0] = A.x0s[0];
-            px[1] = A.x0s[1];
-            px[2] = A.x0s[2];
+            const double *w = A.ws + i * 6;
+            pa[0] = w[0];
+            pa[1] = w[1];
+            pa[2] = w[2];
+            ph = w[3];
+            pr = w[4];
+            pk[0] = A.k0[i * 3 + 0];
+            pk[1] = A.k0[i * 3 + 1];
+            pk[2] = A.k0[i * 3 + 2];
+            if (A.x0) {
+                px[0] = A.x0[i * 3 + 0];
+                px[1] = A.x0[i * 3 + 1];
+                px[2] = A.x0[i * 3 + 2];
+            } else {
+                px[0] = A.x0s[0];
+                px[1] = A.x0s[1];
+                px[2] = A.x0s[2];
+            }
         }
     }
     // All of this batch's loads must have landed HERE, for every lane: otherwise the compiler has
@@ -480,7 +517,10 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
         }
         Q.qh[s] = ph;
         Q.qr[s] = pr;
+        Q.qt[s] = pt;
         Q.qidx[s] = (uint32_t)i;
+        Q.qnatt[s] = natt;
+        Q.qnacc[s] = nacc;
     }
     wave_lds_sync();
     W.q_head = 0;
@@ -497,7 +537,7 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
             if (!W.have_pending) W.pending = issue_fetch(A, lane, W.slice);
             W.have_pending = false;
             const uint64_t base = take_fetch(W.pending, W.slice);
-            if (base >= A.n) {
+            if (base >= A.n_items) {
                 // this slice is dry: steal from the next one
                 W.slice = (W.slice + 1) % NSLICE;
                 if (++W.dry == NSLICE) W.exhausted = true;
@@ -521,9 +561,9 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
                 L.h_abs = Q.qh[s];
                 L.r_cur = Q.qr[s];
                 L.idx = Q.qidx[s];
-                L.t = 0.0;
-                L.n_att = 0;
-                L.n_acc = 0;
+                L.t = Q.qt[s];
+                L.n_att = Q.qnatt[s];
+                L.n_acc = Q.qnacc[s];
                 L.rejected = false;
                 L.active = true;
             }
@@ -618,12 +658,79 @@ __device__ __forceinline__ void dp54_stages(const double x[3], const double v[3]
 }
 
 
+// Visit the event roots of one accepted step in time order (handle_events sorts them, ivp.py:111-122;
+// ties keep the order horizon, exit, disk).  Horizon and sphere exit always end the ray; a disk-plane
+// crossing ends it only inside the annulus R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424).
+// g_r(t, R) = r(t) - R, g_z(t) = z(t), eval(t, x, v) = interpolated state.  Returns true if the ray ended.
+template <class GR, class GZ, class EV>
+__device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind, uint32_t idx, double t, double t_new,
+                                              const GR &g_r, const GZ &g_z, const EV &eval)
+{
+    const double INF = __builtin_inf();
+    double rh = INF, re = INF, rz = INF;
+    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return g_r(tt, A.r_s); }, t, t_new);
+    if (kind & EV_EXIT) re = brent_root([&](double tt) { return g_r(tt, A.r_exit); }, t, t_new);
+    if (kind & EV_DISK) rz = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
+    for (int it = 0; it < 2; it++) {
+        double tm;
+        uint32_t fl;
+        if (rh <= re && rh <= rz) {
+            tm = rh;
+            fl = BHG_FLAG_HIT_HORIZON_;
+        } else if (re <= rz) {
+            tm = re;
+            fl = BHG_FLAG_EXITED_SPHERE_;
+        } else {
+            tm = rz;
+            fl = BHG_FLAG_HIT_DISK_;
+        }
+        if (tm == INF) break;
+        double xe[3], ve[3];
+        eval(tm, xe, ve);
+        if (fl == BHG_FLAG_HIT_DISK_) {
+            const double R = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+            if (!(R >= A.disk_r_in && R <= A.disk_r_out)) {
+                rz = INF;  // crossed the plane outside the annulus: look at what comes later in the step
+                continue;
+            }
+        }
+        store_event_result(A, idx, xe, ve, fl);
+        return true;
+    }
+    return false;
+}
+
+// The step held no terminal event after all: the ray is final if the step reached lambda_end
+// (base.py:203-204), otherwise it is handed to the next trace pass, resuming at the step's end.
+__device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t idx, const double xn[3], const double vn[3],
+                                                 const double an[3], double t_new, double r_new, double h_next)
+{
+    if (t_new - A.lambda_end >= 0.0) {
+        store_event_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_);
+        return;
+    }
+    double *e = A.end + (size_t)idx * 6;
+    reinterpret_cast<double2 *>(e)[0] = make_double2(xn[0], xn[1]);
+    reinterpret_cast<double2 *>(e)[1] = make_double2(xn[2], vn[0]);
+    reinterpret_cast<double2 *>(e)[2] = make_double2(vn[1], vn[2]);
+    double *w = A.ws + (size_t)idx * 6;
+    w[0] = an[0];
+    w[1] = an[1];
+    w[2] = an[2];
+    w[3] = h_next;
+    w[4] = r_new;
+    w[5] = t_new;
+    A.flags[idx] = (uint8_t)EV_RESUME;
+    const unsigned long long slot = atomicAdd(A.work_count_out, 1ull);
+    A.worklist_out[slot] = idx;
+}
+
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
 template <int RHS>
 __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                   const double a1[3], double t, double h, uint32_t kind,
-                                                   uint32_t idx)
+                                                   const double a1[3], double t, double h, double h_next,
+                                                   uint32_t kind, uint32_t idx)
 {
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
     dp54_stages<RHS>(x, v, a1, h, A.r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
@@ -645,22 +752,14 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
         }
     }
     const double t_new = t + h;
-    double rh = 0.0, re = 0.0;
-    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return dense_g(d, tt, A.r_s); }, t, t_new);
-    if (kind & EV_EXIT) re = brent_root([&](double tt) { return dense_g(d, tt, A.r_exit); }, t, t_new);
-    double t_root;
-    uint32_t fl;
-    if ((kind & EV_HORIZON) && (!(kind & EV_EXIT) || rh <= re)) {  // earliest root wins (ivp.py:111-122)
-        t_root = rh;
-        fl = BHG_FLAG_HIT_HORIZON_;
-    } else {
-        t_root = re;
-        fl = BHG_FLAG_EXITED_SPHERE_;
-    }
-    double xe[3], ve[3];
-    dense_pos(d, t_root, xe);
-    dense_dir(d, t_root, ve);
-    store_event_result(A, idx, xe, ve, fl);
+    const bool ended = settle_events(
+        A, kind, idx, t, t_new, [&](double tt, double R) { return dense_g(d, tt, R); },
+        [&](double tt) { return dense_z(d, tt); },
+        [&](double tt, double xe[3], double ve[3]) {
+            dense_pos(d, tt, xe);
+            dense_dir(d, tt, ve);
+        });
+    if (!ended) finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -725,8 +824,8 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
 
 template <int RHS>
 __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                  const double a1[3], double t, double h, uint32_t kind,
-                                                  uint32_t idx)
+                                                  const double a1[3], double t, double h, double h_next,
+                                                  uint32_t kind, uint32_t idx)
 {
     Hermite d;
     double r_new;
@@ -740,21 +839,15 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
         d.a0[c] = a1[c];
     }
     const double t_new = t + h;
-    double rh = 0.0, re = 0.0;
-    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return hermite_g(d, tt, A.r_s); }, t, t_new);
-    if (kind & EV_EXIT) re = brent_root([&](double tt) { return hermite_g(d, tt, A.r_exit); }, t, t_new);
-    double t_root;
-    uint32_t fl;
-    if ((kind & EV_HORIZON) && (!(kind & EV_EXIT) || rh <= re)) {
-        t_root = rh;
-        fl = BHG_FLAG_HIT_HORIZON_;
-    } else {
-        t_root = re;
-        fl = BHG_FLAG_EXITED_SPHERE_;
-    }
-    double xe[3], ve[3];
-    hermite_eval(d, t_root, xe, ve);
-    store_event_result(A, idx, xe, ve, fl);
+    const bool ended = settle_events(
+        A, kind, idx, t, t_new, [&](double tt, double R) { return hermite_g(d, tt, R); },
+        [&](double tt) {
+            double xx[3], vv[3];
+            hermite_eval(d, tt, xx, vv);
+            return xx[2];
+        },
+        [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); });
+    if (!ended) finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -764,16 +857,18 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, uint32_t kind)
 {
+    // ws[idx] = {a1, t, h, |h| the controller chose for the NEXT step (L.h_abs, already updated)}
     double *e = A.end + (size_t)L.idx * 6;
     reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
     reinterpret_cast<double2 *>(e)[2] = make_double2(L.v[1], L.v[2]);
-    double *w = A.ws + (size_t)L.idx * 5;
+    double *w = A.ws + (size_t)L.idx * 6;
     w[0] = L.a1[0];
     w[1] = L.a1[1];
     w[2] = L.a1[2];
     w[3] = L.t;
     w[4] = h;
+    w[5] = L.h_abs;
     A.flags[L.idx] = (uint8_t)(EV_PENDING | kind);
     if (A.n_steps) A.n_steps[L.idx] = L.n_att;
     if (A.n_accepted) A.n_accepted[L.idx] = L.n_acc;
@@ -785,7 +880,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
 #ifndef BHG_DP54_WAVES_PER_SIMD
 #define BHG_DP54_WAVES_PER_SIMD 2
 #endif
-template <int RHS, bool HAS_EXIT>
+template <int RHS, int EVT>
 __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel(const TraceArgs A)
 {
     __shared__ WaveLds Q;
@@ -899,10 +994,12 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                     // events between step ends (ivp.py:109-126): horizon any direction, exit outward
                     const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
-                    const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    if (ev_h || ev_e) {
+                    const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                    const bool ev_d = (EVT & EVT_DISK) && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                                                           ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
+                    if (ev_h || ev_e || ev_d) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
-                        park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u));
+                        park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
                         L.active = false;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
@@ -939,7 +1036,7 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
 // ------------------------------------------------------------------------------------------
 // Fixed-step classic RK4 ("R-fine" regime).  Same persistent lane-refill wave.
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool HAS_EXIT>
+template <int RHS, int EVT>
 __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 {
     __shared__ WaveLds Q;
@@ -984,10 +1081,13 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 L.n_att++;
                 const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
-                const bool ev_e = HAS_EXIT && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                if (ev_h || ev_e) {
+                const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+                const bool ev_d = (EVT & EVT_DISK) && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                                                       ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
+                if (ev_h || ev_e || ev_d) {
                     L.n_acc = L.n_att;
-                    park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u));
+                    L.h_abs = hf;
+                    park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
                     L.active = false;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1016,7 +1116,7 @@ template <int RHS, bool ADAPTIVE>
 __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
+    if (i >= A.n_items) return;
     const double r_s = A.r_s;
     double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
     pk[0] = A.k0[i * 3 + 0];
@@ -1031,7 +1131,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         px[1] = A.x0s[1];
         px[2] = A.x0s[2];
     }
-    double *w = A.ws + i * 5;
+    double *w = A.ws + i * 6;
     const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
     if (r0 <= r_s) {
         // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
@@ -1099,18 +1199,19 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 template <int RHS, bool ADAPTIVE>
 __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= A.n_items) return;
+    const uint64_t i = A.worklist ? A.worklist[j] : j;
     const uint32_t fl = A.flags[i];
-    if (!(fl & EV_PENDING)) return;
+    if ((fl & 0xC0u) != EV_PENDING || (fl & 7u) == 0u) return;
     const double *e = A.end + i * 6;
-    const double *w = A.ws + i * 5;
+    const double *w = A.ws + i * 6;
     double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
-    const double t = w[3], h = w[4];
+    const double t = w[3], h = w[4], h_next = w[5];
     if (ADAPTIVE)
-        dp54_resolve_event<RHS>(A, x, v, a1, t, h, fl & 3u, (uint32_t)i);
+        dp54_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i);
     else
-        rk4_resolve_event<RHS>(A, x, v, a1, t, h, fl & 3u, (uint32_t)i);
+        rk4_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1133,20 +1234,23 @@ __global__ void accel_kernel(const double *x, const double *k, double r_s, uint6
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool EX>
+template <int RHS, int EVT>
 static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    const unsigned gp = (unsigned)((a.n + 255) / 256), gr = (unsigned)((a.n + 63) / 64);
+    const unsigned gp = (unsigned)((a.n_items + 255) / 256), gr = (unsigned)((a.n_items + 63) / 64);
+    const bool first = a.worklist == nullptr;  // resume passes skip the prepare pass
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (method == BHG_METHOD_RK4_)
-        hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
+    if (first) {
+        if (method == BHG_METHOD_RK4_)
+            hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
+    }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (method == BHG_METHOD_RK4_)
-        hipLaunchKernelGGL((trace_rk4_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((trace_rk4_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((trace_dp54_kernel<RHS, EX>), dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((trace_dp54_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
     if (ev) (void)hipEventRecord(ev[2], s);
     if (method == BHG_METHOD_RK4_)
         hipLaunchKernelGGL((resolve_kernel<RHS, false>), dim3(gr), dim3(64), 0, s, a);
@@ -1156,31 +1260,46 @@ static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipSt
     return hipGetLastError();
 }
 
-template <int RHS, bool EX>
+template <int RHS, int EVT>
 static hipError_t occupancy_variant(int method, int *blocks_per_cu)
 {
     if (method == BHG_METHOD_RK4_)
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_rk4_kernel<RHS, EX>, 64, 0);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_dp54_kernel<RHS, EX>, 64, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_rk4_kernel<RHS, EVT>, 64, 0);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_dp54_kernel<RHS, EVT>, 64, 0);
 }
 
-hipError_t launch_trace(const TraceArgs &a, int method, int rhs, bool has_exit, int grid, hipStream_t s,
-                        hipEvent_t *ev)
+template <int RHS>
+static hipError_t launch_rhs(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    if (rhs == BHG_RHS_REDUCED_)
-        return has_exit ? launch_variant<BHG_RHS_REDUCED_, true>(a, method, grid, s, ev)
-                        : launch_variant<BHG_RHS_REDUCED_, false>(a, method, grid, s, ev);
-    return has_exit ? launch_variant<BHG_RHS_CHRISTOFFEL_, true>(a, method, grid, s, ev)
-                    : launch_variant<BHG_RHS_CHRISTOFFEL_, false>(a, method, grid, s, ev);
+    switch (evt) {
+    case 0: return launch_variant<RHS, 0>(a, method, grid, s, ev);
+    case 1: return launch_variant<RHS, 1>(a, method, grid, s, ev);
+    case 2: return launch_variant<RHS, 2>(a, method, grid, s, ev);
+    default: return launch_variant<RHS, 3>(a, method, grid, s, ev);
+    }
 }
 
-hipError_t trace_occupancy(int method, int rhs, bool has_exit, int *blocks_per_cu)
+template <int RHS>
+static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
 {
-    if (rhs == BHG_RHS_REDUCED_)
-        return has_exit ? occupancy_variant<BHG_RHS_REDUCED_, true>(method, blocks_per_cu)
-                        : occupancy_variant<BHG_RHS_REDUCED_, false>(method, blocks_per_cu);
-    return has_exit ? occupancy_variant<BHG_RHS_CHRISTOFFEL_, true>(method, blocks_per_cu)
-                    : occupancy_variant<BHG_RHS_CHRISTOFFEL_, false>(method, blocks_per_cu);
+    switch (evt) {
+    case 0: return occupancy_variant<RHS, 0>(method, blocks_per_cu);
+    case 1: return occupancy_variant<RHS, 1>(method, blocks_per_cu);
+    case 2: return occupancy_variant<RHS, 2>(method, blocks_per_cu);
+    default: return occupancy_variant<RHS, 3>(method, blocks_per_cu);
+    }
+}
+
+hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev)
+{
+    return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
+                                   : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
+}
+
+hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
+{
+    return rhs == BHG_RHS_REDUCED_ ? occupancy_rhs<BHG_RHS_REDUCED_>(method, evt, blocks_per_cu)
+                                   : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }
 
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,

@@ -48,17 +48,21 @@ class GeodesicIntegratorSchwarzschild:
     def context(self) -> _ffi.Context:
         return self._ctx
 
-    def params(self, max_step=np.inf, curve_end=50.0, r_exit=0.0) -> _ffi.Params:
+    def params(self, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None) -> _ffi.Params:
         if max_step is None or max_step == -1:  # the engine's "unset" sentinel (:59-60)
             max_step = np.inf
         return _ffi.make_params(r_s=self.r_s, lambda_end=curve_end, max_step=max_step, rtol=self.rtol,
                                 atol=self.atol, h_fixed=self.h_fixed, r_exit=r_exit,
                                 method=_METHODS[self.method], rhs_form=_RHS[self.rhs_form],
-                                max_steps=self.max_steps)
+                                max_steps=self.max_steps, disk_r_in=disk[0] if disk else 0.0,
+                                disk_r_out=disk[1] if disk else 0.0)
 
     # ------------------------------------------------------------------------------------
-    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0):
+    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None):
         """Batched solve.  k0[N,3] (or [...,3]); x0[3] shared origin or same leading shape as k0.
+        r_exit: outward sphere-exit radius (Limited engine's ray_trace, Limited...py:273-278);
+        disk=(R_in, R_out): thin disk in z = 0, first crossing inside the annulus ends the ray with
+        FLAG_HIT_DISK and the crossing point in ray_end (checkHitDisk, Limited...py:413-438).
 
         Returns dict with
             ray_end[..., 6]            position (0:3) and direction (3:6) at the end of each curve
@@ -70,7 +74,7 @@ class GeodesicIntegratorSchwarzschild:
         k0f = k0.reshape(-1, 3)
         x0 = np.asarray(x0, dtype=np.float64)
         x0f = x0 if x0.ndim == 1 else x0.reshape(-1, 3)
-        end, flags, steps, acc = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit))
+        end, flags, steps, acc = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit, disk))
         return {
             "ray_end": end.reshape(lead + (6,)),
             "ray_blackhole_hit": ((flags & _ffi.FLAG_HIT_HORIZON) != 0).astype(np.uint8).reshape(lead),

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 1
+#define BHG_ABI_VERSION 2
 
 /* return codes */
 #define BHG_OK 0
@@ -63,6 +63,7 @@ extern "C" {
 #define BHG_FLAG_MAX_STEPS 16u      /* attempted-step cap hit */
 #define BHG_FLAG_STEP_TOO_SMALL 32u /* scipy's failure mode (rk.py:132-133) */
 #define BHG_FLAG_NAN 64u            /* non-finite end state */
+#define BHG_FLAG_HIT_DISK 128u      /* crossed z = 0 inside the annulus (LimitedRelativisticRenderEngine.py:413-438) */
 
 /* integrators */
 #define BHG_METHOD_DP54 0 /* Dormand-Prince 5(4) with scipy RK45's controller (README.md:196) */
@@ -84,6 +85,9 @@ typedef struct bhg_params {
     int32_t rhs_form;   /* BHG_RHS_* */
     uint32_t max_steps; /* cap on attempted steps per ray; 0 = library default (1<<20) */
     uint32_t reserved;  /* must be 0 */
+    double disk_r_in;   /* thin disk in the plane z = 0 (BH-centred frame): the ray ends at its first */
+    double disk_r_out;  /* crossing with R_in <= sqrt(x^2+y^2) <= R_out; off when disk_r_out == 0
+                           (disk_on / R_in / R_out of LimitedRelativisticRenderEngine.py:283-286) */
 } bhg_params;
 
 typedef struct bhg_context bhg_context;
@@ -113,8 +117,9 @@ int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is
 /* Device buffers (all d_* are device addresses on ctx's device; x0_shared is a HOST [3] array or
  * NULL when d_x0 [n][3] is given).  Enqueues on `stream` (a hipStream_t; NULL = HIP's null
  * stream, as everywhere in HIP; bhg_context_stream() gives the context's own stream) and
- * returns without synchronising.  Two calls on one context must not be in flight at once:
- * they share the context's work counter. */
+ * returns without synchronising (exception: with a disk the call loops over resume passes and
+ * synchronises the stream).  Two calls on one context must not be in flight at once: they share
+ * the context's work counters and workspace. */
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
@@ -159,7 +164,7 @@ int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
 
 /* Kernel launch geometry chosen for the last bhg_trace* call (for DESIGN/bench reporting):
  * out[0] = workgroups, out[1] = threads per workgroup, out[2] = resident waves per CU,
- * out[3] = 1 if the persistent lane-refill kernel ran. */
+ * out[3] = number of trace passes the call took (1 unless disk crossings had to be resumed). */
 int bhg_last_launch(bhg_context *ctx, int32_t out[4]);
 
 #ifdef __cplusplus

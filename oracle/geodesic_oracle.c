@@ -12,6 +12,10 @@
  *   - the ODE and metric stated in the reference README            (README.md:162-174, :198-209)
  *   - the call-site contract of calc_trajectory                    (raytracer/RelativisticRenderEngine.py:134, :281, :293-313)
  *   - the sphere-exit semantics of the Limited engine's ray_trace  (raytracer/LimitedRelativisticRenderEngine.py:273-278)
+ *   - its thin-disk test: first z sign change whose crossing point lies in the annulus
+ *     R_in <= R <= R_out                                            (raytracer/LimitedRelativisticRenderEngine.py:413-438)
+ *     -- located here on the step's dense output (a scipy event g = z) instead of by linear
+ *     interpolation between trajectory samples (:419-421)
  *   - scipy 1.15.3's RK45 (the integrator README.md:196 names):    scipy/integrate/_ivp/rk.py:14-71 (rk_step),
  *     :111-176 (_step_impl), :377-404 (tableau, dense output P), common.py:63-134 (norm,
  *     select_initial_step), ivp.py:51-76 (brentq event root), :109-126 (find_active_events),
@@ -42,6 +46,7 @@
 #define BHGO_FLAG_MAX_STEPS 16u
 #define BHGO_FLAG_STEP_TOO_SMALL 32u
 #define BHGO_FLAG_NAN 64u
+#define BHGO_FLAG_HIT_DISK 128u
 
 #define BHGO_METHOD_DP54 0
 #define BHGO_METHOD_RK4 1
@@ -60,6 +65,8 @@ typedef struct {
     int32_t rhs_form;  /* BHGO_RHS_* */
     uint32_t max_steps; /* cap on attempted steps per ray, 0 = no cap */
     uint32_t reserved;
+    double disk_r_in;  /* thin disk in the plane z = 0: annulus R_in <= R <= R_out; off when R_out <= 0 */
+    double disk_r_out; /* (LimitedRelativisticRenderEngine.py:283-286, :413-438) */
 } bhgo_params;
 
 /* ---------------------------------------------------------------------------------------
@@ -276,6 +283,7 @@ typedef struct {
     const dense_t *dn;
     const hermite_t *hm;
     double R;
+    int zmode; /* 0: g = r - R; 1: g = z (disk plane) */
 } evfun_t;
 
 static double ev_eval(const evfun_t *e, double t)
@@ -285,6 +293,7 @@ static double ev_eval(const evfun_t *e, double t)
         dense_eval(e->dn, t, y);
     else
         hermite_eval(e->hm, t, y);
+    if (e->zmode) return y[5];
     return radius(y) - e->R;
 }
 
@@ -357,39 +366,65 @@ static void pack_end(const double y[6], double end[6])
     end[5] = y[4];
 }
 
-/* Events after an accepted step (ivp.py:109-126, :673-694).  Both events are terminal; when
-   both fire in one step the earlier root wins (handle_events sorts roots, ivp.py:111-122).
-   Returns 0 = none, else flag bit; *t_root and y_root filled. */
+/* Events after an accepted step (ivp.py:109-126, :673-694).  Horizon and sphere exit are terminal;
+   the disk-plane crossing g = z is terminal only when the crossing point lies in the annulus
+   (LimitedRelativisticRenderEngine.py:423-424), otherwise the ray carries on.  Roots are visited
+   in time order (handle_events sorts them, ivp.py:111-122); the first terminal one wins.
+   Returns 0 = carry on, else the flag bit; *t_root and y_root filled. */
 static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, double g_e,
-                             double g_e_new, const evfun_t *base, double t_old, double t,
-                             double *t_root, double y_root[6])
+                             double g_e_new, double z_old, double z_new, const evfun_t *base,
+                             double t_old, double t, double *t_root, double y_root[6])
 {
     int hor = ((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0));
     int ext = (p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0); /* direction = +1 */
-    if (!hor && !ext) return 0;
-    double rh = 0, re = 0;
+    int dsk = (p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0)));
+    if (!hor && !ext && !dsk) return 0;
+    double root[3];
+    uint32_t flag[3];
+    int n = 0;
     evfun_t e = *base;
     if (hor) {
         e.R = p->r_s;
-        rh = brentq(&e, t_old, t);
+        e.zmode = 0;
+        root[n] = brentq(&e, t_old, t);
+        flag[n++] = BHGO_FLAG_HIT_HORIZON;
     }
     if (ext) {
         e.R = p->r_exit;
-        re = brentq(&e, t_old, t);
+        e.zmode = 0;
+        root[n] = brentq(&e, t_old, t);
+        flag[n++] = BHGO_FLAG_EXITED_SPHERE;
     }
-    uint32_t flag;
-    if (hor && (!ext || rh <= re)) {
-        *t_root = rh;
-        flag = BHGO_FLAG_HIT_HORIZON;
-    } else {
-        *t_root = re;
-        flag = BHGO_FLAG_EXITED_SPHERE;
+    if (dsk) {
+        e.zmode = 1;
+        root[n] = brentq(&e, t_old, t);
+        flag[n++] = BHGO_FLAG_HIT_DISK;
     }
-    if (e.kind == 0)
-        dense_eval(e.dn, *t_root, y_root);
-    else
-        hermite_eval(e.hm, *t_root, y_root);
-    return flag;
+    /* stable insertion sort by root time (ties keep the order horizon, exit, disk) */
+    for (int i = 1; i < n; i++)
+        for (int j = i; j > 0 && root[j] < root[j - 1]; j--) {
+            double tr = root[j];
+            root[j] = root[j - 1];
+            root[j - 1] = tr;
+            uint32_t tf = flag[j];
+            flag[j] = flag[j - 1];
+            flag[j - 1] = tf;
+        }
+    for (int i = 0; i < n; i++) {
+        double y[6];
+        if (e.kind == 0)
+            dense_eval(e.dn, root[i], y);
+        else
+            hermite_eval(e.hm, root[i], y);
+        if (flag[i] == BHGO_FLAG_HIT_DISK) {
+            double R = sqrt(y[1] * y[1] + y[3] * y[3]);
+            if (!(R >= p->disk_r_in && R <= p->disk_r_out)) continue; /* crossed outside the annulus */
+        }
+        *t_root = root[i];
+        memcpy(y_root, y, sizeof(double) * 6);
+        return flag[i];
+    }
+    return 0;
 }
 
 typedef struct {
@@ -488,14 +523,16 @@ static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0
 
         double g_h_new = radius(y) - p->r_s;
         double g_e_new = radius(y) - p->r_exit;
+        double z_old = y_old[5], z_new = y[5];
         dense_t dn;
-        evfun_t base = {0, &dn, NULL, 0.0};
+        evfun_t base = {0, &dn, NULL, 0.0, 0};
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
-                  ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0));
+                  ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0)) ||
+                  ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0))));
         if (any) {
             dense_build(&dn, t_old, t, y_old, K);
             double t_root, y_root[6];
-            uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, &base, t_old, t, &t_root, y_root);
+            uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, z_old, z_new, &base, t_old, t, &t_root, y_root);
             if (fl) {
                 res->flags |= fl;
                 t = t_root;
@@ -570,9 +607,9 @@ static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[
         memcpy(f, f_new, sizeof(f));
         double g_h_new = radius(y) - p->r_s;
         double g_e_new = radius(y) - p->r_exit;
-        evfun_t base = {1, NULL, &hm, 0.0};
+        evfun_t base = {1, NULL, &hm, 0.0, 0};
         double t_root, y_root[6];
-        uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, &base, t_old, t, &t_root, y_root);
+        uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, hm.y0[5], hm.y1[5], &base, t_old, t, &t_root, y_root);
         if (fl) {
             res->flags |= fl;
             t = t_root;

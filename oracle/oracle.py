@@ -22,6 +22,7 @@ FLAG_EXITED_SPHERE = 8
 FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
+FLAG_HIT_DISK = 128
 
 METHOD_DP54 = 0
 METHOD_RK4 = 1
@@ -42,13 +43,16 @@ class Params(C.Structure):
         ("rhs_form", C.c_int32),
         ("max_steps", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("disk_r_in", C.c_double),
+        ("disk_r_out", C.c_double),
     ]
 
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
-                r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0):
+                r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
+                disk_r_out=0.0):
     return Params(r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, method, rhs_form,
-                  max_steps, 0)
+                  max_steps, 0, disk_r_in, disk_r_out)
 
 
 def build(force=False):

@@ -150,10 +150,11 @@ FLAG_EXITED_SPHERE = 8
 FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
+FLAG_HIT_DISK = 128
 
 
 def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
-              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None):
+              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None, disk=None):
     """Integrate one null geodesic with scipy.solve_ivp; returns a dict.
 
     Events: horizon r - r_s = 0 (terminal, any direction); optional outward sphere exit
@@ -180,6 +181,14 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
         ev_exit.terminal = True
         ev_exit.direction = 1.0
         events.append(ev_exit)
+    if disk is not None:
+        # thin disk in z = 0 (LimitedRelativisticRenderEngine.py:413-438): a NON-terminal scipy event
+        # g = z; afterwards the crossings are visited in time order and the first one inside the
+        # annulus R_in <= R <= R_out ends the ray there (what came after is discarded)
+        def ev_disk(_t, y):
+            return y[5]
+
+        events.append(ev_disk)
     t_eval = None
     if nr_points_curve:
         t_eval = np.linspace(0.0, lambda_end, nr_points_curve)
@@ -201,6 +210,16 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
         te, ye = (sol.t[-1], sol.y[:, -1])
     if ye is None:  # t_eval path: last grid point == lambda_end
         ye = sol.y[:, -1]
+    if disk is not None:
+        r_in, r_out = disk
+        for td, yd in zip(sol.t_events[-1], sol.y_events[-1]):
+            R = np.sqrt(yd[1] * yd[1] + yd[3] * yd[3])
+            if r_in <= R <= r_out and td <= te:
+                flags, te, ye = FLAG_HIT_DISK, td, yd
+                # steps up to and including the one that contains the crossing
+                n_acc = int(np.searchsorted(sol.t, td, side="left"))
+                out["n_accepted_disk"] = n_acc
+                break
     out.update(
         flags=flags,
         end=np.array([ye[1], ye[3], ye[5], ye[0], ye[2], ye[4]]),
@@ -210,6 +229,9 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
         n_accepted=(len(sol.t) - 1) if t_eval is None else -1,
         sol=sol,
     )
+    if "n_accepted_disk" in out:
+        out["n_accepted"] = out["n_accepted_disk"]
+        out["n_attempted"] = -1  # scipy kept integrating past the disk: attempted count not comparable
     return out
 
 

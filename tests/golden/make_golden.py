@@ -155,5 +155,31 @@ def main():
          max_step=np.inf, rtol=1e-3, atol=1e-6, **pack(res))
 
 
+def main_disk():
+    # ---- 9. thin disk in z = 0 (LimitedRelativisticRenderEngine.py:283-286, :413-438): config-3 like
+    # geometry, camera at r = 30 seen from five inclinations, annulus 4.5 .. 10.5 r_s (0.15 .. 0.35 x ratio 30)
+    rng = np.random.default_rng(9)
+    ks, xs = [], []
+    for inc_deg in (85.0, 80.0, 60.0, 30.0, 5.0):
+        inc = math.radians(inc_deg)
+        cam = np.array([30 * math.sin(inc), 0.0, 30 * math.cos(inc)])
+        aim = rng.normal(size=(40, 3)) * np.array([9.0, 9.0, 1.0])
+        d = aim - cam
+        ks.append(d / np.linalg.norm(d, axis=1)[:, None])
+        xs.append(np.tile(cam, (40, 1)))
+    k0, x0 = np.concatenate(ks), np.concatenate(xs)
+    end, flags, nacc, tend = [], [], [], []
+    for i in range(len(k0)):
+        r = sr.trace_ray(k0[i], x0[i], r_s=1.0, lambda_end=80.0, form="christoffel", disk=(4.5, 10.5))
+        end.append(r["end"]); flags.append(r["flags"]); nacc.append(r["n_accepted"]); tend.append(r["t_end"])
+    save("disk", k0=k0, x0=x0, r_s=1.0, lambda_end=80.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
+         disk_r_in=4.5, disk_r_out=10.5, end=np.array(end), flags=np.array(flags, np.uint8),
+         n_accepted=np.array(nacc, np.uint32), t_end=np.array(tend))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "disk":
+        main_disk()
+    else:
+        main()
+        main_disk()

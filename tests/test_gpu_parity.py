@@ -7,6 +7,10 @@ Stated tolerances (fp64):
     tolerances (rtol <= 1e-6) -- that form sums 1/(r-r_s)^2 terms that cancel, so close to the
     horizon its error estimate is rounding noise and an accept/reject can flip; at most 0.5 % of
     rays, horizon rays only, step counts within 3 (allow_flips=True below).
+  * horizon rays additionally get 1e-6 (their end state sits on the coordinate singularity, where
+    k^i diverges; the engine only reads their flag, RelativisticRenderEngine.py:242-244);
+  * disk hits additionally get 1e-11 |k| / |k_z| (a plane crossing is located only as sharply as
+    the ray is steep);
   * end state: |gpu - oracle| <= TOL_END + COND * S_i, where S_i is the oracle's OWN sensitivity
     of ray i to a 1-ulp perturbation of k0 (measured per ray, in the test).  The device kernel
     re-associates the RK sums (Nystrom form, FMA); rays that orbit near the photon sphere amplify
@@ -51,6 +55,14 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
     if len(end):
         fin = np.isfinite(o["end"]).all(1)
         tol = TOL_END + COND * np.nan_to_num(_sensitivity(oracle, k0, x0, o["end"], **kw), nan=np.inf, posinf=np.inf)
+        # horizon rays end AT the coordinate singularity: k^i and (Christoffel form) the rounding noise of
+        # the 1/(r-r_s) terms grow without bound there; the engine never reads this state (:242-244)
+        tol = tol + np.where((o["flags"] & 1) != 0, 1e-6, 0.0)
+        # a disk-plane crossing is only as well located as the ray is steep: dt = dz / |k_z|
+        dsk = o["flags"] == 128
+        if dsk.any():
+            steep = np.abs(o["end"][:, 5]) / np.linalg.norm(o["end"][:, 3:6], axis=1)
+            tol = tol + np.where(dsk, 1e-11 / np.maximum(steep, 1e-12), 0.0)
         assert np.all(d[fin] <= tol[fin]), f"worst end-state excess {np.max(d[fin] - tol[fin])}"
     return end, flags, steps, d
 
@@ -153,6 +165,47 @@ def test_sphere_exit_event(ctx, oracle):
     ex = flags == 8
     assert ex.sum() > 0.8 * n
     assert np.abs(np.linalg.norm(end[ex, 0:3], axis=1) - 30.0).max() < 1e-9
+
+
+def _disk_rays(n, seed, inc_deg):
+    inc = math.radians(inc_deg)
+    cam = np.array([30 * math.sin(inc), 0.0, 30 * math.cos(inc)])
+    aim = np.random.default_rng(seed).normal(size=(n, 3)) * np.array([9.0, 9.0, 1.0])
+    d = aim - cam
+    return d / np.linalg.norm(d, axis=1)[:, None], cam
+
+
+@pytest.mark.parametrize("rhs_form", [0, 1])
+def test_disk_golden_and_oracle(ctx, oracle, rhs_form):
+    """Thin-disk crossing (config 3 geometry): scipy golden vectors and the oracle."""
+    g = load_golden("disk")
+    kw = dict(r_s=1.0, lambda_end=80.0, disk_r_in=4.5, disk_r_out=10.5, rhs_form=rhs_form)
+    end, flags, steps, d = _compare(ctx, oracle, g["k0"], g["x0"], **kw)
+    assert np.array_equal(flags, g["flags"])
+    assert np.abs(end - g["end"]).max() < 1e-8
+    assert ctx.last_launch()["passes"] >= 2  # plane crossings outside the annulus were resumed
+
+
+@pytest.mark.parametrize("inc_deg", [85.0, 80.0, 60.0, 30.0, 5.0])
+def test_disk_five_inclinations(ctx, oracle, inc_deg):
+    k, cam = _disk_rays(20000, int(inc_deg), inc_deg)
+    end, flags, steps, d = _compare(ctx, oracle, k, cam, r_s=1.0, lambda_end=80.0, disk_r_in=4.5, disk_r_out=10.5)
+    disk = flags == 128
+    assert disk.sum() > 1000
+    R = np.hypot(end[disk, 0], end[disk, 1])
+    assert np.abs(end[disk, 2]).max() < 1e-12 and R.min() >= 4.5 and R.max() <= 10.5
+    assert np.all((flags == 128) | (flags == 4) | (flags == 1))
+
+
+def test_disk_with_exit_sphere_rk4_and_fine(ctx, oracle):
+    k, cam = _disk_rays(3000, 7, 70.0)
+    _compare(ctx, oracle, k, cam, r_s=1.0, lambda_end=100.0, disk_r_in=3.0, disk_r_out=12.0, r_exit=30.5)
+    _compare(ctx, oracle, k, cam, r_s=1.0, lambda_end=80.0, disk_r_in=4.5, disk_r_out=10.5, method=1, h_fixed=0.2)
+    _compare(ctx, oracle, k[:500], cam, r_s=1.0, lambda_end=80.0, disk_r_in=4.5, disk_r_out=10.5, max_step=0.25)
+    # a disk nobody hits (tiny annulus far away) must not change anything
+    a = ctx.trace(k, cam, _params(r_s=1.0, lambda_end=80.0))
+    b = ctx.trace(k, cam, _params(r_s=1.0, lambda_end=80.0, disk_r_in=500.0, disk_r_out=501.0))
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
 @pytest.mark.parametrize("rhs_form", [0, 1])

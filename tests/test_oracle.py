@@ -138,3 +138,19 @@ def test_rk4_converges_to_dp54(oracle):
     assert same.mean() > 0.9
     esc = same & (a["flags"] == oracle.FLAG_REACHED_END)
     assert np.median(np.abs(a["end"] - b["end"])[esc].max(1)) < 1e-5
+
+
+def test_oracle_disk_crossing_matches_scipy_golden(oracle):
+    """Thin disk (LimitedRelativisticRenderEngine.py:413-438) as a scipy event g = z."""
+    g = load_golden("disk")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=80.0, disk_r_in=float(g["disk_r_in"]),
+                     disk_r_out=float(g["disk_r_out"]))
+    assert np.array_equal(o["flags"], g["flags"])
+    assert np.array_equal(o["n_accepted"], g["n_accepted"])
+    # a crossing time is only as well determined as the ray is steep: dt = dz / |k_z|
+    steep = np.abs(g["end"][:, 5]) / np.linalg.norm(g["end"][:, 3:6], axis=1)
+    assert np.all(np.abs(o["end"] - g["end"]).max(1) < 5e-9 + 1e-12 / np.maximum(steep, 1e-12))
+    disk = o["flags"] == oracle.FLAG_HIT_DISK
+    assert disk.sum() > 30
+    R = np.hypot(o["end"][disk, 0], o["end"][disk, 1])
+    assert np.abs(o["end"][disk, 2]).max() < 1e-12 and R.min() >= 4.5 and R.max() <= 10.5
