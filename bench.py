@@ -108,29 +108,12 @@ def main():
     k0 = None
 
     # frame end: per-pixel RGBA (fp32, what Blender's layer.rect holds) handed to the frame owner.
-    # N > 1: ONE gather per frame over RCCL, issued asynchronously so it overlaps the next
-    # frame's trace; two send slabs so the next shade cannot overwrite a slab in flight.
-    pmax = bdist.max_pixels_per_rank(W, H, a.tile, world) if world > 1 else P
-    slabs = [torch.zeros((pmax, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-    recv = [[torch.empty((pmax, 4), dtype=torch.float32, device="cuda") for _ in range(world)] for _ in range(2)] \
-        if (world > 1 and rank == 0) else [None, None]
-    pending = [None, None]
+    # N > 1: ONE gather per frame over RCCL, issued asynchronously so it overlaps the next frame's
+    # trace (dist.FrameGatherer: two slabs in rotation; rank 0 scatters into frame order).
+    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda")
     kernel_ms = []
-    # rank 0 scatters the gathered slabs into frame order (pixel ids per rank, resident on device)
-    frame_img = torch.empty((H * W, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
-    pix_of = [torch.from_numpy(bdist.rank_pixels(W, H, a.tile, r, world)).cuda() for r in range(world)] if rank == 0 else None
-
-    def finish(b):
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-            if rank == 0:
-                for r in range(world):
-                    frame_img[pix_of[r]] = recv[b][r][: len(pix_of[r])]
 
     def step(i, timed):
-        b = i & 1
-        finish(b)
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -140,16 +123,10 @@ def main():
             kernel_ms.append((e0, e1))
         else:
             fr.trace(params)
-        rgba = fr.shade()
-        slabs[b][:P].copy_(rgba)
-        if world > 1:
-            pending[b] = dist.gather(slabs[b], recv[b], dst=0, async_op=True)
-        else:
-            frame_img[pix_of[0]] = slabs[b][:P]
+        gatherer.submit(i, fr.shade())
 
     def barrier():
-        for b in (0, 1):
-            finish(b)
+        gatherer.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -68,3 +68,69 @@ def gather_frame(local, width: int, height: int, tile: int, group=None, dst: int
         px = torch.from_numpy(rank_pixels(W, H, tile, r, world)).to(local.device)
         out[px] = bufs[r][: len(px)]
     return out.reshape(H, W, C_)
+
+
+class FrameGatherer:
+    """The frame-end exchange of a sharded frame: ONE gather per frame of this rank's per-pixel
+    slab to rank `dst`, issued asynchronously (it overlaps the next frame's trace) with two slabs in
+    rotation so a slab in flight is never overwritten.  Rank dst scatters the slabs into frame order.
+    Works over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests)."""
+
+    def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist if dist.is_initialized() else None
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank = dist.get_rank(group) if self.dist else 0
+        self.W, self.H, self.tile = int(width), int(height), int(tile)
+        dtype = dtype or torch.float32
+        self.P = len(rank_pixels(self.W, self.H, tile, self.rank, self.world))
+        self.pmax = max_pixels_per_rank(self.W, self.H, tile, self.world)
+        self.slabs = [torch.zeros((self.pmax, channels), dtype=dtype, device=device) for _ in range(2)]
+        self.is_dst = self.rank == dst
+        self.recv = [None, None]
+        self.pix_of = None
+        self.frame = None
+        if self.is_dst:
+            if self.world > 1:
+                self.recv = [[torch.empty((self.pmax, channels), dtype=dtype, device=device) for _ in range(self.world)]
+                             for _ in range(2)]
+            self.pix_of = [torch.from_numpy(rank_pixels(self.W, self.H, tile, r, self.world)).to(device)
+                           for r in range(self.world)]
+            self.frame = torch.zeros((self.H * self.W, channels), dtype=dtype, device=device)
+        self.pending = [None, None]
+        self.frames_done = 0
+
+    def finish(self, b):
+        """Wait for slab b's gather (if any) and, on dst, scatter it into the frame image."""
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+            if self.is_dst:
+                for r in range(self.world):
+                    self.frame[self.pix_of[r]] = self.recv[b][r][: len(self.pix_of[r])]
+                self.frames_done += 1
+
+    def submit(self, i, local):
+        """Frame i's per-pixel result of this rank ([P, C], rank_pixels() order)."""
+        b = i & 1
+        self.finish(b)
+        self.last = b
+        self.slabs[b][: self.P].copy_(local)
+        if self.world > 1:
+            self.pending[b] = self.dist.gather(self.slabs[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.frame[self.pix_of[0]] = self.slabs[b][: self.P]
+            self.frames_done += 1
+
+    def drain(self):
+        """Finish what is in flight, oldest frame first."""
+        last = getattr(self, "last", 1)
+        for b in (last ^ 1, last):
+            self.finish(b)
+
+    def image(self):
+        """[H, W, C] on dst (call drain() first), None elsewhere."""
+        return self.frame.reshape(self.H, self.W, -1) if self.is_dst else None

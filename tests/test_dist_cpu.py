@@ -62,6 +62,65 @@ dist.destroy_process_group()
 """
 
 
+_WORKER2 = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["BHG_ROOT"])
+from blackhole_geodesic_calculator_amd import dist as bd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H, T = 96, 64, 32
+g = bd.FrameGatherer(W, H, T, channels=4, dtype=torch.float32, device="cpu")
+px = bd.rank_pixels(W, H, T, rank, world)
+assert g.P == len(px)
+for frame in range(5):   # five frames through the two rotating slabs
+    local = torch.tensor(np.stack([px + 1000 * frame, np.full_like(px, rank), px // W, px % W], 1), dtype=torch.float32)
+    g.submit(frame, local)
+g.drain()
+dist.barrier()
+if rank == 0:
+    img = g.image().numpy()
+    ids = np.arange(W * H).reshape(H, W)
+    assert g.frames_done == 5
+    assert np.array_equal(img[..., 0], ids + 4000)      # the last frame is what the image holds
+    assert np.array_equal(img[..., 2], ids // W) and np.array_equal(img[..., 3], ids % W)
+    print("GATHERER_OK")
+else:
+    assert g.image() is None
+dist.destroy_process_group()
+"""
+
+
+def _run_world2(tmp_path, body, token):
+    script = tmp_path / "worker.py"
+    script.write_text(body)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BHG_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BHGEO_NO_TORCH_PRELOAD="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert token in out.stdout
+
+
+def test_frame_gatherer_async_double_buffer_world2_gloo(tmp_path):
+    """bench.py's frame-end path: asynchronous gather, two slabs in rotation, scatter on rank 0."""
+    _run_world2(tmp_path, _WORKER2, "GATHERER_OK")
+
+
+def test_frame_gatherer_single_process():
+    import torch
+    from blackhole_geodesic_calculator_amd import dist as bd
+    g = bd.FrameGatherer(64, 32, 16, channels=2, dtype=torch.float64)
+    px = bd.rank_pixels(64, 32, 16, 0, 1)
+    g.submit(0, torch.tensor(np.stack([px, 2 * px], 1), dtype=torch.float64))
+    g.drain()
+    img = g.image().numpy()
+    assert np.array_equal(img[..., 0].reshape(-1), np.arange(64 * 32)) and g.frames_done == 1
+
+
 def test_gather_frame_world2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
