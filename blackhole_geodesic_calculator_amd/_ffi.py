@@ -33,6 +33,7 @@ METHOD_DP54 = 0
 METHOD_RK4 = 1
 RHS_CHRISTOFFEL = 0
 RHS_REDUCED = 1
+RHS_KERR_BL = 2
 
 # every symbol include/bhgeo.h declares (tests check the built library exports all of them)
 EXPORTS = (
@@ -65,6 +66,7 @@ class Params(C.Structure):
         ("reserved", C.c_uint32),
         ("disk_r_in", C.c_double),
         ("disk_r_out", C.c_double),
+        ("spin", C.c_double),
     ]
 
 
@@ -150,10 +152,10 @@ def default_params() -> Params:
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
                 r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
-                disk_r_out=0.0) -> Params:
+                disk_r_out=0.0, spin=0.0) -> Params:
     return Params(float(r_s), float(lambda_end), float(max_step), float(rtol), float(atol),
                   float(h_fixed), float(r_exit), int(method), int(rhs_form), int(max_steps), 0,
-                  float(disk_r_in), float(disk_r_out))
+                  float(disk_r_in), float(disk_r_out), float(spin))
 
 
 def device_count() -> int:

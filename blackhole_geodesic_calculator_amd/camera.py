@@ -17,7 +17,7 @@ import pickle
 
 import numpy as np
 
-from .integrator import GeodesicIntegratorSchwarzschild
+from .integrator import GeodesicIntegratorKerr, GeodesicIntegratorSchwarzschild
 from .raygen import euler_xyz_matrix
 
 
@@ -25,9 +25,8 @@ class RelativisticCamera:
     def __init__(self, resolution=(64, 64), field_of_view=(0.6, 0.6), a=0.0, M=0.5,
                  camera_location=(1e-4, 0.0, 30.0), camera_rotation_euler=(0.0, 0.0, 0.0),
                  max_step=np.inf, curve_end=50.0, verbose=False, integrator=None, device=0, **integrator_kw):
-        if a != 0.0:
-            # Kerr is a listed goal of the reference (README.md:218), not on this path yet
-            raise NotImplementedError("only a = 0 (Schwarzschild) is implemented on the GPU path")
+        if not abs(a) < 1.0:
+            raise ValueError("|a| (dimensionless spin a/M, CamEdition.py:210) must be < 1")
         self.resolution = [int(resolution[0]), int(resolution[1])]  # [H, W]
         self.field_of_view = [float(field_of_view[0]), float(field_of_view[1])]  # [x, y]
         self.a, self.M = float(a), float(M)
@@ -58,8 +57,13 @@ class RelativisticCamera:
         return d / np.sqrt((d * d).sum(-1))[..., None]
 
     def run(self, verbose=False, verbose_lvl=0):
-        gi = self._integrator or GeodesicIntegratorSchwarzschild(
-            mass=self.M, time_like=False, verbose=False, device=self._device, **self._integrator_kw)
+        if self._integrator is not None:
+            gi = self._integrator
+        elif self.a != 0.0:
+            gi = GeodesicIntegratorKerr(mass=self.M, a=self.a, device=self._device, **self._integrator_kw)
+        else:
+            gi = GeodesicIntegratorSchwarzschild(mass=self.M, time_like=False, verbose=False, device=self._device,
+                                                 **self._integrator_kw)
         out = gi.trace(self.pixel_directions(), self.camera_location, max_step=self.max_step,
                        curve_end=self.curve_end)
         self.ray_end = out["ray_end"]

@@ -24,8 +24,10 @@ static_assert(BHG_FLAG_MAX_STEPS == bhg::BHG_FLAG_MAX_STEPS_, "flag mismatch");
 static_assert(BHG_FLAG_STEP_TOO_SMALL == bhg::BHG_FLAG_STEP_TOO_SMALL_, "flag mismatch");
 static_assert(BHG_FLAG_NAN == bhg::BHG_FLAG_NAN_, "flag mismatch");
 static_assert(BHG_METHOD_DP54 == bhg::BHG_METHOD_DP54_ && BHG_METHOD_RK4 == bhg::BHG_METHOD_RK4_, "method mismatch");
-static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_, "rhs mismatch");
-static_assert(sizeof(bhg_params) == 88, "bhg_params layout is part of the ABI");
+static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_ &&
+                  BHG_RHS_KERR_BL == bhg::BHG_RHS_KERR_BL_,
+              "rhs mismatch");
+static_assert(sizeof(bhg_params) == 96, "bhg_params layout is part of the ABI");
 static_assert(BHG_FLAG_HIT_DISK == bhg::BHG_FLAG_HIT_DISK_, "flag mismatch");
 
 namespace {
@@ -106,8 +108,13 @@ int validate(const bhg_params *p)
     } else {
         return fail(BHG_E_INVALID, "unknown method");
     }
-    if (p->rhs_form != BHG_RHS_CHRISTOFFEL && p->rhs_form != BHG_RHS_REDUCED)
+    if (p->rhs_form != BHG_RHS_CHRISTOFFEL && p->rhs_form != BHG_RHS_REDUCED && p->rhs_form != BHG_RHS_KERR_BL)
         return fail(BHG_E_INVALID, "unknown rhs_form");
+    if (p->rhs_form == BHG_RHS_KERR_BL) {
+        if (!std::isfinite(p->spin) || !(std::fabs(p->spin) < 0.5 * p->r_s))
+            return fail(BHG_E_INVALID, "Kerr needs |spin| < M = r_s/2");
+        if (p->disk_r_out > 0.0) return fail(BHG_E_INVALID, "the disk event is not available with BHG_RHS_KERR_BL");
+    }
     if (!(p->disk_r_in >= 0.0) || !(p->disk_r_out >= 0.0) || !std::isfinite(p->disk_r_in) || !std::isfinite(p->disk_r_out))
         return fail(BHG_E_INVALID, "disk radii must be finite and >= 0");
     if (p->disk_r_out > 0.0 && p->disk_r_in > p->disk_r_out) return fail(BHG_E_INVALID, "disk_r_in > disk_r_out");
@@ -149,6 +156,7 @@ void bhg_default_params(bhg_params *p)
     p->reserved = 0;
     p->disk_r_in = 0.0;
     p->disk_r_out = 0.0;  // no disk
+    p->spin = 0.0;
 }
 
 int bhg_create(int device, bhg_context **out)
@@ -267,7 +275,7 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     //   with a disk: n_steps / n_accepted [n] u32 when not wanted, two resume worklists [n] u32, two counts
     const bool has_exit = p->r_exit > 0.0;
     const bool has_disk = p->disk_r_out > 0.0;
-    const size_t sz_ws = n * 6 * sizeof(double);
+    const size_t sz_ws = n * 8 * sizeof(double);
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
     const size_t sz_steps = (has_disk && !d_n_steps) ? sz_u32 : 0;
@@ -313,6 +321,14 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     a.r_exit = p->r_exit;
     a.disk_r_in = p->disk_r_in;
     a.disk_r_out = p->disk_r_out;
+    a.spin = p->spin;
+    a.r_hor = p->r_s;
+    a.from_records = 0;
+    if (p->rhs_form == BHG_RHS_KERR_BL) {
+        const double M = 0.5 * p->r_s;
+        a.r_hor = (M + std::sqrt(M * M - p->spin * p->spin)) * (1.0 + BHG_KERR_HORIZON_MARGIN);
+        a.from_records = 1;
+    }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
     const int evt = (has_exit ? 1 : 0) | (has_disk ? 2 : 0);

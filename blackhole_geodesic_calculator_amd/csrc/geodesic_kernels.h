@@ -19,6 +19,7 @@ constexpr int BHG_METHOD_DP54_ = 0;
 constexpr int BHG_METHOD_RK4_ = 1;
 constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
 constexpr int BHG_RHS_REDUCED_ = 1;
+constexpr int BHG_RHS_KERR_BL_ = 2;
 
 // Kernel arguments (passed by value -> SGPRs).  All pointers are device addresses.
 struct TraceArgs {
@@ -29,7 +30,7 @@ struct TraceArgs {
     uint32_t *n_steps;           // [n] or nullptr
     uint32_t *n_accepted;        // [n] or nullptr
     unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
-    double *ws;                  // [n][6] per-ray records: prepare {a0, h0, r0, -}, park {a1, t, h, h_next}, resume {a, h, r, t}
+    double *ws;                  // [n][8] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
     uint64_t n;                  // rays in the call
     uint64_t n_items;            // work items of this pass: n, or the length of worklist
     const uint32_t *worklist;    // nullptr (item j = ray j) or ray indices to resume
@@ -37,6 +38,9 @@ struct TraceArgs {
     unsigned long long *work_count_out;
     double x0s[3];
     double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, disk_r_in, disk_r_out;
+    double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
+    double r_hor;                // horizon event radius: r_s, or r_plus (1 + margin) for Kerr
+    int32_t from_records;        // pass 0 starts rays from records the prepare pass wrote (Kerr)
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
     unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps

@@ -174,10 +174,39 @@ __device__ __forceinline__ double pow_m0p1(double x)
 // RHS: spatial acceleration a^i = -Gamma^i_{mu nu} k^mu k^nu, k^t from the null condition
 // (README.md:198-209; time_like=False at RelativisticRenderEngine.py:134).  Also returns r.
 // ------------------------------------------------------------------------------------------
+// Metric parameters (wave-uniform) plus, for Kerr, the ray's Killing constants.
+struct Metric {
+    double r_s;   // Schwarzschild radius 2M
+    double M, a;  // Kerr mass and spin (Boyer-Lindquist), RHS == BHG_RHS_KERR_BL_ only
+    double E, L;  // per ray: E = -k_t, L = k_phi
+};
+
+// Kerr in Boyer-Lindquist coordinates: x = (r, theta, phi), k = d/dlambda of those.  The body is
+// generated by tools/gen_kerr_rhs.py from the sympy-derived Christoffel symbols (the reference's
+// method, README.md:133-135, :182-184, applied to the Kerr metric of its goals list, README.md:218).
+__device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[3], const Metric &m, double acc[3],
+                                              double &r_out)
+{
+    const double r = x[0], th = x[1], ur = k[0], uth = k[1], uph = k[2];
+    const double E = m.E, L = m.L, M = m.M, a = m.a;
+    double ar, ath, aph, ktv;
+#include "kerr_rhs.inc"
+    (void)ktv;
+    acc[0] = ar;
+    acc[1] = ath;
+    acc[2] = aph;
+    r_out = r;
+}
+
 template <int RHS>
-__device__ __forceinline__ void accel(const double x[3], const double k[3], double r_s,
+__device__ __forceinline__ void accel(const double x[3], const double k[3], const Metric &m,
                                       double a[3], double &r)
 {
+    if (RHS == BHG_RHS_KERR_BL_) {
+        accel_kerr_bl(x, k, m, a, r);
+        return;
+    }
+    const double r_s = m.r_s;
     double r2 = __builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]));
     double kk = __builtin_fma(k[2], k[2], __builtin_fma(k[1], k[1], k[0] * k[0]));
     double xk = __builtin_fma(x[2], k[2], __builtin_fma(x[1], k[1], x[0] * k[0]));
@@ -273,10 +302,12 @@ __device__ __forceinline__ double dense_z(const Dense &d, double t)
     return x[2];
 }
 
-__device__ __forceinline__ double dense_g(const Dense &d, double t, double R)
+// g(t) = r(t) - R; `bl`: the state is Boyer-Lindquist (r is the first coordinate)
+__device__ __forceinline__ double dense_g(const Dense &d, double t, double R, bool bl = false)
 {
     double x[3];
     dense_pos(d, t, x);
+    if (bl) return x[0] - R;
     return sqrt(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]))) - R;
 }
 
@@ -369,6 +400,7 @@ struct WaveLds {
     double qh[64];     // |h| to try first (initial step, common.py:68-134; or the controller's next step)
     double qr[64];     // r at the start point
     double qt[64];     // lambda at the start point (0 unless the ray is resumed)
+    double qE[64], qL[64];  // Kerr: the ray's Killing constants
     uint32_t qidx[64];
     uint32_t qnatt[64], qnacc[64];
 };
@@ -380,11 +412,13 @@ struct WaveLds {
 //                       carries on from the end of that step in the next trace pass
 // No final flag value has both of the top bits and any of the low three bits set.
 constexpr uint32_t EV_PENDING = 0xC0u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_RESUME = 0xC8u;
-constexpr int EVT_EXIT = 1, EVT_DISK = 2;  // template bitmask: which optional events are compiled in
+constexpr int EVT_EXIT = 1, EVT_DISK = 2;
+constexpr int WS_STRIDE = 8;  // doubles per ray record: {a(3), w3, w4, w5, E, L}  // template bitmask: which optional events are compiled in
 
 struct Lane {
     double x[3], v[3], a1[3];
     double t, h_abs, r_cur;
+    double E, Lz;  // Kerr only
     uint32_t idx, n_att, n_acc;
     bool active, rejected;
 };
@@ -459,11 +493,12 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
 {
     const uint64_t j = base + lane;
     double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0, pt = 0.0;
+    double pE = 0.0, pL = 0.0;
     uint32_t natt = 0, nacc = 0;
     uint64_t i = j;
     if (j < A.n_items) {
-        if (A.worklist) {
-            i = A.worklist[j];
+        if (A.worklist || A.from_records) {
+            if (A.worklist) i = A.worklist[j];
             const double *e = A.end + i * 6;
             px[0] = e[0];
             px[1] = e[1];
@@ -471,17 +506,21 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
             pk[0] = e[3];
             pk[1] = e[4];
             pk[2] = e[5];
-            const double *w = A.ws + i * 6;
+            const double *w = A.ws + i * WS_STRIDE;
             pa[0] = w[0];
             pa[1] = w[1];
             pa[2] = w[2];
             ph = w[3];
             pr = w[4];
             pt = w[5];
-            natt = A.n_steps[i];
-            nacc = A.n_accepted[i];
+            pE = w[6];
+            pL = w[7];
+            if (A.worklist) {
+                natt = A.n_steps[i];
+                nacc = A.n_accepted[i];
+            }
         } else {
-            const double *w = A.ws + i * 6;
+            const double *w = A.ws + i * WS_STRIDE;
             pa[0] = w[0];
             pa[1] = w[1];
             pa[2] = w[2];
@@ -518,6 +557,8 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
         Q.qh[s] = ph;
         Q.qr[s] = pr;
         Q.qt[s] = pt;
+        Q.qE[s] = pE;
+        Q.qL[s] = pL;
         Q.qidx[s] = (uint32_t)i;
         Q.qnatt[s] = natt;
         Q.qnacc[s] = nacc;
@@ -562,6 +603,8 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
                 L.r_cur = Q.qr[s];
                 L.idx = Q.qidx[s];
                 L.t = Q.qt[s];
+                L.E = Q.qE[s];
+                L.Lz = Q.qL[s];
                 L.n_att = Q.qnatt[s];
                 L.n_acc = Q.qnacc[s];
                 L.rejected = false;
@@ -590,7 +633,7 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
 // ------------------------------------------------------------------------------------------
 template <int RHS>
 __device__ __forceinline__ void dp54_stages(const double x[3], const double v[3], const double a1[3], double h,
-                                            double r_s, double a2[3], double a3[3], double a4[3], double a5[3],
+                                            const Metric &r_s, double a2[3], double a3[3], double a4[3], double a5[3],
                                             double a6[3], double a7[3], double xn[3], double vn[3], double &r_new)
 {
     const double h2 = h * h;
@@ -668,7 +711,7 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
 {
     const double INF = __builtin_inf();
     double rh = INF, re = INF, rz = INF;
-    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return g_r(tt, A.r_s); }, t, t_new);
+    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return g_r(tt, A.r_hor); }, t, t_new);
     if (kind & EV_EXIT) re = brent_root([&](double tt) { return g_r(tt, A.r_exit); }, t, t_new);
     if (kind & EV_DISK) rz = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
     for (int it = 0; it < 2; it++) {
@@ -713,7 +756,7 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
     reinterpret_cast<double2 *>(e)[0] = make_double2(xn[0], xn[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(xn[2], vn[0]);
     reinterpret_cast<double2 *>(e)[2] = make_double2(vn[1], vn[2]);
-    double *w = A.ws + (size_t)idx * 6;
+    double *w = A.ws + (size_t)idx * WS_STRIDE;
     w[0] = an[0];
     w[1] = an[1];
     w[2] = an[2];
@@ -730,10 +773,10 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
 template <int RHS>
 __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                    const double a1[3], double t, double h, double h_next,
-                                                   uint32_t kind, uint32_t idx)
+                                                   uint32_t kind, uint32_t idx, const Metric &m)
 {
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
-    dp54_stages<RHS>(x, v, a1, h, A.r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+    dp54_stages<RHS>(x, v, a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
     Dense d;
     d.t0 = t;
     d.h = h;
@@ -753,7 +796,7 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
     }
     const double t_new = t + h;
     const bool ended = settle_events(
-        A, kind, idx, t, t_new, [&](double tt, double R) { return dense_g(d, tt, R); },
+        A, kind, idx, t, t_new, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) { return dense_z(d, tt); },
         [&](double tt, double xe[3], double ve[3]) {
             dense_pos(d, tt, xe);
@@ -767,7 +810,7 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
 // ------------------------------------------------------------------------------------------
 template <int RHS>
 __device__ __forceinline__ void rk4_step(const double x[3], const double v[3], const double a1[3], double h,
-                                         double r_s, double xn[3], double vn[3], double an[3], double &r_new)
+                                         const Metric &r_s, double xn[3], double vn[3], double an[3], double &r_new)
 {
     const double hh = 0.5 * h;
     double a2[3], a3[3], a4[3], xs[3], v2[3], v3[3], v4[3], rr;
@@ -815,21 +858,22 @@ __device__ __forceinline__ void hermite_eval(const Hermite &d, double t, double 
     }
 }
 
-__device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R)
+__device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R, bool bl = false)
 {
     double x[3], v[3];
     hermite_eval(d, t, x, v);
+    if (bl) return x[0] - R;
     return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) - R;
 }
 
 template <int RHS>
 __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                   const double a1[3], double t, double h, double h_next,
-                                                  uint32_t kind, uint32_t idx)
+                                                  uint32_t kind, uint32_t idx, const Metric &m)
 {
     Hermite d;
     double r_new;
-    rk4_step<RHS>(x, v, a1, h, A.r_s, d.x1, d.v1, d.a1, r_new);
+    rk4_step<RHS>(x, v, a1, h, m, d.x1, d.v1, d.a1, r_new);
     d.t0 = t;
     d.h = h;
 #pragma unroll
@@ -840,7 +884,7 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
     }
     const double t_new = t + h;
     const bool ended = settle_events(
-        A, kind, idx, t, t_new, [&](double tt, double R) { return hermite_g(d, tt, R); },
+        A, kind, idx, t, t_new, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
             double xx[3], vv[3];
             hermite_eval(d, tt, xx, vv);
@@ -862,7 +906,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
     reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
     reinterpret_cast<double2 *>(e)[2] = make_double2(L.v[1], L.v[2]);
-    double *w = A.ws + (size_t)L.idx * 6;
+    double *w = A.ws + (size_t)L.idx * WS_STRIDE;
     w[0] = L.a1[0];
     w[1] = L.a1[1];
     w[2] = L.a1[2];
@@ -885,13 +929,19 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
 {
     __shared__ WaveLds Q;
     const uint32_t lane = threadIdx.x;
-    const double r_s = A.r_s, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+    const double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     const double max_step = A.max_step;
+    Metric met;
+    met.r_s = A.r_s;
+    met.M = 0.5 * A.r_s;
+    met.a = A.spin;
+    met.E = met.L = 0.0;
 
     Lane L;
 #pragma unroll
     for (int c = 0; c < 3; c++) L.x[c] = L.v[c] = L.a1[c] = 0.0;
     L.t = L.h_abs = L.r_cur = 0.0;
+    L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
     L.active = L.rejected = false;
     Wave W;
@@ -946,7 +996,11 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                 const double h2 = h * h;
 
                 double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
-                dp54_stages<RHS>(L.x, L.v, L.a1, h, r_s, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+                if (RHS == BHG_RHS_KERR_BL_) {
+                    met.E = L.E;
+                    met.L = L.Lz;
+                }
+                dp54_stages<RHS>(L.x, L.v, L.a1, h, met, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
                 L.n_att++;
 
                 // error estimate (rk.py:105-109, :143-146), RMS over the 6 components
@@ -995,7 +1049,7 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                     const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    const bool ev_d = (EVT & EVT_DISK) && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                    const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                            ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
                     if (ev_h || ev_e || ev_d) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
@@ -1041,12 +1095,18 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 {
     __shared__ WaveLds Q;
     const uint32_t lane = threadIdx.x;
-    const double r_s = A.r_s, t_bound = A.lambda_end, hf = A.h_fixed;
+    const double r_s = A.r_hor, t_bound = A.lambda_end, hf = A.h_fixed;  // r_s: horizon EVENT radius
+    Metric met;
+    met.r_s = A.r_s;
+    met.M = 0.5 * A.r_s;
+    met.a = A.spin;
+    met.E = met.L = 0.0;
 
     Lane L;
 #pragma unroll
     for (int c = 0; c < 3; c++) L.x[c] = L.v[c] = L.a1[c] = 0.0;
     L.t = L.h_abs = L.r_cur = 0.0;
+    L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
     L.active = L.rejected = false;
     Wave W;
@@ -1077,12 +1137,16 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 if (t_new - t_bound > 0.0) t_new = t_bound;
                 const double h = t_new - L.t;
                 double xn[3], vn[3], an[3], r_new;
-                rk4_step<RHS>(L.x, L.v, L.a1, h, r_s, xn, vn, an, r_new);
+                if (RHS == BHG_RHS_KERR_BL_) {
+                    met.E = L.E;
+                    met.L = L.Lz;
+                }
+                rk4_step<RHS>(L.x, L.v, L.a1, h, met, xn, vn, an, r_new);
                 L.n_att++;
                 const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                const bool ev_d = (EVT & EVT_DISK) && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                        ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
                 if (ev_h || ev_e || ev_d) {
                     L.n_acc = L.n_att;
@@ -1131,15 +1195,55 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         px[1] = A.x0s[1];
         px[2] = A.x0s[2];
     }
-    double *w = A.ws + i * 6;
-    const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
-    if (r0 <= r_s) {
+    double *w = A.ws + i * WS_STRIDE;
+    Metric met;
+    met.r_s = A.r_s;
+    met.M = 0.5 * A.r_s;
+    met.a = A.spin;
+    met.E = met.L = 0.0;
+    double cx[3] = {px[0], px[1], px[2]}, ck[3] = {pk[0], pk[1], pk[2]};  // Cartesian input, kept for start-inside
+    if (RHS == BHG_RHS_KERR_BL_) {
+        // Cartesian -> Boyer-Lindquist: x = sqrt(r^2+a^2) sin th cos ph, y = ... sin ph, z = r cos th
+        const double a = met.a, M = met.M;
+        const double rho2 = px[0] * px[0] + px[1] * px[1] + px[2] * px[2];
+        const double b = rho2 - a * a;
+        const double r = sqrt(0.5 * (b + sqrt(b * b + 4.0 * a * a * px[2] * px[2])));
+        const double th = acos(px[2] / r), ph = atan2(px[1], px[0]);
+        const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+        const double J00 = r / R * st * cp, J01 = R * ct * cp, J02 = -R * st * sp;
+        const double J10 = r / R * st * sp, J11 = R * ct * sp, J12 = R * st * cp;
+        const double J20 = ct, J21 = -r * st, J22 = 0.0;
+        const double det = J00 * (J11 * J22 - J12 * J21) - J01 * (J10 * J22 - J12 * J20) + J02 * (J10 * J21 - J11 * J20);
+        const double u0 = (pk[0] * (J11 * J22 - J12 * J21) - J01 * (pk[1] * J22 - J12 * pk[2]) + J02 * (pk[1] * J21 - J11 * pk[2])) / det;
+        const double u1 = (J00 * (pk[1] * J22 - J12 * pk[2]) - pk[0] * (J10 * J22 - J12 * J20) + J02 * (J10 * pk[2] - pk[1] * J20)) / det;
+        const double u2 = (J00 * (J11 * pk[2] - pk[1] * J21) - J01 * (J10 * pk[2] - pk[1] * J20) + pk[0] * (J10 * J21 - J11 * J20)) / det;
+        px[0] = r;
+        px[1] = th;
+        px[2] = ph;
+        pk[0] = u0;
+        pk[1] = u1;
+        pk[2] = u2;
+        // E = -k_t, L = k_phi from the null condition at the camera (future-directed root, g_tt < 0)
+        const double s2 = st * st, c2 = ct * ct;
+        const double Sig = r * r + a * a * c2, Del = r * r - 2.0 * M * r + a * a;
+        const double gtt = -(1.0 - 2.0 * M * r / Sig), gtp = -2.0 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
+        const double gpp = (r * r + a * a + 2.0 * M * a * a * r * s2 / Sig) * s2;
+        const double S = grr * u0 * u0 + gthth * u1 * u1 + gpp * u2 * u2;
+        const double B = gtp * u2;
+        const double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
+        met.E = -(gtt * kt + gtp * u2);
+        met.L = gtp * kt + gpp * u2;
+    }
+    const double r0 = (RHS == BHG_RHS_KERR_BL_)
+                          ? px[0]
+                          : sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+    if (r0 <= A.r_hor) {
         // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
-        store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+        store_result(A, (uint32_t)i, cx, ck, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
         w[3] = -1.0;
         return;
     }
-    accel<RHS>(px, pk, r_s, pa, pr);
+    accel<RHS>(px, pk, met, pa, pr);
     if (ADAPTIVE) {
         const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
         double isc[6];
@@ -1165,7 +1269,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
             x1[c] = __builtin_fma(h0, pk[c], px[c]);
             k1[c] = __builtin_fma(h0, pa[c], pk[c]);
         }
-        accel<RHS>(x1, k1, r_s, f1, r1);
+        accel<RHS>(x1, k1, met, f1, r1);
         double d2 = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -1190,6 +1294,19 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
     w[2] = pa[2];
     w[3] = ph;
     w[4] = pr;
+    if (RHS == BHG_RHS_KERR_BL_) {
+        // the trace pass starts Kerr rays from records: BL state in the ray's end[] slot
+        w[5] = 0.0;
+        w[6] = met.E;
+        w[7] = met.L;
+        double *e = A.end + i * 6;
+        e[0] = px[0];
+        e[1] = px[1];
+        e[2] = px[2];
+        e[3] = pk[0];
+        e[4] = pk[1];
+        e[5] = pk[2];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1205,14 +1322,41 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
     const uint32_t fl = A.flags[i];
     if ((fl & 0xC0u) != EV_PENDING || (fl & 7u) == 0u) return;
     const double *e = A.end + i * 6;
-    const double *w = A.ws + i * 6;
+    const double *w = A.ws + i * WS_STRIDE;
     double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
     const double t = w[3], h = w[4], h_next = w[5];
+    Metric met;
+    met.r_s = A.r_s;
+    met.M = 0.5 * A.r_s;
+    met.a = A.spin;
+    met.E = w[6];
+    met.L = w[7];
     if (ADAPTIVE)
-        dp54_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i);
+        dp54_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i, met);
     else
-        rk4_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i);
+        rk4_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i, met);
 }
+
+// Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into
+// the Cartesian frame the boundary speaks (rays that started inside were stored Cartesian already).
+__global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    if (A.flags[i] & BHG_FLAG_START_INSIDE_) return;
+    double *e = A.end + i * 6;
+    const double r = e[0], th = e[1], ph = e[2], u0 = e[3], u1 = e[4], u2 = e[5], a = A.spin;
+    const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+    e[0] = R * st * cp;
+    e[1] = R * st * sp;
+    e[2] = r * ct;
+    e[3] = (r / R * st * cp) * u0 + (R * ct * cp) * u1 + (-R * st * sp) * u2;
+    e[4] = (r / R * st * sp) * u0 + (R * ct * sp) * u1 + (R * st * cp) * u2;
+    e[5] = ct * u0 + (-r * st) * u1 + 0.0 * u2;
+    const bool bad = !(isfinite(e[0]) && isfinite(e[1]) && isfinite(e[2]) && isfinite(e[3]) && isfinite(e[4]) && isfinite(e[5]));
+    if (bad) A.flags[i] |= (uint8_t)BHG_FLAG_NAN_;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Acceleration probe (tests compare the device RHS with the oracle's)
@@ -1225,7 +1369,11 @@ __global__ void accel_kernel(const double *x, const double *k, double r_s, uint6
     double px[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
     double pk[3] = {k[3 * i], k[3 * i + 1], k[3 * i + 2]};
     double a[3], r;
-    accel<RHS>(px, pk, r_s, a, r);
+    Metric met;
+    met.r_s = r_s;
+    met.M = 0.5 * r_s;
+    met.a = met.E = met.L = 0.0;
+    accel<RHS>(px, pk, met, a, r);
     acc[3 * i] = a[0];
     acc[3 * i + 1] = a[1];
     acc[3 * i + 2] = a[2];
@@ -1256,6 +1404,8 @@ static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipSt
         hipLaunchKernelGGL((resolve_kernel<RHS, false>), dim3(gr), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((resolve_kernel<RHS, true>), dim3(gr), dim3(64), 0, s, a);
+    if (RHS == BHG_RHS_KERR_BL_)
+        hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
     if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }
@@ -1292,12 +1442,18 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
 
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
+    if (rhs == BHG_RHS_KERR_BL_)  // Kerr: horizon + optional exit sphere only (the C-ABI layer rejects a disk)
+        return (evt & 1) ? launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev)
+                         : launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
     return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
 
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {
+    if (rhs == BHG_RHS_KERR_BL_)
+        return (evt & 1) ? occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu)
+                         : occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
     return rhs == BHG_RHS_REDUCED_ ? occupancy_rhs<BHG_RHS_REDUCED_>(method, evt, blocks_per_cu)
                                    : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }

@@ -19,7 +19,7 @@ import numpy as np
 from . import _ffi
 
 _METHODS = {"RK45": _ffi.METHOD_DP54, "DP54": _ffi.METHOD_DP54, "RK4": _ffi.METHOD_RK4}
-_RHS = {"christoffel": _ffi.RHS_CHRISTOFFEL, "reduced": _ffi.RHS_REDUCED}
+_RHS = {"christoffel": _ffi.RHS_CHRISTOFFEL, "reduced": _ffi.RHS_REDUCED, "kerr_bl": _ffi.RHS_KERR_BL}
 
 
 class GeodesicIntegratorSchwarzschild:
@@ -41,6 +41,7 @@ class GeodesicIntegratorSchwarzschild:
         self.rtol, self.atol = float(rtol), float(atol)
         self.method, self.rhs_form = method, rhs_form
         self.h_fixed, self.max_steps = float(h_fixed), int(max_steps)
+        self.spin = 0.0  # Kerr a in length units (GeodesicIntegratorKerr)
         self._ctx = context if context is not None else _ffi.Context(device)
 
     # ------------------------------------------------------------------------------------
@@ -55,7 +56,7 @@ class GeodesicIntegratorSchwarzschild:
                                 atol=self.atol, h_fixed=self.h_fixed, r_exit=r_exit,
                                 method=_METHODS[self.method], rhs_form=_RHS[self.rhs_form],
                                 max_steps=self.max_steps, disk_r_in=disk[0] if disk else 0.0,
-                                disk_r_out=disk[1] if disk else 0.0)
+                                disk_r_out=disk[1] if disk else 0.0, spin=self.spin)
 
     # ------------------------------------------------------------------------------------
     def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None):
@@ -110,3 +111,22 @@ class GeodesicIntegratorSchwarzschild:
         if verbose or self.verbose:
             print("calc_trajectory:", result)
         return k_xyz, x_xyz, result
+
+
+class GeodesicIntegratorKerr(GeodesicIntegratorSchwarzschild):
+    """Null geodesics around a Kerr black hole (BASELINE.json config 5).
+
+    The reference lists Kerr as a goal (README.md:218) and its pre-traced camera takes `a = 0.9`
+    (raytracer/RelativisticRenderEngineCamEdition.py:210, :217); with mass 0.5 that can only be the
+    dimensionless spin a/M, which is what `a` means here.  Same boundary as the Schwarzschild
+    integrator: Cartesian k0 / x0 in, Cartesian end state out; integrated in Boyer-Lindquist
+    coordinates with sympy-derived Christoffel symbols (tools/gen_kerr_rhs.py)."""
+
+    def __init__(self, mass=1.0, a=0.0, time_like=False, verbose=False, **kw):
+        kw.pop("rhs_form", None)
+        super().__init__(mass=mass, time_like=time_like, verbose=verbose, rhs_form="kerr_bl", **kw)
+        if not abs(a) < 1.0:
+            raise ValueError("|a| = |J|/M^2 must be < 1")
+        self.a = float(a)
+        self.spin = self.a * self.mass
+        self.r_plus = self.mass + (self.mass**2 - self.spin**2) ** 0.5

@@ -72,6 +72,12 @@ extern "C" {
 /* right-hand-side formulations (algebraically identical for null rays) */
 #define BHG_RHS_CHRISTOFFEL 0 /* -Gamma^i_{mu nu} k^mu k^nu, k^t from the null condition (README.md:198-209) */
 #define BHG_RHS_REDUCED 1     /* -(3/2) r_s |x cross k|^2 x / r^5 (regular at the horizon) */
+#define BHG_RHS_KERR_BL 2     /* Kerr, Boyer-Lindquist Christoffels (README.md:218 goal; `a = 0.9`,
+                                 RelativisticRenderEngineCamEdition.py:210).  Same boundary: Cartesian x0, k0 in,
+                                 Cartesian end state out (x = sqrt(r^2+a^2) sin th cos ph, z = r cos th); integrated
+                                 in (r, theta, phi) with k^t from the Killing constants; the horizon event sits at
+                                 r_plus (1 + BHG_KERR_HORIZON_MARGIN) because the coordinates are singular at r_plus */
+#define BHG_KERR_HORIZON_MARGIN 1e-3
 
 typedef struct bhg_params {
     double r_s;         /* horizon radius = 2*mass                 (RelativisticRenderEngine.py:95) */
@@ -88,6 +94,7 @@ typedef struct bhg_params {
     double disk_r_in;   /* thin disk in the plane z = 0 (BH-centred frame): the ray ends at its first */
     double disk_r_out;  /* crossing with R_in <= sqrt(x^2+y^2) <= R_out; off when disk_r_out == 0
                            (disk_on / R_in / R_out of LimitedRelativisticRenderEngine.py:283-286) */
+    double spin;        /* Kerr a in length units, |a| < M = r_s/2 (BHG_RHS_KERR_BL only) */
 } bhg_params;
 
 typedef struct bhg_context bhg_context;

@@ -16,6 +16,11 @@
  *     R_in <= R <= R_out                                            (raytracer/LimitedRelativisticRenderEngine.py:413-438)
  *     -- located here on the step's dense output (a scipy event g = z) instead of by linear
  *     interpolation between trajectory samples (:419-421)
+ *   - Kerr (BASELINE.json config 5; a goal of the reference, README.md:218, hinted at by `a = 0.9`,
+ *     raytracer/RelativisticRenderEngineCamEdition.py:210): no reference arithmetic exists; the
+ *     reference's METHOD (metric -> sympy Christoffels -> solve_ivp) is applied to the Kerr metric in
+ *     Boyer-Lindquist coordinates by tools/gen_kerr_rhs.py, whose generated snippet kerr_rhs.inc is
+ *     compiled here
  *   - scipy 1.15.3's RK45 (the integrator README.md:196 names):    scipy/integrate/_ivp/rk.py:14-71 (rk_step),
  *     :111-176 (_step_impl), :377-404 (tableau, dense output P), common.py:63-134 (norm,
  *     select_initial_step), ivp.py:51-76 (brentq event root), :109-126 (find_active_events),
@@ -52,6 +57,8 @@
 #define BHGO_METHOD_RK4 1
 #define BHGO_RHS_CHRISTOFFEL 0
 #define BHGO_RHS_REDUCED 1
+#define BHGO_RHS_KERR_BL 2
+#define BHGO_KERR_HORIZON_MARGIN 1e-3
 
 typedef struct {
     double r_s;        /* horizon radius = 2*mass (RelativisticRenderEngine.py:95) */
@@ -67,7 +74,16 @@ typedef struct {
     uint32_t reserved;
     double disk_r_in;  /* thin disk in the plane z = 0: annulus R_in <= R <= R_out; off when R_out <= 0 */
     double disk_r_out; /* (LimitedRelativisticRenderEngine.py:283-286, :413-438) */
+    double spin;       /* Kerr a (length units, |a| < M = r_s/2); used by BHGO_RHS_KERR_BL only */
 } bhgo_params;
+
+/* per-ray context: Schwarzschild-Cartesian rays need none of it; Kerr rays are integrated in
+   Boyer-Lindquist (r, theta, phi) with k^t from the Killing constants E, L fixed at the camera */
+typedef struct {
+    int kerr;
+    double E, L, M, a;
+    double r_hor; /* horizon event radius: r_s, or r_plus (1 + margin) in Boyer-Lindquist */
+} rayctx;
 
 /* ---------------------------------------------------------------------------------------
  * RHS: the spatial acceleration -Gamma^i_{mu nu} k^mu k^nu with k^t from the null condition
@@ -108,11 +124,33 @@ static void acc_reduced(const double x[3], const double k[3], double r_s, double
 }
 
 /* y = [k_x, x, k_y, y, k_z, z]  (RelativisticRenderEngine.py:301) */
-static void rhs(const bhgo_params *p, const double y[6], double dy[6])
+static void acc_kerr_bl(const rayctx *rc, const double q[3], const double u[3], double acc[3])
+{
+    const double r = q[0], th = q[1], ur = u[0], uth = u[1], uph = u[2];
+    const double E = rc->E, L = rc->L, M = rc->M, a = rc->a;
+    double ar, ath, aph, ktv;
+#include "kerr_rhs.inc"
+    (void)ktv;
+    acc[0] = ar;
+    acc[1] = ath;
+    acc[2] = aph;
+}
+
+static void rhs(const bhgo_params *p, const rayctx *rc, const double y[6], double dy[6])
 {
     double x[3] = {y[1], y[3], y[5]};
     double k[3] = {y[0], y[2], y[4]};
     double a[3];
+    if (rc->kerr) {
+        acc_kerr_bl(rc, x, k, a);
+        dy[0] = a[0];
+        dy[1] = k[0];
+        dy[2] = a[1];
+        dy[3] = k[1];
+        dy[4] = a[2];
+        dy[5] = k[2];
+        return;
+    }
     if (p->rhs_form == BHGO_RHS_REDUCED)
         acc_reduced(x, k, p->r_s, a);
     else
@@ -125,9 +163,15 @@ static void rhs(const bhgo_params *p, const double y[6], double dy[6])
     dy[5] = k[2];
 }
 
-static double radius(const double y[6])
+static double radius_cart(const double y[6])
 {
     return sqrt(y[1] * y[1] + y[3] * y[3] + y[5] * y[5]);
+}
+
+/* the radial coordinate the horizon / exit events watch */
+static double radius(const rayctx *rc, const double y[6])
+{
+    return rc->kerr ? y[1] : radius_cart(y);
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -166,7 +210,7 @@ static double rms6(const double v[6])
 }
 
 /* common.py:68-134 */
-static double select_initial_step(const bhgo_params *p, const double y0[6], const double f0[6],
+static double select_initial_step(const bhgo_params *p, const rayctx *rc, const double y0[6], const double f0[6],
                                   double t0, double t_bound, uint32_t *nfev)
 {
     const int order = 4; /* error_estimator_order, rk.py:96-98 */
@@ -186,7 +230,7 @@ static double select_initial_step(const bhgo_params *p, const double y0[6], cons
     if (interval_length < h0) h0 = interval_length;
     double y1[6], f1[6];
     for (int i = 0; i < 6; i++) y1[i] = y0[i] + h0 * f0[i];
-    rhs(p, y1, f1);
+    rhs(p, rc, y1, f1);
     (*nfev)++;
     for (int i = 0; i < 6; i++) v[i] = (f1[i] - f0[i]) / scale[i];
     double d2 = rms6(v) / h0;
@@ -206,7 +250,7 @@ static double select_initial_step(const bhgo_params *p, const double y0[6], cons
 }
 
 /* rk.py:14-71 */
-static void rk_step(const bhgo_params *p, const double y[6], const double f[6], double h,
+static void rk_step(const bhgo_params *p, const rayctx *rc, const double y[6], const double f[6], double h,
                     double K[7][6], double y_new[6], double f_new[6])
 {
     memcpy(K[0], f, sizeof(double) * 6);
@@ -217,14 +261,14 @@ static void rk_step(const bhgo_params *p, const double y[6], const double f[6], 
             for (int j = 0; j < s; j++) dot += K[j][i] * A_[s][j];
             ys[i] = y[i] + dot * h;
         }
-        rhs(p, ys, K[s]);
+        rhs(p, rc, ys, K[s]);
     }
     for (int i = 0; i < 6; i++) {
         double dot = 0.0;
         for (int j = 0; j < 6; j++) dot += K[j][i] * B_[j];
         y_new[i] = y[i] + h * dot;
     }
-    rhs(p, y_new, f_new);
+    rhs(p, rc, y_new, f_new);
     memcpy(K[6], f_new, sizeof(double) * 6);
 }
 
@@ -284,6 +328,7 @@ typedef struct {
     const hermite_t *hm;
     double R;
     int zmode; /* 0: g = r - R; 1: g = z (disk plane) */
+    const rayctx *rc;
 } evfun_t;
 
 static double ev_eval(const evfun_t *e, double t)
@@ -294,7 +339,7 @@ static double ev_eval(const evfun_t *e, double t)
     else
         hermite_eval(e->hm, t, y);
     if (e->zmode) return y[5];
-    return radius(y) - e->R;
+    return radius(e->rc, y) - e->R;
 }
 
 /* Brent's method as scipy.optimize.brentq runs it (xtol = rtol = 4 eps, ivp.py:74-75) */
@@ -384,7 +429,7 @@ static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, d
     int n = 0;
     evfun_t e = *base;
     if (hor) {
-        e.R = p->r_s;
+        e.R = e.rc->r_hor;
         e.zmode = 0;
         root[n] = brentq(&e, t_old, t);
         flag[n++] = BHGO_FLAG_HIT_HORIZON;
@@ -437,18 +482,18 @@ typedef struct {
  * One ray, adaptive DP5(4): RungeKutta.__init__ (rk.py:84-104) + solve_ivp loop
  * (ivp.py:654-723) + _step_impl (rk.py:111-176)
  * ------------------------------------------------------------------------------------- */
-static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res)
 {
     double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
     double f[6], K[7][6], y_new[6], f_new[6];
     const double t_bound = p->lambda_end;
     double t = 0.0;
     memset(res, 0, sizeof(*res));
-    rhs(p, y, f);
+    rhs(p, rc, y, f);
     res->nfev = 1;
-    double h_abs = select_initial_step(p, y, f, t, t_bound, &res->nfev);
-    double g_h = radius(y) - p->r_s;
-    double g_e = radius(y) - p->r_exit;
+    double h_abs = select_initial_step(p, rc, y, f, t, t_bound, &res->nfev);
+    double g_h = radius(rc, y) - rc->r_hor;
+    double g_e = radius(rc, y) - p->r_exit;
     const uint32_t cap = p->max_steps ? p->max_steps : 0xFFFFFFFFu;
 
     for (;;) {
@@ -477,7 +522,7 @@ static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0
             if (t_new - t_bound > 0) t_new = t_bound;
             h = t_new - t;
             h_abs = fabs(h);
-            rk_step(p, y, f, h, K, y_new, f_new);
+            rk_step(p, rc, y, f, h, K, y_new, f_new);
             res->nfev += 6;
             res->n_attempted++;
             double ev[6];
@@ -521,11 +566,11 @@ static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0
         memcpy(f, f_new, sizeof(f));
         res->n_accepted++;
 
-        double g_h_new = radius(y) - p->r_s;
-        double g_e_new = radius(y) - p->r_exit;
+        double g_h_new = radius(rc, y) - rc->r_hor;
+        double g_e_new = radius(rc, y) - p->r_exit;
         double z_old = y_old[5], z_new = y[5];
         dense_t dn;
-        evfun_t base = {0, &dn, NULL, 0.0, 0};
+        evfun_t base = {0, &dn, NULL, 0.0, 0, rc};
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
                   ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0)) ||
                   ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0))));
@@ -557,17 +602,17 @@ static void trace_dp54(const bhgo_params *p, const double x0[3], const double k0
 /* ---------------------------------------------------------------------------------------
  * One ray, classic fixed-step RK4 (the build's own "R-fine" regime; not a scipy method)
  * ------------------------------------------------------------------------------------- */
-static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res)
 {
     double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
     double f[6];
     const double t_bound = p->lambda_end;
     double t = 0.0;
     memset(res, 0, sizeof(*res));
-    rhs(p, y, f);
+    rhs(p, rc, y, f);
     res->nfev = 1;
-    double g_h = radius(y) - p->r_s;
-    double g_e = radius(y) - p->r_exit;
+    double g_h = radius(rc, y) - rc->r_hor;
+    double g_e = radius(rc, y) - p->r_exit;
     const uint32_t cap = p->max_steps ? p->max_steps : 0xFFFFFFFFu;
     for (;;) {
         if (t >= t_bound) {
@@ -584,13 +629,13 @@ static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[
         h = t_new - t;
         double k2[6], k3[6], k4[6], ys[6], y_new[6], f_new[6];
         for (int i = 0; i < 6; i++) ys[i] = y[i] + (0.5 * h) * f[i];
-        rhs(p, ys, k2);
+        rhs(p, rc, ys, k2);
         for (int i = 0; i < 6; i++) ys[i] = y[i] + (0.5 * h) * k2[i];
-        rhs(p, ys, k3);
+        rhs(p, rc, ys, k3);
         for (int i = 0; i < 6; i++) ys[i] = y[i] + h * k3[i];
-        rhs(p, ys, k4);
+        rhs(p, rc, ys, k4);
         for (int i = 0; i < 6; i++) y_new[i] = y[i] + (h / 6.0) * (f[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
-        rhs(p, y_new, f_new);
+        rhs(p, rc, y_new, f_new);
         res->nfev += 4;
         res->n_attempted++;
         res->n_accepted++;
@@ -605,9 +650,9 @@ static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[
         t = t_new;
         memcpy(y, y_new, sizeof(y));
         memcpy(f, f_new, sizeof(f));
-        double g_h_new = radius(y) - p->r_s;
-        double g_e_new = radius(y) - p->r_exit;
-        evfun_t base = {1, NULL, &hm, 0.0, 0};
+        double g_h_new = radius(rc, y) - rc->r_hor;
+        double g_e_new = radius(rc, y) - p->r_exit;
+        evfun_t base = {1, NULL, &hm, 0.0, 0, rc};
         double t_root, y_root[6];
         uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, hm.y0[5], hm.y1[5], &base, t_old, t, &t_root, y_root);
         if (fl) {
@@ -629,8 +674,94 @@ static void trace_rk4(const bhgo_params *p, const double x0[3], const double k0[
     res->t_end = t;
 }
 
+/* Boyer-Lindquist <-> Cartesian: x = sqrt(r^2+a^2) sin th cos ph, y = ... sin ph, z = r cos th */
+static void bl_jacobian(double r, double th, double ph, double a, double J[3][3])
+{
+    double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+    J[0][0] = r / R * st * cp;
+    J[0][1] = R * ct * cp;
+    J[0][2] = -R * st * sp;
+    J[1][0] = r / R * st * sp;
+    J[1][1] = R * ct * sp;
+    J[1][2] = R * st * cp;
+    J[2][0] = ct;
+    J[2][1] = -r * st;
+    J[2][2] = 0.0;
+}
+
+static void cart_to_bl(const double x[3], const double k[3], double a, double q[3], double u[3])
+{
+    double rho2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    double b = rho2 - a * a;
+    double r = sqrt(0.5 * (b + sqrt(b * b + 4 * a * a * x[2] * x[2])));
+    q[0] = r;
+    q[1] = acos(x[2] / r);
+    q[2] = atan2(x[1], x[0]);
+    double J[3][3];
+    bl_jacobian(q[0], q[1], q[2], a, J);
+    /* u = J^-1 k by Cramer's rule */
+    double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                 J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+    u[0] = (k[0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (k[1] * J[2][2] - J[1][2] * k[2]) +
+            J[0][2] * (k[1] * J[2][1] - J[1][1] * k[2])) / det;
+    u[1] = (J[0][0] * (k[1] * J[2][2] - J[1][2] * k[2]) - k[0] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+            J[0][2] * (J[1][0] * k[2] - k[1] * J[2][0])) / det;
+    u[2] = (J[0][0] * (J[1][1] * k[2] - k[1] * J[2][1]) - J[0][1] * (J[1][0] * k[2] - k[1] * J[2][0]) +
+            k[0] * (J[1][0] * J[2][1] - J[1][1] * J[2][0])) / det;
+}
+
+static void bl_to_cart(const double q[3], const double u[3], double a, double x[3], double k[3])
+{
+    double R = sqrt(q[0] * q[0] + a * a);
+    x[0] = R * sin(q[1]) * cos(q[2]);
+    x[1] = R * sin(q[1]) * sin(q[2]);
+    x[2] = q[0] * cos(q[1]);
+    double J[3][3];
+    bl_jacobian(q[0], q[1], q[2], a, J);
+    for (int i = 0; i < 3; i++) k[i] = J[i][0] * u[0] + J[i][1] * u[1] + J[i][2] * u[2];
+}
+
 static void trace_one(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
 {
+    rayctx rc;
+    memset(&rc, 0, sizeof(rc));
+    rc.r_hor = p->r_s;
+    if (p->rhs_form == BHGO_RHS_KERR_BL) {
+        const double M = 0.5 * p->r_s, a = p->spin;
+        rc.kerr = 1;
+        rc.M = M;
+        rc.a = a;
+        rc.r_hor = (M + sqrt(M * M - a * a)) * (1.0 + BHGO_KERR_HORIZON_MARGIN);
+        double q[3], u[3];
+        cart_to_bl(x0, k0, a, q, u);
+        if (q[0] <= rc.r_hor) {
+            memset(res, 0, sizeof(*res));
+            res->flags = BHGO_FLAG_START_INSIDE | BHGO_FLAG_HIT_HORIZON;
+            memcpy(res->end, x0, sizeof(double) * 3);
+            memcpy(res->end + 3, k0, sizeof(double) * 3);
+            return;
+        }
+        /* E = -k_t, L = k_phi from the null condition at the camera (future-directed root, g_tt < 0) */
+        double r = q[0], th = q[1], s2 = sin(th) * sin(th), c2 = cos(th) * cos(th);
+        double Sig = r * r + a * a * c2, Del = r * r - 2 * M * r + a * a;
+        double gtt = -(1 - 2 * M * r / Sig), gtp = -2 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
+        double gpp = (r * r + a * a + 2 * M * a * a * r * s2 / Sig) * s2;
+        double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+        double B = gtp * u[2];
+        double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
+        rc.E = -(gtt * kt + gtp * u[2]);
+        rc.L = gtp * kt + gpp * u[2];
+        if (p->method == BHGO_METHOD_RK4)
+            trace_rk4(p, &rc, q, u, res);
+        else
+            trace_dp54(p, &rc, q, u, res);
+        /* res->end is {r, th, ph, ur, uth, uph}: back to Cartesian */
+        double xe[3], ke[3];
+        bl_to_cart(res->end, res->end + 3, a, xe, ke);
+        memcpy(res->end, xe, sizeof(xe));
+        memcpy(res->end + 3, ke, sizeof(ke));
+        return;
+    }
     double r0 = sqrt(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]);
     if (r0 <= p->r_s) {
         /* 'start_inside_hole' -> (False, True, [], []) at RelativisticRenderEngine.py:311-313 */
@@ -645,9 +776,9 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
         return;
     }
     if (p->method == BHGO_METHOD_RK4)
-        trace_rk4(p, x0, k0, res);
+        trace_rk4(p, &rc, x0, k0, res);
     else
-        trace_dp54(p, x0, k0, res);
+        trace_dp54(p, &rc, x0, k0, res);
 }
 
 /* ---------------------------------------------------------------------------------------

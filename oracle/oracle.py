@@ -28,6 +28,8 @@ METHOD_DP54 = 0
 METHOD_RK4 = 1
 RHS_CHRISTOFFEL = 0
 RHS_REDUCED = 1
+RHS_KERR_BL = 2
+KERR_HORIZON_MARGIN = 1e-3
 
 
 class Params(C.Structure):
@@ -45,19 +47,20 @@ class Params(C.Structure):
         ("reserved", C.c_uint32),
         ("disk_r_in", C.c_double),
         ("disk_r_out", C.c_double),
+        ("spin", C.c_double),
     ]
 
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
                 r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
-                disk_r_out=0.0):
+                disk_r_out=0.0, spin=0.0):
     return Params(r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, method, rhs_form,
-                  max_steps, 0, disk_r_in, disk_r_out)
+                  max_steps, 0, disk_r_in, disk_r_out, spin)
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "geodesic_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("geodesic_oracle.c", "kerr_rhs.inc")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
 

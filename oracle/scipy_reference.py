@@ -262,3 +262,112 @@ def trace_rays(k0, x0, **kw):
 def trace_ray_converged(k0, x0, r_s=1.0, lambda_end=50.0, form="reduced"):
     return trace_ray(k0, x0, r_s=r_s, lambda_end=lambda_end, rtol=1e-12, atol=1e-14,
                      form=form, method="DOP853")
+
+
+# --------------------------------------------------------------------------------------
+# Kerr, Boyer-Lindquist coordinates (BASELINE.json config 5).  No reference arithmetic exists
+# (README.md:218 lists Kerr as a goal; `a = 0.9` at CamEdition.py:210); the method is the
+# reference's: metric -> sympy Christoffels -> solve_ivp.  The derivation lives in
+# tools/gen_kerr_rhs.py and is shared with the C snippet the oracle and the kernel compile.
+# --------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=2)
+def kerr_rhs_lambdified():
+    import importlib.util
+    import os
+
+    import sympy as sp
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_kerr_rhs.py")
+    spec = importlib.util.spec_from_file_location("gen_kerr_rhs", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    syms, kt_expr, acc = mod.derive()
+    r, th, ur, uth, uph, E, L, M, a, kt = syms
+    acc = [e.subs(kt, kt_expr) for e in acc]
+    return sp.lambdify((r, th, ur, uth, uph, E, L, M, a), acc + [kt_expr], modules="math", cse=True)
+
+
+def kerr_metric(r, th, M, a):
+    s2, c2 = np.sin(th) ** 2, np.cos(th) ** 2
+    Sig = r * r + a * a * c2
+    Del = r * r - 2 * M * r + a * a
+    gtt = -(1 - 2 * M * r / Sig)
+    gtp = -2 * M * a * r * s2 / Sig
+    grr = Sig / Del
+    gthth = Sig
+    gpp = (r * r + a * a + 2 * M * a * a * r * s2 / Sig) * s2
+    return gtt, gtp, grr, gthth, gpp
+
+
+def cart_to_bl(x, k, a):
+    """(x, y, z), k_cart -> (r, th, ph), (ur, uth, uph) with x = sqrt(r^2+a^2) sin th cos ph, z = r cos th."""
+    x = np.asarray(x, float)
+    rho2 = x @ x
+    b = rho2 - a * a
+    r = np.sqrt(0.5 * (b + np.sqrt(b * b + 4 * a * a * x[2] * x[2])))
+    th = np.arccos(x[2] / r)
+    ph = np.arctan2(x[1], x[0])
+    J = bl_jacobian(r, th, ph, a)
+    u = np.linalg.solve(J, np.asarray(k, float))
+    return np.array([r, th, ph]), u
+
+
+def bl_jacobian(r, th, ph, a):
+    R = np.sqrt(r * r + a * a)
+    st, ct, sp_, cp = np.sin(th), np.cos(th), np.sin(ph), np.cos(ph)
+    return np.array([[r / R * st * cp, R * ct * cp, -R * st * sp_],
+                     [r / R * st * sp_, R * ct * sp_, R * st * cp],
+                     [ct, -r * st, 0.0]])
+
+
+def bl_to_cart(q, u, a):
+    r, th, ph = q
+    R = np.sqrt(r * r + a * a)
+    x = np.array([R * np.sin(th) * np.cos(ph), R * np.sin(th) * np.sin(ph), r * np.cos(th)])
+    return x, bl_jacobian(r, th, ph, a) @ np.asarray(u)
+
+
+def kerr_constants(q, u, M, a):
+    """E = -k_t, L = k_phi from the null condition at the start (future-directed root, g_tt < 0)."""
+    gtt, gtp, grr, gthth, gpp = kerr_metric(q[0], q[1], M, a)
+    S = grr * u[0] ** 2 + gthth * u[1] ** 2 + gpp * u[2] ** 2
+    B = gtp * u[2]
+    kt = (-B - np.sqrt(B * B - gtt * S)) / gtt
+    return -(gtt * kt + gtp * u[2]), gtp * kt + gpp * u[2], kt
+
+
+KERR_HORIZON_MARGIN = 1e-3  # terminal event at r = r_plus (1 + margin): BL coordinates are singular at r_plus
+
+
+def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, method="RK45"):
+    """One null geodesic in Kerr; state y = [ur, r, uth, th, uph, ph]; Cartesian in, Cartesian out."""
+    fn = kerr_rhs_lambdified()
+    q0, u0 = cart_to_bl(x0, k0, a)
+    r_plus = M + np.sqrt(M * M - a * a)
+    r_h = r_plus * (1 + KERR_HORIZON_MARGIN)
+    out = {"nfev": 0, "n_accepted": 0, "n_attempted": 0, "t_end": 0.0}
+    if q0[0] <= r_h:
+        out.update(flags=FLAG_START_INSIDE | FLAG_HIT_HORIZON, end=np.concatenate([x0, k0]))
+        return out
+    E, L, _ = kerr_constants(q0, u0, M, a)
+
+    def rhs(_t, y):
+        ar, ath, aph, _kt = fn(y[1], y[3], y[0], y[2], y[4], E, L, M, a)
+        return np.array([ar, y[0], ath, y[2], aph, y[4]])
+
+    def ev(_t, y):
+        return y[1] - r_h
+
+    ev.terminal = True
+    y0 = np.array([u0[0], q0[0], u0[1], q0[1], u0[2], q0[2]])
+    sol = solve_ivp(rhs, (0.0, lambda_end), y0, method=method, events=[ev], max_step=max_step, rtol=rtol, atol=atol)
+    if sol.status == 1:
+        flags, te, ye = FLAG_HIT_HORIZON, sol.t_events[0][-1], sol.y_events[0][-1]
+    elif sol.status == 0:
+        flags, te, ye = FLAG_REACHED_END, sol.t[-1], sol.y[:, -1]
+    else:
+        flags, te, ye = FLAG_STEP_TOO_SMALL, sol.t[-1], sol.y[:, -1]
+    xe, ke = bl_to_cart((ye[1], ye[3], ye[5]), (ye[0], ye[2], ye[4]), a)
+    out.update(flags=flags, end=np.concatenate([xe, ke]), end_bl=np.array([ye[1], ye[3], ye[5], ye[0], ye[2], ye[4]]),
+               t_end=float(te), nfev=int(sol.nfev), n_attempted=(int(sol.nfev) - 2) // 6 if method == "RK45" else -1,
+               n_accepted=len(sol.t) - 1, E=E, L=L, sol=sol)
+    return out

@@ -177,9 +177,32 @@ def main_disk():
          n_accepted=np.array(nacc, np.uint32), t_end=np.array(tend))
 
 
+def main_kerr():
+    # ---- 10. Kerr a/M = 0.9 (CamEdition.py:210), mass 0.5, Boyer-Lindquist Christoffels (config 5) ----
+    M, a = 0.5, 0.45
+    rng = np.random.default_rng(10)
+    sets = []
+    # (i) the reference's near-axis camera (x = 1e-4, CamEdition.py:216-221), (ii) an off-axis camera
+    cam1 = CAM
+    k1 = np.stack([rng.uniform(-0.3, 0.3, 48), rng.uniform(-0.3, 0.3, 48), -np.ones(48)], 1)
+    cam2 = np.array([0.0, -25.0, 12.0])
+    k2 = (-cam2 / np.linalg.norm(cam2))[None, :] + rng.normal(size=(96, 3)) * 0.08
+    for cam, k in ((cam1, k1), (cam2, k2)):
+        k = k / np.linalg.norm(k, axis=1)[:, None]
+        for i in range(len(k)):
+            r = sr.trace_ray_kerr(k[i], cam, M, a, lambda_end=60.0)
+            sets.append((k[i], cam, r["end"], r["flags"], r["n_attempted"], r["n_accepted"], r["t_end"]))
+    save("kerr_a09", k0=np.array([s[0] for s in sets]), x0=np.array([s[1] for s in sets]), r_s=1.0, spin=a,
+         lambda_end=60.0, max_step=np.inf, rtol=1e-3, atol=1e-6, end=np.array([s[2] for s in sets]),
+         flags=np.array([s[3] for s in sets], np.uint8), n_attempted=np.array([s[4] for s in sets], np.uint32),
+         n_accepted=np.array([s[5] for s in sets], np.uint32), t_end=np.array([s[6] for s in sets]))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "disk":
-        main_disk()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all",):
         main()
+    if which in ("all", "disk"):
         main_disk()
+    if which in ("all", "kerr"):
+        main_kerr()

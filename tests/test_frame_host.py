@@ -140,5 +140,6 @@ def test_camera_pixel_directions_and_pickle(tmp_path):
     cam.save(p)
     cam2 = RelativisticCamera().load(p)
     assert np.array_equal(cam2.ray_end, cam.ray_end) and np.array_equal(cam2.ray_blackhole_hit, cam.ray_blackhole_hit)
-    with pytest.raises(NotImplementedError):
-        RelativisticCamera(a=0.9)
+    with pytest.raises(ValueError):
+        RelativisticCamera(a=1.2)
+    assert RelativisticCamera(a=0.9, integrator=StubIntegrator()).a == 0.9

@@ -35,9 +35,12 @@ def _params(**kw):
 
 
 def _sensitivity(oracle, k0, x0, ref_end, **kw):
-    """Per-ray conditioning: how far the ORACLE's end state moves when k0 moves by one ulp."""
-    kp = np.nextafter(np.asarray(k0, float), np.inf)
-    return np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1)
+    """Per-ray conditioning: how far the ORACLE's end state moves when k0 moves by an ulp or two
+    (the largest of three perturbation patterns; one pattern alone can sit in a ray's blind spot)."""
+    k0 = np.asarray(k0, float)
+    eps = np.finfo(float).eps
+    pats = (np.nextafter(k0, np.inf), np.nextafter(k0, -np.inf), k0 * (1.0 + np.array([2.0, -2.0, 2.0]) * eps))
+    return np.max([np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1) for kp in pats], axis=0)
 
 
 def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
@@ -46,7 +49,7 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
     assert np.array_equal(flags, o["flags"])
     if allow_flips:
         bad = (steps != o["n_attempted"]) | (acc != o["n_accepted"])
-        assert bad.mean() <= 0.005 and np.all((flags[bad] & 1) == 1)
+        assert bad.mean() <= (0.005 if allow_flips is True else allow_flips) and np.all((flags[bad] & (1 | 64)) != 0)
         assert np.abs(steps.astype(int) - o["n_attempted"].astype(int)).max(initial=0) <= 3
     else:
         assert np.array_equal(steps, o["n_attempted"])
@@ -54,7 +57,8 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
     d = np.abs(end - o["end"]).max(1) if len(end) else np.zeros(0)
     if len(end):
         fin = np.isfinite(o["end"]).all(1)
-        tol = TOL_END + COND * np.nan_to_num(_sensitivity(oracle, k0, x0, o["end"], **kw), nan=np.inf, posinf=np.inf)
+        cond = COND * (10.0 if kw.get("rhs_form") == 2 else 1.0)  # Kerr: hundreds of libm sin/cos calls differ by an ulp
+        tol = TOL_END + cond * np.nan_to_num(_sensitivity(oracle, k0, x0, o["end"], **kw), nan=np.inf, posinf=np.inf)
         # horizon rays end AT the coordinate singularity: k^i and (Christoffel form) the rounding noise of
         # the 1/(r-r_s) terms grow without bound there; the engine never reads this state (:242-244)
         tol = tol + np.where((o["flags"] & 1) != 0, 1e-6, 0.0)
@@ -213,6 +217,53 @@ def test_rk4_fixed_step(ctx, oracle, rhs_form):
     k = frame_rays(3000, seed=28)
     _compare(ctx, oracle, k, CAM, r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.1, rhs_form=rhs_form)
     _compare(ctx, oracle, k[:200], CAM, r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.37, rhs_form=rhs_form, r_exit=40.0)
+
+
+# ---- Kerr, Boyer-Lindquist (BASELINE.json config 5) ---------------------------------------------------
+def test_kerr_golden_and_oracle(ctx, oracle):
+    g = load_golden("kerr_a09")
+    kw = dict(r_s=1.0, lambda_end=60.0, rhs_form=2, spin=float(g["spin"]))
+    end, flags, steps, d = _compare(ctx, oracle, g["k0"][48:], g["x0"][48:], **kw)   # off-axis camera
+    assert np.array_equal(flags, g["flags"][48:]) and np.array_equal(steps, g["n_attempted"][48:])
+    assert np.abs(end - g["end"][48:]).max() < 1e-5
+    # the reference's near-axis camera (x = 1e-4): flags and step counts still identical
+    o = oracle.trace(g["k0"][:48], g["x0"][:48], **kw)
+    e2, f2, s2, a2 = ctx.trace(g["k0"][:48], g["x0"][:48], _params(**kw))
+    assert np.array_equal(f2, o["flags"]) and np.array_equal(f2, g["flags"][:48])
+    assert (s2 == o["n_attempted"]).mean() > 0.9
+
+
+def test_kerr_seeded_rays_and_rk4(ctx, oracle):
+    cam = np.array([4.0, -24.0, 13.0])
+    rng = np.random.default_rng(41)
+    k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(20000, 3)) * 0.12
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    end, flags, steps, d = _compare(ctx, oracle, k, cam, r_s=1.0, lambda_end=60.0, rhs_form=2, spin=0.45)
+    assert 0.02 < ((flags & 1) != 0).mean() < 0.5 and np.median(d) < 1e-9
+    _compare(ctx, oracle, k[:3000], cam, r_s=1.0, lambda_end=60.0, rhs_form=2, spin=-0.3, r_exit=35.0)
+    # fixed steps h = 0.1 through the 1/Delta singularity of the Boyer-Lindquist Christoffels: horizon rays
+    # are rounding-sensitive there (which step first lands below r_plus(1+margin), or first turns NaN, flips
+    # for ~1/3 of them); escaping rays must still agree step for step
+    _compare(ctx, oracle, k[:2000], cam, r_s=1.0, lambda_end=40.0, rhs_form=2, spin=0.45, method=1, h_fixed=0.1, allow_flips=0.15)
+    # start inside the (margin) horizon, and argument checks
+    e, f, s_, a_ = ctx.trace(k[:4], np.array([0.3, 0.2, 0.6]), _params(r_s=1.0, rhs_form=2, spin=0.45))
+    assert np.all(f == 3)
+    from blackhole_geodesic_calculator_amd import _ffi
+    for bad in (dict(spin=0.5), dict(spin=0.45, disk_r_in=2.0, disk_r_out=5.0)):
+        with pytest.raises(_ffi.BhgError):
+            ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, **bad))
+
+
+def test_kerr_integrator_and_camera_adaptors(ctx, oracle):
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorKerr
+    from blackhole_geodesic_calculator_amd.camera import RelativisticCamera
+    gi = GeodesicIntegratorKerr(mass=0.5, a=0.9, context=ctx)
+    assert abs(gi.spin - 0.45) < 1e-15 and abs(gi.r_plus - (0.5 + (0.25 - 0.45**2) ** 0.5)) < 1e-15
+    cam = RelativisticCamera(resolution=[24, 32], field_of_view=[0.6, 0.6], a=0.9, M=0.5,
+                             camera_location=[0.0, -25.0, 12.0], camera_rotation_euler=(1.1, 0.0, 0.0), integrator=gi)
+    cam.run()
+    o = oracle.trace(cam.pixel_directions().reshape(-1, 3), cam.camera_location, r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45)
+    assert np.array_equal(cam.ray_blackhole_hit.reshape(-1), (o["flags"] & 1).astype(np.uint8))
 
 
 def test_nonfinite_input_is_flagged_not_hung(ctx):

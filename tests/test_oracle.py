@@ -154,3 +154,61 @@ def test_oracle_disk_crossing_matches_scipy_golden(oracle):
     assert disk.sum() > 30
     R = np.hypot(o["end"][disk, 0], o["end"][disk, 1])
     assert np.abs(o["end"][disk, 2]).max() < 1e-12 and R.min() >= 4.5 and R.max() <= 10.5
+
+
+# ---- Kerr (BASELINE.json config 5): sympy-derived Boyer-Lindquist Christoffels --------------------
+def test_oracle_kerr_matches_scipy_golden(oracle):
+    g = load_golden("kerr_a09")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=60.0, rhs_form=oracle.RHS_KERR_BL, spin=float(g["spin"]))
+    assert np.array_equal(o["flags"], g["flags"])
+    assert np.array_equal(o["n_attempted"], g["n_attempted"])
+    assert np.array_equal(o["n_accepted"], g["n_accepted"])
+    d = np.abs(o["end"] - g["end"]).max(1)
+    # the near-axis camera (first 48 rays, x = 1e-4 as in the reference's pickle names) sits on the
+    # coordinate singularity theta = 0: phi amplifies rounding by ~1/sin(theta)
+    assert d[48:].max() < 1e-5 and np.median(d[48:]) < 1e-9 and d[:48].max() < 5e-2
+
+
+def test_kerr_conserves_killing_constants_and_null_norm(oracle):
+    from oracle import scipy_reference as sr
+    M, a = 0.5, 0.45
+    cam = np.array([0.0, -25.0, 12.0])
+    rng = np.random.default_rng(12)
+    k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(40, 3)) * 0.1
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    o = oracle.trace(k, cam, r_s=1.0, lambda_end=60.0, rtol=1e-10, atol=1e-12, rhs_form=oracle.RHS_KERR_BL, spin=a)
+    esc = o["flags"] == oracle.FLAG_REACHED_END
+    assert esc.sum() > 10
+    for i in np.nonzero(esc)[0]:
+        q0, u0 = sr.cart_to_bl(cam, k[i], a)
+        E0, L0, _ = sr.kerr_constants(q0, u0, M, a)
+        q1, u1 = sr.cart_to_bl(o["end"][i, 0:3], o["end"][i, 3:6], a)
+        E1, L1, _ = sr.kerr_constants(q1, u1, M, a)  # null condition re-solved at the end point
+        assert abs(E1 - E0) < 1e-7 and abs(L1 - L0) < 1e-6
+        # Carter constant Q = p_th^2 + cos^2 th (L^2 / sin^2 th - a^2 E^2)
+        def carter(q, u, E, L):
+            Sig = q[0] ** 2 + a * a * np.cos(q[1]) ** 2
+            return (Sig * u[1]) ** 2 + np.cos(q[1]) ** 2 * (L * L / np.sin(q[1]) ** 2 - a * a * E * E)
+        assert abs(carter(q1, u1, E1, L1) - carter(q0, u0, E0, L0)) < 1e-5
+
+
+def test_kerr_zero_spin_is_schwarzschild(oracle):
+    k = frame_rays(60, seed=13)
+    cam = np.array([3.0, -20.0, 14.0])
+    kw = dict(r_s=1.0, lambda_end=50.0, rtol=1e-11, atol=1e-13)
+    a = oracle.trace(k, cam, rhs_form=oracle.RHS_KERR_BL, spin=1e-12, **kw)
+    b = oracle.trace(k, cam, rhs_form=oracle.RHS_REDUCED, **kw)
+    esc = (a["flags"] == 4) & (b["flags"] == 4)
+    assert esc.sum() > 40 and np.array_equal(a["flags"] & 1, b["flags"] & 1)
+    assert np.abs(a["end"] - b["end"])[esc].max() < 1e-6
+
+
+def test_kerr_frame_dragging_breaks_the_mirror_symmetry(oracle):
+    """Equatorial camera: prograde and retrograde rays with mirrored impact parameters differ."""
+    cam = np.array([0.0, -30.0, 0.0])
+    kp = np.array([+2.4 / 30, 1.0, 0.0]); km = np.array([-2.4 / 30, 1.0, 0.0])
+    k = np.stack([kp / np.linalg.norm(kp), km / np.linalg.norm(km)])
+    o = oracle.trace(k, cam, r_s=1.0, lambda_end=80.0, rtol=1e-9, atol=1e-11, rhs_form=oracle.RHS_KERR_BL, spin=0.45)
+    s = oracle.trace(k, cam, r_s=1.0, lambda_end=80.0, rtol=1e-9, atol=1e-11, rhs_form=oracle.RHS_REDUCED)
+    assert np.array_equal(s["flags"], [1, 1])      # b = 2.4 < 2.598: both captured without spin
+    assert sorted(o["flags"].tolist()) == [1, 4]   # with a/M = 0.9 the prograde side escapes
