@@ -26,8 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic flop per attempted ray-step: 6 RHS x 44 + 390 bookkeeping
-FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468,
-                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130}
+# Kerr (config 5): the generated Boyer-Lindquist RHS has 134 operations after CSE (tools/gen_kerr_rhs.py),
+# sin/cos counted as one each -> 6 x 134 + 390 and 4 x 134 + 78
+FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468, ("dp54", "kerr"): 1194,
+                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130, ("rk4", "kerr"): 614}
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
@@ -41,7 +43,8 @@ def parse():
     ap.add_argument("--regime", choices=["adaptive", "fine", "rk4"], default="adaptive",
                     help="adaptive: DP5(4) rtol 1e-3 atol 1e-6 max_step inf (engine + scipy defaults); "
                          "fine: same with max_step 0.1; rk4: fixed step 0.1")
-    ap.add_argument("--rhs", choices=["christoffel", "reduced"], default="christoffel")
+    ap.add_argument("--rhs", choices=["christoffel", "reduced", "kerr"], default="christoffel",
+                    help="kerr = BASELINE.json configs[4]: a/M = 0.9, Boyer-Lindquist Christoffels, same camera")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--samples", type=int, default=5)
@@ -87,7 +90,8 @@ def main():
     params = _ffi.make_params(
         r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
         h_fixed=0.1, method=_ffi.METHOD_RK4 if method == "rk4" else _ffi.METHOD_DP54,
-        rhs_form=_ffi.RHS_REDUCED if a.rhs == "reduced" else _ffi.RHS_CHRISTOFFEL)
+        rhs_form={"reduced": _ffi.RHS_REDUCED, "kerr": _ffi.RHS_KERR_BL}.get(a.rhs, _ffi.RHS_CHRISTOFFEL),
+        spin=0.45 if a.rhs == "kerr" else 0.0)
 
     # ---- synthetic input, resident in HBM before the timed region ----------------------------
     # this rank's tiles of the frame (all samples of a pixel together); jitter stream = the
@@ -170,7 +174,7 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 Schwarzschild frame per GPU",
+            "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU",
             "value": rays_all / (dt / a.steps) / 1e6,
             "unit": "Mrays/s",
             "ray_steps_per_s": steps_all / (dt / a.steps),
@@ -184,7 +188,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[1]: {a.width}x{a.height} x{S} multisample Schwarzschild frame per GPU "
+                "workload": f"BASELINE.json configs[{4 if a.rhs == 'kerr' else 1}]: {a.width}x{a.height} x{S} multisample "
+                            f"{'Kerr a/M=0.9' if a.rhs == 'kerr' else 'Schwarzschild'} frame per GPU "
                             f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50",
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
@@ -222,7 +227,8 @@ def cpu_baseline(k0, cam, a, method):
     from oracle import oracle as oc
     oc.build()
     kw = dict(r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
-              h_fixed=0.1, method=1 if method == "rk4" else 0, rhs_form=1 if a.rhs == "reduced" else 0)
+              h_fixed=0.1, method=1 if method == "rk4" else 0, rhs_form={"reduced": 1, "kerr": 2}.get(a.rhs, 0),
+              spin=0.45 if a.rhs == "kerr" else 0.0)
     cores = oc.num_threads()
     n = len(k0)
     probe = k0[:: max(1, n // 16384)]

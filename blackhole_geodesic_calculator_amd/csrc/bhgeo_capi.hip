@@ -324,10 +324,12 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     a.spin = p->spin;
     a.r_hor = p->r_s;
     a.from_records = 0;
+    a.ws_stride = 6;
     if (p->rhs_form == BHG_RHS_KERR_BL) {
         const double M = 0.5 * p->r_s;
         a.r_hor = (M + std::sqrt(M * M - p->spin * p->spin)) * (1.0 + BHG_KERR_HORIZON_MARGIN);
         a.from_records = 1;
+        a.ws_stride = 8;
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;

@@ -30,7 +30,7 @@ struct TraceArgs {
     uint32_t *n_steps;           // [n] or nullptr
     uint32_t *n_accepted;        // [n] or nullptr
     unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
-    double *ws;                  // [n][8] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
+    double *ws;                  // [n][ws_stride] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
     uint64_t n;                  // rays in the call
     uint64_t n_items;            // work items of this pass: n, or the length of worklist
     const uint32_t *worklist;    // nullptr (item j = ray j) or ray indices to resume
@@ -40,6 +40,7 @@ struct TraceArgs {
     double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, disk_r_in, disk_r_out;
     double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
     double r_hor;                // horizon event radius: r_s, or r_plus (1 + margin) for Kerr
+    int32_t ws_stride;           // doubles per ray record in ws: 6, or 8 for Kerr ({E, L} appended)
     int32_t from_records;        // pass 0 starts rays from records the prepare pass wrote (Kerr)
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]

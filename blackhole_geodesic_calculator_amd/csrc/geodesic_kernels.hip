@@ -413,7 +413,7 @@ struct WaveLds {
 // No final flag value has both of the top bits and any of the low three bits set.
 constexpr uint32_t EV_PENDING = 0xC0u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_RESUME = 0xC8u;
 constexpr int EVT_EXIT = 1, EVT_DISK = 2;
-constexpr int WS_STRIDE = 8;  // doubles per ray record: {a(3), w3, w4, w5, E, L}  // template bitmask: which optional events are compiled in
+// ray records in A.ws are A.ws_stride doubles apart: {a(3), w3, w4, w5} (+ {E, L} for Kerr, stride 8)  // template bitmask: which optional events are compiled in
 
 struct Lane {
     double x[3], v[3], a1[3];
@@ -506,21 +506,23 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
             pk[0] = e[3];
             pk[1] = e[4];
             pk[2] = e[5];
-            const double *w = A.ws + i * WS_STRIDE;
+            const double *w = A.ws + i * (uint64_t)A.ws_stride;
             pa[0] = w[0];
             pa[1] = w[1];
             pa[2] = w[2];
             ph = w[3];
             pr = w[4];
             pt = w[5];
-            pE = w[6];
-            pL = w[7];
+            if (A.ws_stride == 8) {
+                pE = w[6];
+                pL = w[7];
+            }
             if (A.worklist) {
                 natt = A.n_steps[i];
                 nacc = A.n_accepted[i];
             }
         } else {
-            const double *w = A.ws + i * WS_STRIDE;
+            const double *w = A.ws + i * (uint64_t)A.ws_stride;
             pa[0] = w[0];
             pa[1] = w[1];
             pa[2] = w[2];
@@ -756,7 +758,7 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
     reinterpret_cast<double2 *>(e)[0] = make_double2(xn[0], xn[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(xn[2], vn[0]);
     reinterpret_cast<double2 *>(e)[2] = make_double2(vn[1], vn[2]);
-    double *w = A.ws + (size_t)idx * WS_STRIDE;
+    double *w = A.ws + (size_t)idx * (size_t)A.ws_stride;
     w[0] = an[0];
     w[1] = an[1];
     w[2] = an[2];
@@ -906,7 +908,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
     reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
     reinterpret_cast<double2 *>(e)[2] = make_double2(L.v[1], L.v[2]);
-    double *w = A.ws + (size_t)L.idx * WS_STRIDE;
+    double *w = A.ws + (size_t)L.idx * (size_t)A.ws_stride;
     w[0] = L.a1[0];
     w[1] = L.a1[1];
     w[2] = L.a1[2];
@@ -1195,7 +1197,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         px[1] = A.x0s[1];
         px[2] = A.x0s[2];
     }
-    double *w = A.ws + i * WS_STRIDE;
+    double *w = A.ws + i * (uint64_t)A.ws_stride;
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
@@ -1322,15 +1324,18 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
     const uint32_t fl = A.flags[i];
     if ((fl & 0xC0u) != EV_PENDING || (fl & 7u) == 0u) return;
     const double *e = A.end + i * 6;
-    const double *w = A.ws + i * WS_STRIDE;
+    const double *w = A.ws + i * (uint64_t)A.ws_stride;
     double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
     const double t = w[3], h = w[4], h_next = w[5];
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
     met.a = A.spin;
-    met.E = w[6];
-    met.L = w[7];
+    met.E = met.L = 0.0;
+    if (RHS == BHG_RHS_KERR_BL_) {
+        met.E = w[6];
+        met.L = w[7];
+    }
     if (ADAPTIVE)
         dp54_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i, met);
     else
