@@ -204,7 +204,7 @@ def main():
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(a, method),
                 "flop_per_ray_step": F,
                 "ray_steps_per_launch": ray_steps,
                 "kernel_ms": k_ms,
@@ -219,6 +219,24 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(a, method):
+    """HBM bytes per launch of the dominant kernel from the latest committed PMC summary
+    (profiles/rNN*_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be
+    read inside the timed run, so this is the committed measurement, or None if it does not apply."""
+    import glob
+    if not (a.regime == "adaptive" and a.rhs == "christoffel" and method == "dp54" and a.width == 1024
+            and a.height == 1024 and a.samples == 5):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def cpu_baseline(k0, cam, a, method):
