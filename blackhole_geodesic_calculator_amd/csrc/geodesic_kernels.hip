@@ -230,9 +230,13 @@ __device__ __forceinline__ void accel(const double x[3], const double k[3], cons
         double fp = r_s * w;
         double q = rcp_nr(f);          // 1/f
         double h = u * q;              // r_s/(r - r_s)
-        double hp = -(fp * q) * q;     // -r_s/(r - r_s)^2
-        double kt2 = __builtin_fma(h, nk2, kk) * q;
-        double s = __builtin_fma(0.5 * f, __builtin_fma(hp, nk2, fp * kt2), fp * (kk - nk2));
+        // f' (k^t)^2 + h' (n.k)^2 with (k^t)^2 = (|k|^2 + h (n.k)^2)/f and h' = -f' / f^2, both terms
+        // sharing g = f'/f:  g [ (|k|^2 + h (n.k)^2) - (n.k)^2 / f ]  -- same quantities, same 1/f
+        // singularity, two multiplications fewer than forming h' and (k^t)^2 separately
+        double g = fp * q;
+        double T = __builtin_fma(h, nk2, kk);
+        double inner = g * __builtin_fma(-q, nk2, T);
+        double s = __builtin_fma(0.5 * f, inner, fp * (kk - nk2));
         c = -s * rinv;
     }
     a[0] = c * x[0];
@@ -1005,31 +1009,57 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                 dp54_stages<RHS>(L.x, L.v, L.a1, h, met, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
                 L.n_att++;
 
-                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components
-                double errsq = 0.0;
+                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components.  The six scale
+                // reciprocals come from ONE v_rcp_f64 (batch inversion: prefix products, one reciprocal,
+                // back-substitution) -- the transcendental pipe is the scarce one; h and h^2 are factored
+                // out of the sums.
+                double evr[3], exr[3], sc[6];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    double ev = __builtin_fma(
+                    evr[c] = __builtin_fma(
                         TB.e[7], a7[c],
                         __builtin_fma(TB.e[6], a6[c],
                                       __builtin_fma(TB.e[5], a5[c],
                                                     __builtin_fma(TB.e[4], a4[c],
                                                                   __builtin_fma(TB.e[3], a3[c], TB.e[1] * L.a1[c])))));
-                    ev *= h;
-                    double ex = __builtin_fma(
+                    exr[c] = __builtin_fma(
                         TB.et[6], a6[c],
                         __builtin_fma(TB.et[5], a5[c],
                                       __builtin_fma(TB.et[4], a4[c],
                                                     __builtin_fma(TB.et[3], a3[c],
                                                                   __builtin_fma(TB.et[2], a2[c], TB.et[1] * L.a1[c])))));
-                    ex *= h2;
-                    double scv = __builtin_fma(fmax(fabs(L.v[c]), fabs(vn[c])), rtol, atol);
-                    double scx = __builtin_fma(fmax(fabs(L.x[c]), fabs(xn[c])), rtol, atol);
-                    double qv = ev * rcp_nr(scv);
-                    double qx = ex * rcp_nr(scx);
-                    errsq = __builtin_fma(qv, qv, __builtin_fma(qx, qx, errsq));
+                    sc[c] = __builtin_fma(fmax(fabs(L.v[c]), fabs(vn[c])), rtol, atol);
+                    sc[3 + c] = __builtin_fma(fmax(fabs(L.x[c]), fabs(xn[c])), rtol, atol);
                 }
-                errsq *= (1.0 / 6.0);
+                double isc[6];
+                {
+                    const double p1 = sc[0] * sc[1], p2 = p1 * sc[2], p3 = p2 * sc[3], p4 = p3 * sc[4], p5 = p4 * sc[5];
+                    if (p5 > 1e-250) {
+                        double inv = rcp_nr(p5);
+                        isc[5] = inv * p4;
+                        inv *= sc[5];
+                        isc[4] = inv * p3;
+                        inv *= sc[4];
+                        isc[3] = inv * p2;
+                        inv *= sc[3];
+                        isc[2] = inv * p1;
+                        inv *= sc[2];
+                        isc[1] = inv * sc[0];
+                        isc[0] = inv * sc[1];
+                    } else {  // absurdly small tolerances (or NaN): no product, six reciprocals
+#pragma unroll
+                        for (int c = 0; c < 6; c++) isc[c] = rcp_nr(sc[c]);
+                    }
+                }
+                double sv = 0.0, sx = 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double qv = evr[c] * isc[c];
+                    const double qx = exr[c] * isc[3 + c];
+                    sv = __builtin_fma(qv, qv, sv);
+                    sx = __builtin_fma(qx, qx, sx);
+                }
+                double errsq = __builtin_fma(sx, h2, sv) * (h2 * (1.0 / 6.0));
                 // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
                 if (!(r_new == r_new)) errsq = __builtin_nan("");
 
