@@ -21,12 +21,21 @@ def rank_tiles(width: int, height: int, tile: int, rank: int, world: int) -> np.
     return np.arange(rank, tx * ty, world, dtype=np.int64)
 
 
-def rank_pixels(width: int, height: int, tile: int, rank: int, world: int) -> np.ndarray:
-    """Flat pixel indices (y*W + x) owned by `rank`, tile after tile, row-major inside a tile."""
+def rank_pixels(width: int, height: int, tile: int, rank: int, world: int, tile_cost=None) -> np.ndarray:
+    """Flat pixel indices (y*W + x) owned by `rank`, tile after tile, row-major inside a tile.
+
+    tile_cost(cx, cy) -> float, optional: the rank's tiles are visited in order of DECREASING cost
+    (longest-processing-time-first: the expensive rays near the photon sphere start early and the
+    kernel's tail is made of cheap far-field rays).  Which pixels a rank owns does not change."""
     W, H = int(width), int(height)
     tx, _ = tile_grid(W, H, tile)
     out = []
-    for t in rank_tiles(W, H, tile, rank, world):
+    tiles = rank_tiles(W, H, tile, rank, world)
+    if tile_cost is not None:
+        ty_, tx_ = np.divmod(tiles, tx)
+        cost = np.array([tile_cost((x + 0.5) * tile, (y + 0.5) * tile) for x, y in zip(tx_, ty_)])
+        tiles = tiles[np.argsort(-cost, kind="stable")]
+    for t in tiles:
         ty_, tx_ = divmod(int(t), tx)
         ys = np.arange(ty_ * tile, min((ty_ + 1) * tile, H))
         xs = np.arange(tx_ * tile, min((tx_ + 1) * tile, W))
