@@ -352,6 +352,7 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
         static unsigned long long *dbuf = nullptr;
         if (!dbuf) HIP_TRY(hipMalloc((void **)&dbuf, 65536 * 8 * sizeof(unsigned long long)));
         a.diag = dbuf;
+        a.dbg_idx = std::getenv("BHGEO_DBG_IDX") ? (uint32_t)std::atoi(std::getenv("BHGEO_DBG_IDX")) : 0xFFFFFFFFu;
         if (const char *path = std::getenv("BHGEO_DIAG_DUMP")) {
             static unsigned long long host[65536 * 8];
             HIP_TRY(hipDeviceSynchronize());

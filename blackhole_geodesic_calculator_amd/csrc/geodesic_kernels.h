@@ -44,6 +44,7 @@ struct TraceArgs {
     int32_t from_records;        // pass 0 starts rays from records the prepare pass wrote (Kerr)
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
+    uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged
     unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
 };
 

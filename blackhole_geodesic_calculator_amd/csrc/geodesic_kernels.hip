@@ -778,8 +778,8 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
 template <int RHS>
 __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                   const double a1[3], double t, double h, double h_next,
-                                                   uint32_t kind, uint32_t idx, const Metric &m)
+                                                   const double a1[3], double t, double t_new, double h,
+                                                   double h_next, uint32_t kind, uint32_t idx, const Metric &m)
 {
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
     dp54_stages<RHS>(x, v, a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
@@ -800,7 +800,6 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
             d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
         }
     }
-    const double t_new = t + h;
     const bool ended = settle_events(
         A, kind, idx, t, t_new, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) { return dense_z(d, tt); },
@@ -874,8 +873,8 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
 
 template <int RHS>
 __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                  const double a1[3], double t, double h, double h_next,
-                                                  uint32_t kind, uint32_t idx, const Metric &m)
+                                                  const double a1[3], double t, double t_new, double h,
+                                                  double h_next, uint32_t kind, uint32_t idx, const Metric &m)
 {
     Hermite d;
     double r_new;
@@ -888,7 +887,6 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
         d.v0[c] = v[c];
         d.a0[c] = a1[c];
     }
-    const double t_new = t + h;
     const bool ended = settle_events(
         A, kind, idx, t, t_new, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
@@ -905,9 +903,11 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
 // global memory (its own end[] slot and its prepare-record slot, both free by now) and refills at
 // once; the resolve pass recomputes that step converged and locates the root.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, uint32_t kind)
+__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, double t_new, uint32_t kind)
 {
-    // ws[idx] = {a1, t, h, |h| the controller chose for the NEXT step (L.h_abs, already updated)}
+    // ws[idx] = {a1, t_new, h, |h| the controller chose for the NEXT step (L.h_abs, already updated)}.
+    // t_new is stored as the integrate loop computed it (possibly clipped to lambda_end): t + h need
+    // not reproduce it bit for bit, and "did the step reach lambda_end" must not depend on that.
     double *e = A.end + (size_t)L.idx * 6;
     reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
@@ -916,7 +916,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
     w[0] = L.a1[0];
     w[1] = L.a1[1];
     w[2] = L.a1[2];
-    w[3] = L.t;
+    w[3] = t_new;
     w[4] = h;
     w[5] = L.h_abs;
     A.flags[L.idx] = (uint8_t)(EV_PENDING | kind);
@@ -1062,10 +1062,21 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                 double errsq = __builtin_fma(sx, h2, sv) * (h2 * (1.0 / 6.0));
                 // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
                 if (!(r_new == r_new)) errsq = __builtin_nan("");
+#ifdef BHG_DIAG
+                if (A.diag && L.idx == A.dbg_idx && L.n_att <= 64) {
+                    double *dd = reinterpret_cast<double *>(A.diag) + 262144 + (L.n_att - 1) * 4;
+                    dd[0] = L.t;
+                    dd[1] = h;
+                    dd[2] = errsq;
+                    dd[3] = sv;
+                }
+#endif
 
                 // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
+                // The clamps make the result independent of errsq outside [0.09^10, 4.5^10] = [3.5e-11, 3.41e6];
+                // the fast power is evaluated on the wider [1e-11, 1e7] so both clamp points lie inside.
                 double fac;
-                if (errsq < 3.4e6) {
+                if (errsq < 1e7) {
                     fac = 0.9 * pow_m0p1(fmax(errsq, 1e-11));
                 } else {
                     fac = 0.2;  // also the NaN case: python max(0.2, nan) == 0.2
@@ -1085,7 +1096,7 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                                                            ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
                     if (ev_h || ev_e || ev_d) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
-                        park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
+                        park_event(A, L, h, t_new, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
                         L.active = false;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
@@ -1183,7 +1194,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 if (ev_h || ev_e || ev_d) {
                     L.n_acc = L.n_att;
                     L.h_abs = hf;
-                    park_event(A, L, h, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
+                    park_event(A, L, h, t_new, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
                     L.active = false;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1356,7 +1367,8 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
     const double *e = A.end + i * 6;
     const double *w = A.ws + i * (uint64_t)A.ws_stride;
     double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
-    const double t = w[3], h = w[4], h_next = w[5];
+    const double t_new = w[3], h = w[4], h_next = w[5];
+    const double t = t_new - h;  // the step's start, good to an ulp: only brackets the root search
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
@@ -1367,9 +1379,9 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
         met.L = w[7];
     }
     if (ADAPTIVE)
-        dp54_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i, met);
+        dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, fl & 7u, (uint32_t)i, met);
     else
-        rk4_resolve_event<RHS>(A, x, v, a1, t, h, h_next, fl & 7u, (uint32_t)i, met);
+        rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, fl & 7u, (uint32_t)i, met);
 }
 
 // Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into

@@ -36,6 +36,9 @@
  *  raytracer/RelativisticRenderEngineCamEdition.py:225-228).
  */
 #include <math.h>
+#include <stdio.h>
+static int bhgo_debug = 0;
+void bhgo_set_debug(int v) { bhgo_debug = v; }
 #include <float.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -535,6 +538,7 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
                 ev[i] = dot * h / scale;
             }
             double error_norm = rms6(ev);
+            if (bhgo_debug) fprintf(stderr, "oracle att %u t %.17g h %.17g errsq %.17g\n", res->n_attempted, t, h, error_norm * error_norm);
             if (error_norm < 1) {
                 double factor;
                 if (error_norm == 0)

@@ -43,7 +43,7 @@ def _sensitivity(oracle, k0, x0, ref_end, **kw):
     return np.max([np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1) for kp in pats], axis=0)
 
 
-def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
+def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, **kw):
     o = oracle.trace(k0, x0, **kw)
     end, flags, steps, acc = ctx.trace(k0, x0, _params(**kw))
     assert np.array_equal(flags, o["flags"])
@@ -67,7 +67,11 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, **kw):
         if dsk.any():
             steep = np.abs(o["end"][:, 5]) / np.linalg.norm(o["end"][:, 3:6], axis=1)
             tol = tol + np.where(dsk, 1e-11 / np.maximum(steep, 1e-12), 0.0)
-        assert np.all(d[fin] <= tol[fin]), f"worst end-state excess {np.max(d[fin] - tol[fin])}"
+        over = d[fin] > tol[fin]
+        # `outliers`: S_i is an estimate from three perturbations, not a bound; the fuzz test lets a
+        # fraction of rays exceed it, but never by more than a factor 1e3
+        assert over.mean() <= outliers and np.all(d[fin] <= 1e3 * tol[fin]), \
+            f"worst end-state excess {np.max(d[fin] - tol[fin])}, {over.sum()} rays over"
     return end, flags, steps, d
 
 
@@ -264,6 +268,84 @@ def test_kerr_integrator_and_camera_adaptors(ctx, oracle):
     cam.run()
     o = oracle.trace(cam.pixel_directions().reshape(-1, 3), cam.camera_location, r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45)
     assert np.array_equal(cam.ray_blackhole_hit.reshape(-1), (o["flags"] & 1).astype(np.uint8))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("BHG_FUZZ", "16"))))
+def test_randomised_configurations(ctx, oracle, seed):
+    """Fuzz: random metric size, camera, tolerances, step caps and optional events, all on one code
+    path per draw; every draw must agree with the oracle like the fixed cases do."""
+    rng = np.random.default_rng(1000 + seed)
+    r_s = float(rng.choice([0.0, 0.3, 1.0, 2.5]))
+    dist_cam = float(rng.uniform(3.0, 60.0)) * max(r_s, 0.5)
+    cam = rng.normal(size=3)
+    cam = dist_cam * cam / np.linalg.norm(cam)
+    n = int(rng.integers(1, 3000))
+    aim = rng.normal(size=(n, 3)) * max(r_s, 0.5) * float(rng.uniform(1.0, 8.0))
+    k = aim - cam
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    if rng.random() < 0.3:  # per-ray origins
+        x0 = cam + rng.normal(size=(n, 3)) * 0.1 * dist_cam
+    else:
+        x0 = cam
+    kw = dict(r_s=r_s, lambda_end=float(rng.uniform(0.5, 4.0)) * dist_cam, rhs_form=int(rng.integers(0, 2)))
+    mode = int(rng.integers(0, 4))
+    if mode == 0:
+        kw.update(rtol=float(10 ** rng.uniform(-7, -2)), atol=float(10 ** rng.uniform(-10, -4)))
+    elif mode == 1:
+        kw.update(max_step=float(rng.uniform(0.05, 2.0)) * max(r_s, 0.5))
+    elif mode == 2:
+        kw.update(method=1, h_fixed=float(rng.uniform(0.05, 0.5)) * max(r_s, 0.5))
+    if rng.random() < 0.4:
+        kw["r_exit"] = float(rng.uniform(0.5, 1.5)) * dist_cam
+    if rng.random() < 0.4:
+        a = float(rng.uniform(1.5, 6.0)) * max(r_s, 0.5)
+        kw.update(disk_r_in=a, disk_r_out=a * float(rng.uniform(1.1, 3.0)))
+    if rng.random() < 0.2:
+        kw["max_steps"] = int(rng.integers(1, 40))
+    tight = kw.get("rtol", 1e-3) <= 1e-6 and kw["rhs_form"] == 0
+    _compare(ctx, oracle, k, x0, allow_flips=(0.02 if tight else False), outliers=2e-3, **kw)
+
+
+@pytest.mark.parametrize("seed", range(max(4, int(__import__("os").environ.get("BHG_FUZZ", "48")) // 4)))
+def test_randomised_kerr(ctx, oracle, seed):
+    rng = np.random.default_rng(5000 + seed)
+    r_s = float(rng.choice([0.6, 1.0, 2.0]))
+    spin = float(rng.uniform(-0.98, 0.98)) * 0.5 * r_s
+    dist_cam = float(rng.uniform(6.0, 50.0)) * r_s
+    cam = rng.normal(size=3)
+    cam[2] *= 0.7
+    cam = dist_cam * cam / np.linalg.norm(cam)
+    if abs(cam[0]) + abs(cam[1]) < 0.05 * dist_cam:  # keep off the polar axis (coordinate singularity)
+        cam[0] += 0.2 * dist_cam
+    n = int(rng.integers(1, 2500))
+    aim = rng.normal(size=(n, 3)) * r_s * float(rng.uniform(1.0, 6.0))
+    k = aim - cam
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    kw = dict(r_s=r_s, spin=spin, rhs_form=2, lambda_end=float(rng.uniform(1.0, 3.0)) * dist_cam)
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        kw.update(rtol=float(10 ** rng.uniform(-6, -2)), atol=float(10 ** rng.uniform(-9, -4)))
+    elif mode == 1:
+        kw.update(max_step=float(rng.uniform(0.1, 2.0)) * r_s)
+    if rng.random() < 0.4:
+        kw["r_exit"] = float(rng.uniform(0.6, 1.4)) * dist_cam
+    if rng.random() < 0.2:
+        kw["max_steps"] = int(rng.integers(1, 60))
+    # Boyer-Lindquist coordinates are singular on the horizon (1/Delta) and on the polar axis (cot theta):
+    # rays that end on the horizon or pass close to the axis (small L_z) have rounding-sensitive step
+    # sequences in the oracle and on the GPU alike.  Everything else must agree step for step.
+    o = oracle.trace(k, cam, **kw)
+    end, flags, steps, acc = ctx.trace(k, cam, _params(**kw))
+    assert (flags != o["flags"]).mean() <= 0.002
+    same = (steps == o["n_attempted"]) & (acc == o["n_accepted"]) & (flags == o["flags"])
+    from oracle import scipy_reference as sr
+    Lz = np.array([sr.kerr_constants(*sr.cart_to_bl(cam, kk, spin), 0.5 * r_s, spin)[1] for kk in k[~same]])
+    touchy = ((flags[~same] & (1 | 64)) != 0) | (np.abs(Lz) < 0.3 * r_s)
+    assert (~same).mean() <= 0.08 and touchy.mean() >= 0.9 if len(Lz) else True
+    d = np.abs(end - o["end"]).max(1)
+    tol = 1e-9 + 1e4 * _sensitivity(oracle, k, cam, o["end"], **kw) + np.where((o["flags"] & 1) != 0, 1e-5, 0.0)
+    ok = same & np.isfinite(o["end"]).all(1)
+    assert (d[ok] > tol[ok]).mean() <= 0.01 and np.median(d[ok]) < 1e-7
 
 
 def test_nonfinite_input_is_flagged_not_hung(ctx):
