@@ -40,7 +40,7 @@ EXPORTS = (
     "bhg_version", "bhg_device_count", "bhg_last_error", "bhg_default_params", "bhg_create",
     "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
-    "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms",
+    "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory",
 )
 
 
@@ -121,6 +121,9 @@ def load():
     L.bhg_shade_device.restype = C.c_int
     L.bhg_shade_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.bhg_trajectory.restype = C.c_int
+    L.bhg_trajectory.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int, _dp, C.c_size_t, C.c_uint32, _dp,
+                                 _u32p, _dp, _u8p]
     L.bhg_set_profiling.restype = C.c_int
     L.bhg_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.bhg_last_pass_ms.restype = C.c_int
@@ -241,6 +244,21 @@ class Context:
                                 _np_dp(end), flags.ctypes.data_as(_u8p), steps.ctypes.data_as(_u32p),
                                 acc.ctypes.data_as(_u32p) if acc is not None else None))
         return end, flags, steps, acc
+
+    def trajectory(self, k0, x0, params: Params, n_points):
+        """Sampled curves: (traj[N,6,T], n_valid[N], end[N,6], flags[N])."""
+        k0 = np.ascontiguousarray(k0, dtype=np.float64).reshape(-1, 3)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = k0.shape[0]
+        shared = x0.ndim == 1
+        traj = np.empty((n, 6, int(n_points)), np.float64)
+        nv = np.empty(n, np.uint32)
+        end = np.empty((n, 6), np.float64)
+        flags = np.empty(n, np.uint8)
+        _check(load().bhg_trajectory(self._h, C.byref(params), _np_dp(x0), 1 if shared else 0, _np_dp(k0), n,
+                                     int(n_points), _np_dp(traj), nv.ctypes.data_as(_u32p), _np_dp(end),
+                                     flags.ctypes.data_as(_u8p)))
+        return traj, nv, end, flags
 
     # -- device buffers (raw addresses, e.g. torch.Tensor.data_ptr()) -------------------
     def trace_device(self, params: Params, n, d_k0, d_end, x0_shared=None, d_x0=0, d_flags=0,

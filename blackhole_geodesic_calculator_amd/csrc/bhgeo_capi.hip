@@ -485,6 +485,80 @@ int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags
     return BHG_OK;
 }
 
+int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0, size_t n,
+                   uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    if (p->method != BHG_METHOD_DP54) return fail(BHG_E_INVALID, "trajectories are sampled with BHG_METHOD_DP54 only");
+    if (p->disk_r_out > 0.0) return fail(BHG_E_INVALID, "the disk event is not available for sampled trajectories");
+    if (n_points < 2) return fail(BHG_E_INVALID, "n_points must be >= 2");
+    if (n == 0) return BHG_OK;
+    if (!x0 || !k0 || !traj || !n_valid) return fail(BHG_E_INVALID, "x0 / k0 / traj / n_valid is NULL");
+    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = n * 3 * sizeof(double) * (x0_is_shared ? 1 : 2);
+    const size_t sz_traj = n * 6 * (size_t)n_points * sizeof(double);
+    const size_t off_end = sz_traj, off_nv = off_end + n * 6 * sizeof(double), off_steps = off_nv + n * sizeof(uint32_t);
+    const size_t off_acc = off_steps + n * sizeof(uint32_t), off_flags = off_acc + n * sizeof(uint32_t);
+    rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
+    if (rc != BHG_OK) return rc;
+    rc = ensure(&c->d_out, &c->d_out_bytes, off_flags + n + 64);
+    if (rc != BHG_OK) return rc;
+    rc = ensure(&c->d_ws, &c->d_ws_bytes, n * 8 * sizeof(double) + 64);
+    if (rc != BHG_OK) return rc;
+    double *d_k0 = (double *)c->d_in, *d_x0 = x0_is_shared ? nullptr : d_k0 + n * 3;
+    char *o = (char *)c->d_out;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(o, 0xFF, sz_traj, s));  // samples a ray never reaches read back as NaN
+
+    bhg::TraceArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.k0 = d_k0;
+    a.x0 = d_x0;
+    a.end = (double *)(o + off_end);
+    a.ws = (double *)c->d_ws;
+    a.flags = (uint8_t *)(o + off_flags);
+    a.n_steps = (uint32_t *)(o + off_steps);
+    a.n_accepted = (uint32_t *)(o + off_acc);
+    a.counter = c->counter;
+    a.n = n;
+    a.n_items = n;
+    if (!d_x0) {
+        a.x0s[0] = x0[0];
+        a.x0s[1] = x0[1];
+        a.x0s[2] = x0[2];
+    }
+    a.r_s = p->r_s;
+    a.lambda_end = p->lambda_end;
+    a.max_step = p->max_step;
+    a.rtol = p->rtol;
+    a.atol = p->atol;
+    a.h_fixed = p->h_fixed;
+    a.r_exit = p->r_exit;
+    a.spin = p->spin;
+    a.r_hor = p->r_s;
+    a.ws_stride = 6;
+    if (p->rhs_form == BHG_RHS_KERR_BL) {
+        const double M = 0.5 * p->r_s;
+        a.r_hor = (M + std::sqrt(M * M - p->spin * p->spin)) * (1.0 + BHG_KERR_HORIZON_MARGIN);
+        a.from_records = 1;
+        a.ws_stride = 8;
+    }
+    a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
+    a.min_step_cap = 0.0;
+    HIP_TRY(bhg::launch_trajectory(a, p->rhs_form, (double *)o, (uint32_t *)(o + off_nv), n_points, s));
+    HIP_TRY(hipMemcpyAsync(traj, o, sz_traj, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_valid, o + off_nv, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (end) HIP_TRY(hipMemcpyAsync(end, o + off_end, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (flags) HIP_TRY(hipMemcpyAsync(flags, o + off_flags, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BHG_OK;
+}
+
 int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const double *k, size_t n, double *acc)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");

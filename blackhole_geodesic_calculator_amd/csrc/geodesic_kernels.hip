@@ -707,6 +707,70 @@ __device__ __forceinline__ void dp54_stages(const double x[3], const double v[3]
 }
 
 
+// Squared RMS error norm of one DP5(4) step (rk.py:105-109, :143-146) over the 6 components.  The six
+// scale reciprocals come from ONE v_rcp_f64 (batch inversion: prefix products, one reciprocal,
+// back-substitution) -- the transcendental pipe is the scarce one; h and h^2 are factored out of the sums.
+__device__ __forceinline__ double dp54_errsq(const double x[3], const double v[3], const double xn[3],
+                                             const double vn[3], const double a1[3], const double a2[3],
+                                             const double a3[3], const double a4[3], const double a5[3],
+                                             const double a6[3], const double a7[3], double h, double rtol, double atol)
+{
+    const double h2 = h * h;
+    double evr[3], exr[3], sc[6];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        evr[c] = __builtin_fma(
+            TB.e[7], a7[c],
+            __builtin_fma(TB.e[6], a6[c],
+                          __builtin_fma(TB.e[5], a5[c],
+                                        __builtin_fma(TB.e[4], a4[c], __builtin_fma(TB.e[3], a3[c], TB.e[1] * a1[c])))));
+        exr[c] = __builtin_fma(
+            TB.et[6], a6[c],
+            __builtin_fma(TB.et[5], a5[c],
+                          __builtin_fma(TB.et[4], a4[c],
+                                        __builtin_fma(TB.et[3], a3[c], __builtin_fma(TB.et[2], a2[c], TB.et[1] * a1[c])))));
+        sc[c] = __builtin_fma(fmax(fabs(v[c]), fabs(vn[c])), rtol, atol);
+        sc[3 + c] = __builtin_fma(fmax(fabs(x[c]), fabs(xn[c])), rtol, atol);
+    }
+    double isc[6];
+    {
+        const double p1 = sc[0] * sc[1], p2 = p1 * sc[2], p3 = p2 * sc[3], p4 = p3 * sc[4], p5 = p4 * sc[5];
+        if (p5 > 1e-250) {
+            double inv = rcp_nr(p5);
+            isc[5] = inv * p4;
+            inv *= sc[5];
+            isc[4] = inv * p3;
+            inv *= sc[4];
+            isc[3] = inv * p2;
+            inv *= sc[3];
+            isc[2] = inv * p1;
+            inv *= sc[2];
+            isc[1] = inv * sc[0];
+            isc[0] = inv * sc[1];
+        } else {  // absurdly small tolerances (or NaN): no product, six reciprocals
+#pragma unroll
+            for (int c = 0; c < 6; c++) isc[c] = rcp_nr(sc[c]);
+        }
+    }
+    double sv = 0.0, sx = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double qv = evr[c] * isc[c];
+        const double qx = exr[c] * isc[3 + c];
+        sv = __builtin_fma(qv, qv, sv);
+        sx = __builtin_fma(qx, qx, sx);
+    }
+    return __builtin_fma(sx, h2, sv) * (h2 * (1.0 / 6.0));
+}
+
+// 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10) before the [0.2, 10] clamps of rk.py:148-163.  The clamps make
+// the result independent of errsq outside [0.09^10, 4.5^10] = [3.5e-11, 3.41e6]; the fast power is
+// evaluated on the wider [1e-11, 1e7] so both clamp points lie inside.  NaN -> 0.2 (python max(0.2, nan)).
+__device__ __forceinline__ double dp54_factor(double errsq)
+{
+    return (errsq < 1e7) ? 0.9 * pow_m0p1(fmax(errsq, 1e-11)) : 0.2;
+}
+
 // Visit the event roots of one accepted step in time order (handle_events sorts them, ivp.py:111-122;
 // ties keep the order horizon, exit, disk).  Horizon and sphere exit always end the ray; a disk-plane
 // crossing ends it only inside the annulus R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424).
@@ -999,7 +1063,6 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                 if (t_new - t_bound > 0.0) t_new = t_bound;
                 const double h = t_new - L.t;
                 L.h_abs = fabs(h);
-                const double h2 = h * h;
 
                 double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
                 if (RHS == BHG_RHS_KERR_BL_) {
@@ -1009,57 +1072,7 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                 dp54_stages<RHS>(L.x, L.v, L.a1, h, met, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
                 L.n_att++;
 
-                // error estimate (rk.py:105-109, :143-146), RMS over the 6 components.  The six scale
-                // reciprocals come from ONE v_rcp_f64 (batch inversion: prefix products, one reciprocal,
-                // back-substitution) -- the transcendental pipe is the scarce one; h and h^2 are factored
-                // out of the sums.
-                double evr[3], exr[3], sc[6];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    evr[c] = __builtin_fma(
-                        TB.e[7], a7[c],
-                        __builtin_fma(TB.e[6], a6[c],
-                                      __builtin_fma(TB.e[5], a5[c],
-                                                    __builtin_fma(TB.e[4], a4[c],
-                                                                  __builtin_fma(TB.e[3], a3[c], TB.e[1] * L.a1[c])))));
-                    exr[c] = __builtin_fma(
-                        TB.et[6], a6[c],
-                        __builtin_fma(TB.et[5], a5[c],
-                                      __builtin_fma(TB.et[4], a4[c],
-                                                    __builtin_fma(TB.et[3], a3[c],
-                                                                  __builtin_fma(TB.et[2], a2[c], TB.et[1] * L.a1[c])))));
-                    sc[c] = __builtin_fma(fmax(fabs(L.v[c]), fabs(vn[c])), rtol, atol);
-                    sc[3 + c] = __builtin_fma(fmax(fabs(L.x[c]), fabs(xn[c])), rtol, atol);
-                }
-                double isc[6];
-                {
-                    const double p1 = sc[0] * sc[1], p2 = p1 * sc[2], p3 = p2 * sc[3], p4 = p3 * sc[4], p5 = p4 * sc[5];
-                    if (p5 > 1e-250) {
-                        double inv = rcp_nr(p5);
-                        isc[5] = inv * p4;
-                        inv *= sc[5];
-                        isc[4] = inv * p3;
-                        inv *= sc[4];
-                        isc[3] = inv * p2;
-                        inv *= sc[3];
-                        isc[2] = inv * p1;
-                        inv *= sc[2];
-                        isc[1] = inv * sc[0];
-                        isc[0] = inv * sc[1];
-                    } else {  // absurdly small tolerances (or NaN): no product, six reciprocals
-#pragma unroll
-                        for (int c = 0; c < 6; c++) isc[c] = rcp_nr(sc[c]);
-                    }
-                }
-                double sv = 0.0, sx = 0.0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const double qv = evr[c] * isc[c];
-                    const double qx = exr[c] * isc[3 + c];
-                    sv = __builtin_fma(qv, qv, sv);
-                    sx = __builtin_fma(qx, qx, sx);
-                }
-                double errsq = __builtin_fma(sx, h2, sv) * (h2 * (1.0 / 6.0));
+                double errsq = dp54_errsq(L.x, L.v, xn, vn, L.a1, a2, a3, a4, a5, a6, a7, h, rtol, atol);
                 // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
                 if (!(r_new == r_new)) errsq = __builtin_nan("");
 #ifdef BHG_DIAG
@@ -1068,19 +1081,12 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                     dd[0] = L.t;
                     dd[1] = h;
                     dd[2] = errsq;
-                    dd[3] = sv;
+                    dd[3] = 0.0;
                 }
 #endif
 
                 // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
-                // The clamps make the result independent of errsq outside [0.09^10, 4.5^10] = [3.5e-11, 3.41e6];
-                // the fast power is evaluated on the wider [1e-11, 1e7] so both clamp points lie inside.
-                double fac;
-                if (errsq < 1e7) {
-                    fac = 0.9 * pow_m0p1(fmax(errsq, 1e-11));
-                } else {
-                    fac = 0.2;  // also the NaN case: python max(0.2, nan) == 0.2
-                }
+                double fac = dp54_factor(errsq);
                 if (errsq < 1.0) {
                     fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
                     if (L.rejected) fac = fmin(1.0, fac);
@@ -1404,6 +1410,199 @@ __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
     if (bad) A.flags[i] |= (uint8_t)BHG_FLAG_NAN_;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Sampled trajectories: what calc_trajectory returns with nr_points_curve (RelativisticRenderEngine.py:
+// 293-294; the curves of README Fig. 5/6).  One lane per ray, a plain loop -- this is the small-n
+// plotting path, not the frame path.  Same prepare record, same stages / error norm / factor helpers as
+// the integrate loop; after every accepted step the samples t_eval_j <= t are emitted through the step's
+// dense output (solve_ivp's t_eval semantics, ivp.py:706-723); rays that end early emit fewer samples.
+// ------------------------------------------------------------------------------------------
+template <int RHS>
+__global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, double *traj, uint32_t *n_valid,
+                                                             uint32_t T)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end, max_step = A.max_step;
+    double x[3], v[3], a1[3], h_abs, r_cur;
+    Metric met;
+    met.r_s = A.r_s;
+    met.M = 0.5 * A.r_s;
+    met.a = A.spin;
+    met.E = met.L = 0.0;
+    const double *w = A.ws + i * (uint64_t)A.ws_stride;
+    a1[0] = w[0];
+    a1[1] = w[1];
+    a1[2] = w[2];
+    h_abs = w[3];
+    r_cur = w[4];
+    if (h_abs < 0.0) {  // start inside: the prepare pass has written the result
+        n_valid[i] = 0;
+        return;
+    }
+    if (RHS == BHG_RHS_KERR_BL_) {
+        const double *e = A.end + i * 6;
+        for (int c = 0; c < 3; c++) {
+            x[c] = e[c];
+            v[c] = e[3 + c];
+        }
+        met.E = w[6];
+        met.L = w[7];
+    } else {
+        for (int c = 0; c < 3; c++) {
+            v[c] = A.k0[i * 3 + c];
+            x[c] = A.x0 ? A.x0[i * 3 + c] : A.x0s[c];
+        }
+    }
+    double *out = traj + i * 6 * (uint64_t)T;
+    const double dt = t_bound / (double)(T - 1);
+    double t = 0.0;
+    uint32_t n_att = 0, n_acc = 0, next = 0, flags = 0;
+    bool rejected = false;
+    double xe[3] = {x[0], x[1], x[2]}, ve[3] = {v[0], v[1], v[2]};
+    for (;;) {
+        const double min_step = 10.0 * ulp_of(t);
+        if (!rejected) {
+            if (h_abs > max_step)
+                h_abs = max_step;
+            else if (h_abs < min_step)
+                h_abs = min_step;
+        }
+        if (h_abs < min_step) {
+            flags = BHG_FLAG_STEP_TOO_SMALL_;
+            break;
+        }
+        if (n_att >= A.max_steps) {
+            flags = BHG_FLAG_MAX_STEPS_;
+            break;
+        }
+        if (t == t_bound) {
+            flags = BHG_FLAG_REACHED_END_;
+            break;
+        }
+        double t_new = t + h_abs;
+        if (t_new - t_bound > 0.0) t_new = t_bound;
+        const double h = t_new - t;
+        h_abs = fabs(h);
+        double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+        dp54_stages<RHS>(x, v, a1, h, met, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+        n_att++;
+        double errsq = dp54_errsq(x, v, xn, vn, a1, a2, a3, a4, a5, a6, a7, h, rtol, atol);
+        if (!(r_new == r_new)) errsq = __builtin_nan("");
+        double fac = dp54_factor(errsq);
+        if (!(errsq < 1.0)) {
+            h_abs *= fmax(0.2, fac);
+            rejected = true;
+            continue;
+        }
+        fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
+        if (rejected) fac = fmin(1.0, fac);
+        h_abs *= fac;
+        rejected = false;
+        n_acc++;
+        // dense output of the accepted step
+        Dense d;
+        d.t0 = t;
+        d.h = h;
+        for (int c = 0; c < 3; c++) {
+            d.x0[c] = x[c];
+            d.v0[c] = v[c];
+            for (int m = 0; m < 4; m++) {
+                double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] + TB.p[5][m] * a5[c] +
+                            TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
+                double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] + TB.pt[4][m] * a4[c] +
+                            TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
+                d.qv[m][c] = qv;
+                d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
+            }
+        }
+        const bool bl = RHS == BHG_RHS_KERR_BL_;
+        const bool ev_h = ((r_cur - A.r_hor <= 0.0) && (r_new - A.r_hor >= 0.0)) ||
+                          ((r_cur - A.r_hor >= 0.0) && (r_new - A.r_hor <= 0.0));
+        const bool ev_e = (A.r_exit > 0.0) && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+        double t_stop = t_new;
+        uint32_t evflag = 0;
+        if (ev_h || ev_e) {
+            const double INF = __builtin_inf();
+            double rh = INF, re = INF;
+            if (ev_h) rh = brent_root([&](double tt) { return dense_g(d, tt, A.r_hor, bl); }, t, t_new);
+            if (ev_e) re = brent_root([&](double tt) { return dense_g(d, tt, A.r_exit, bl); }, t, t_new);
+            t_stop = (rh <= re) ? rh : re;
+            evflag = (rh <= re) ? BHG_FLAG_HIT_HORIZON_ : BHG_FLAG_EXITED_SPHERE_;
+        }
+        // emit every sample time up to where this step ends
+        while (next < T) {
+            const double te = (next + 1 == T) ? t_bound : (double)next * dt;
+            if (!(te <= t_stop)) break;
+            double sx[3], sv[3];
+            dense_pos(d, te, sx);
+            dense_dir(d, te, sv);
+            if (bl) {
+                const double r = sx[0], th = sx[1], ph = sx[2], a = A.spin;
+                const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
+                const double u0 = sv[0], u1 = sv[1], u2 = sv[2];
+                sx[0] = R * st * cp;
+                sx[1] = R * st * sp;
+                sx[2] = r * ct;
+                sv[0] = (r / R * st * cp) * u0 + (R * ct * cp) * u1 + (-R * st * sp) * u2;
+                sv[1] = (r / R * st * sp) * u0 + (R * ct * sp) * u1 + (R * st * cp) * u2;
+                sv[2] = ct * u0 + (-r * st) * u1;
+            }
+            for (int c = 0; c < 3; c++) {
+                out[(uint64_t)c * T + next] = sx[c];
+                out[(uint64_t)(3 + c) * T + next] = sv[c];
+            }
+            next++;
+        }
+        if (evflag) {
+            flags = evflag;
+            dense_pos(d, t_stop, xe);
+            dense_dir(d, t_stop, ve);
+            break;
+        }
+        for (int c = 0; c < 3; c++) {
+            xe[c] = xn[c];
+            ve[c] = vn[c];
+        }
+        if (t_new - t_bound >= 0.0) {
+            flags = BHG_FLAG_REACHED_END_;
+            break;
+        }
+        t = t_new;
+        r_cur = r_new;
+        for (int c = 0; c < 3; c++) {
+            x[c] = xn[c];
+            v[c] = vn[c];
+            a1[c] = a7[c];
+        }
+    }
+    if (flags & (BHG_FLAG_STEP_TOO_SMALL_ | BHG_FLAG_MAX_STEPS_)) {
+        for (int c = 0; c < 3; c++) {
+            xe[c] = x[c];
+            ve[c] = v[c];
+        }
+    }
+    n_valid[i] = next;
+    store_result(A, (uint32_t)i, xe, ve, flags, n_att, n_acc);  // Kerr: still Boyer-Lindquist, finalised next
+}
+
+hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+{
+    const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
+    if (rhs == BHG_RHS_KERR_BL_) {
+        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+        hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a);
+    } else if (rhs == BHG_RHS_REDUCED_) {
+        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_REDUCED_, true>), dim3(gp), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+    } else {
+        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_CHRISTOFFEL_, true>), dim3(gp), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+    }
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------
 // Acceleration probe (tests compare the device RHS with the oracle's)

@@ -89,29 +89,30 @@ class GeodesicIntegratorSchwarzschild:
                         verbose=False, **_ignored):
         """Per-ray drop-in for the call at RelativisticRenderEngine.py:293-294.
 
-        Returns (k_xyz, x_xyz, result): k_xyz and x_xyz have shape (3, 2) -- the start of the
-        curve and its end -- so that `x_xyz[axis][-1]` / `k_xyz[axis][-1]` (:307-308) give the
-        end location and direction.  `nr_points_curve` is accepted for signature compatibility;
-        the engine consumes only the last sample, so the intermediate samples are not produced.
+        Returns (k_xyz, x_xyz, result): k_xyz and x_xyz have shape (3, T') with the curve sampled at
+        t_eval = linspace(0, curve_end, nr_points_curve) up to where the ray ends (T' <= nr_points_curve,
+        as solve_ivp's t_eval gives), so that `x, y, z = x_xyz` (:299) and `x[-1]` (:307-308) work as
+        in the reference.  result['end_loc'] / ['end_dir'] carry the exact end state (the event root for
+        horizon rays), the same numbers trace() returns.
         """
         k0 = np.asarray(k0_xyz, dtype=np.float64).reshape(3)
         x0 = np.asarray(x0_xyz, dtype=np.float64).reshape(3)
-        out = self.trace(k0[None, :], x0, max_step=max_step, curve_end=curve_end)
-        end = out["ray_end"][0]
-        flags = int(out["flags"][0])
-        x_xyz = np.stack([x0, end[0:3]], axis=1)
-        k_xyz = np.stack([k0, end[3:6]], axis=1)
+        n_pts = max(2, int(nr_points_curve))
+        traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end), n_pts)
+        m = int(nv[0])
+        fl = int(flags[0])
+        x_xyz = traj[0, 0:3, :m].copy()
+        k_xyz = traj[0, 3:6, :m].copy()
         result = {
-            "start_inside_hole": bool(flags & _ffi.FLAG_START_INSIDE),
-            "hit_blackhole": bool(flags & _ffi.FLAG_HIT_HORIZON),
-            "flags": flags,
-            "n_steps": int(out["n_steps"][0]),
-            "n_accepted": int(out["n_accepted"][0]),
+            "start_inside_hole": bool(fl & _ffi.FLAG_START_INSIDE),
+            "hit_blackhole": bool(fl & _ffi.FLAG_HIT_HORIZON),
+            "flags": fl,
+            "end_loc": end[0, 0:3].copy(),
+            "end_dir": end[0, 3:6].copy(),
         }
         if verbose or self.verbose:
-            print("calc_trajectory:", result)
+            print("calc_trajectory:", {k: result[k] for k in ("start_inside_hole", "hit_blackhole", "flags")})
         return k_xyz, x_xyz, result
-
 
 class GeodesicIntegratorKerr(GeodesicIntegratorSchwarzschild):
     """Null geodesics around a Kerr black hole (BASELINE.json config 5).

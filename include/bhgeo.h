@@ -121,6 +121,17 @@ int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is
               const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
               uint32_t *n_accepted);
 
+/* Sampled curves, host buffers: what calc_trajectory returns for nr_points_curve samples
+ * (RelativisticRenderEngine.py:293-294, :299-302; the trajectory plots of README.md Fig. 5/6).
+ * t_eval = linspace(0, lambda_end, n_points); after every accepted step the samples t_eval <= lambda
+ * are produced from the step's dense output, as solve_ivp does with t_eval; a ray that ends early (horizon,
+ * exit sphere) yields n_valid[i] < n_points samples, the rest of its row is NaN.  traj [n][6][n_points]
+ * (rows x, y, z, k_x, k_y, k_z).  end [n][6] / flags [n] (may be NULL): the same end state and flags
+ * bhg_trace gives.  BHG_METHOD_DP54 only; the disk event is not available here.  Small-n path: one
+ * lane per ray. */
+int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
+                   size_t n, uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags);
+
 /* Device buffers (all d_* are device addresses on ctx's device; x0_shared is a HOST [3] array or
  * NULL when d_x0 [n][3] is given).  Enqueues on `stream` (a hipStream_t; NULL = HIP's null
  * stream, as everywhere in HIP; bhg_context_stream() gives the context's own stream) and

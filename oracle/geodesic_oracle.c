@@ -204,6 +204,8 @@ static const double P_[7][4] = {
 #define MIN_FACTOR 0.2
 #define MAX_FACTOR 10.0
 
+static void pack_end(const double y[6], double end[6]);
+
 /* RMS norm -- common.py:63-65 */
 static double rms6(const double v[6])
 {
@@ -481,11 +483,38 @@ typedef struct {
     uint32_t flags, n_attempted, n_accepted, nfev;
 } ray_result;
 
+/* optional trajectory sampler: t_eval = linspace(0, lambda_end, T) like the engine's
+   nr_points_curve request (RelativisticRenderEngine.py:294); samples with t_eval <= t are emitted
+   through the step's dense output after every accepted step (ivp.py:706-723) */
+typedef struct {
+    uint32_t T, next;
+    double lambda_end;
+    double *out; /* [6][T]: x, y, z, k_x, k_y, k_z rows (Kerr: converted by the caller) */
+} sampler_t;
+
+static double sampler_time(const sampler_t *sm, uint32_t j)
+{
+    if (j + 1 == sm->T) return sm->lambda_end;
+    return (double)j * (sm->lambda_end / (double)(sm->T - 1));
+}
+
+static void sampler_emit(sampler_t *sm, const dense_t *dn, double t_upto)
+{
+    while (sm->next < sm->T && sampler_time(sm, sm->next) <= t_upto) {
+        double y[6], e[6];
+        dense_eval(dn, sampler_time(sm, sm->next), y);
+        pack_end(y, e);
+        for (int c = 0; c < 6; c++) sm->out[(size_t)c * sm->T + sm->next] = e[c];
+        sm->next++;
+    }
+}
+
 /* ---------------------------------------------------------------------------------------
  * One ray, adaptive DP5(4): RungeKutta.__init__ (rk.py:84-104) + solve_ivp loop
  * (ivp.py:654-723) + _step_impl (rk.py:111-176)
  * ------------------------------------------------------------------------------------- */
-static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res)
+static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res,
+                       sampler_t *sm)
 {
     double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
     double f[6], K[7][6], y_new[6], f_new[6];
@@ -578,17 +607,19 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
                   ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0)) ||
                   ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0))));
+        if (any || sm) dense_build(&dn, t_old, t, y_old, K);
         if (any) {
-            dense_build(&dn, t_old, t, y_old, K);
             double t_root, y_root[6];
             uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, z_old, z_new, &base, t_old, t, &t_root, y_root);
             if (fl) {
                 res->flags |= fl;
                 t = t_root;
                 memcpy(y, y_root, sizeof(y));
+                if (sm) sampler_emit(sm, &dn, t);
                 break;
             }
         }
+        if (sm) sampler_emit(sm, &dn, t);
         g_h = g_h_new;
         g_e = g_e_new;
         if (t - t_bound >= 0) { /* base.py:203-204 */
@@ -725,7 +756,7 @@ static void bl_to_cart(const double q[3], const double u[3], double a, double x[
     for (int i = 0; i < 3; i++) k[i] = J[i][0] * u[0] + J[i][1] * u[1] + J[i][2] * u[2];
 }
 
-static void trace_one(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res)
+static void trace_one(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res, sampler_t *sm)
 {
     rayctx rc;
     memset(&rc, 0, sizeof(rc));
@@ -758,12 +789,25 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
         if (p->method == BHGO_METHOD_RK4)
             trace_rk4(p, &rc, q, u, res);
         else
-            trace_dp54(p, &rc, q, u, res);
+            trace_dp54(p, &rc, q, u, res, sm);
         /* res->end is {r, th, ph, ur, uth, uph}: back to Cartesian */
         double xe[3], ke[3];
         bl_to_cart(res->end, res->end + 3, a, xe, ke);
         memcpy(res->end, xe, sizeof(xe));
         memcpy(res->end + 3, ke, sizeof(ke));
+        if (sm)
+            for (uint32_t j = 0; j < sm->next; j++) {
+                double qq[3], uu[3];
+                for (int c = 0; c < 3; c++) {
+                    qq[c] = sm->out[(size_t)c * sm->T + j];
+                    uu[c] = sm->out[(size_t)(3 + c) * sm->T + j];
+                }
+                bl_to_cart(qq, uu, a, xe, ke);
+                for (int c = 0; c < 3; c++) {
+                    sm->out[(size_t)c * sm->T + j] = xe[c];
+                    sm->out[(size_t)(3 + c) * sm->T + j] = ke[c];
+                }
+            }
         return;
     }
     double r0 = sqrt(x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2]);
@@ -782,7 +826,7 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
     if (p->method == BHGO_METHOD_RK4)
         trace_rk4(p, &rc, x0, k0, res);
     else
-        trace_dp54(p, &rc, x0, k0, res);
+        trace_dp54(p, &rc, x0, k0, res, sm);
 }
 
 /* ---------------------------------------------------------------------------------------
@@ -816,12 +860,28 @@ int bhgo_trace(const bhgo_params *p, const double *x0, int x0_shared, const doub
     for (long long i = 0; i < nn; i++) {
         ray_result r;
         const double *xi = x0_shared ? x0 : x0 + 3 * i;
-        trace_one(p, xi, k0 + 3 * i, &r);
+        trace_one(p, xi, k0 + 3 * i, &r, NULL);
         memcpy(end + 6 * i, r.end, sizeof(double) * 6);
         if (flags) flags[i] = (uint8_t)r.flags;
         if (n_attempted) n_attempted[i] = r.n_attempted;
         if (n_accepted) n_accepted[i] = r.n_accepted;
         if (t_end) t_end[i] = r.t_end;
+    }
+    return 0;
+}
+
+/* Sampled trajectories (DP5(4) only): traj [n][6][T], n_valid [n] = samples emitted per ray
+   (t_eval points beyond the ray's end are not produced, as with solve_ivp's t_eval) */
+int bhgo_trajectory(const bhgo_params *p, const double *x0, int x0_shared, const double *k0, size_t n, uint32_t T,
+                    double *traj, uint32_t *n_valid, uint8_t *flags)
+{
+    if (!p || !x0 || !k0 || !traj || !n_valid || T < 2 || p->method != BHGO_METHOD_DP54) return -1;
+    for (size_t i = 0; i < n; i++) {
+        ray_result r;
+        sampler_t sm = {T, 0, p->lambda_end, traj + i * 6 * (size_t)T};
+        trace_one(p, x0_shared ? x0 : x0 + 3 * i, k0 + 3 * i, &r, &sm);
+        n_valid[i] = sm.next;
+        if (flags) flags[i] = (uint8_t)r.flags;
     }
     return 0;
 }

@@ -80,6 +80,9 @@ def lib():
                                  C.POINTER(C.c_uint32), dp, C.c_int]
         L.bhgo_acceleration.restype = C.c_int
         L.bhgo_acceleration.argtypes = [C.POINTER(Params), dp, dp, C.c_size_t, dp]
+        L.bhgo_trajectory.restype = C.c_int
+        L.bhgo_trajectory.argtypes = [C.POINTER(Params), dp, C.c_int, dp, C.c_size_t, C.c_uint32, dp,
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
         L.bhgo_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -110,6 +113,22 @@ def trace(k0, x0, n_threads=0, **kw):
     if rc != 0:
         raise RuntimeError(f"bhgo_trace failed: {rc}")
     return {"end": end, "flags": flags, "n_attempted": natt, "n_accepted": nacc, "t_end": tend}
+
+
+def trajectory(k0, x0, n_points, **kw):
+    """Sampled curves: (traj[N,6,T], n_valid[N], flags[N]); t_eval = linspace(0, lambda_end, T)."""
+    p = make_params(**kw)
+    k0 = np.ascontiguousarray(np.atleast_2d(k0), dtype=np.float64)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    n = k0.shape[0]
+    traj = np.full((n, 6, n_points), np.nan)
+    nv = np.zeros(n, np.uint32)
+    flags = np.zeros(n, np.uint8)
+    rc = lib().bhgo_trajectory(C.byref(p), _dp(x0), 1 if x0.ndim == 1 else 0, _dp(k0), n, n_points, _dp(traj),
+                               nv.ctypes.data_as(C.POINTER(C.c_uint32)), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != 0:
+        raise RuntimeError(f"bhgo_trajectory failed: {rc}")
+    return traj, nv, flags
 
 
 def acceleration(x, k, **kw):

@@ -437,20 +437,52 @@ def test_device_buffer_entry_point_matches_host_entry_point(ctx, full_frame):
 
 
 def test_calc_trajectory_adaptor(ctx, oracle):
-    """The per-ray drop-in for RelativisticRenderEngine.py:293-313."""
+    """The per-ray drop-in for RelativisticRenderEngine.py:293-313, with the sampled curve the
+    reference requests (nr_points_curve) compared with the oracle's solve_ivp-style t_eval sampling."""
     from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
     gi = GeodesicIntegratorSchwarzschild(mass=0.5, time_like=False, verbose=False, context=ctx)
-    for b in (0.5, 2.62, 5.0):
+    for b, npts in ((0.5, 10000), (2.0, 10000), (2.62, 777), (5.0, 10000)):
         k0 = np.array([b / 30.0, 0.0, -1.0])
         k0 /= np.linalg.norm(k0)
-        k_xyz, x_xyz, result = gi.calc_trajectory(k0, CAM, max_step=np.inf, curve_end=50, nr_points_curve=10000, verbose=False)
+        k_xyz, x_xyz, result = gi.calc_trajectory(k0, CAM, max_step=np.inf, curve_end=50, nr_points_curve=npts, verbose=False)
         o = oracle.trace(k0[None], CAM, r_s=1.0, lambda_end=50.0)
-        x, y, z = x_xyz
-        k_x, k_y, k_z = k_xyz
-        end_loc = np.array([x[-1], y[-1], z[-1]])
-        end_dir = np.array([k_x[-1], k_y[-1], k_z[-1]])
+        tr, nv, fl = oracle.trajectory(k0[None], CAM, npts, r_s=1.0, lambda_end=50.0)
+        x, y, z = x_xyz                      # :299
+        k_x, k_y, k_z = k_xyz                # :300
         assert result["start_inside_hole"] is False
         assert result["hit_blackhole"] == bool(o["flags"][0] & 1)
-        assert np.abs(end_loc - o["end"][0, 0:3]).max() < 1e-8 and np.abs(end_dir - o["end"][0, 3:6]).max() < 1e-8
-    _, _, result = gi.calc_trajectory(np.array([0, 0, -1.0]), np.array([0.1, 0.1, 0.1]))
-    assert result["start_inside_hole"] is True and result["hit_blackhole"] is True
+        assert len(x) == nv[0] and (len(x) == npts) == (not result["hit_blackhole"])
+        assert np.abs(x_xyz - tr[0, 0:3, :nv[0]]).max() < 1e-8 and np.abs(k_xyz - tr[0, 3:6, :nv[0]]).max() < 1e-8
+        assert np.array_equal(x_xyz[:, 0], CAM) and np.array_equal(k_xyz[:, 0], k0)
+        # exact end state rides along; for escaping rays it is also the last sample (:307-308)
+        assert np.abs(result["end_loc"] - o["end"][0, 0:3]).max() < 1e-8
+        if not result["hit_blackhole"]:
+            end_loc = np.array([x[-1], y[-1], z[-1]])
+            end_dir = np.array([k_x[-1], k_y[-1], k_z[-1]])
+            assert np.abs(end_loc - o["end"][0, 0:3]).max() < 1e-8 and np.abs(end_dir - o["end"][0, 3:6]).max() < 1e-8
+    k_xyz, x_xyz, result = gi.calc_trajectory(np.array([0, 0, -1.0]), np.array([0.1, 0.1, 0.1]))
+    assert result["start_inside_hole"] is True and result["hit_blackhole"] is True and x_xyz.shape == (3, 0)
+
+
+def test_trajectories_batch_match_trace_and_oracle(ctx, oracle):
+    k = frame_rays(300, seed=51)
+    for kw in (dict(r_s=1.0, lambda_end=50.0), dict(r_s=1.0, lambda_end=50.0, rhs_form=1, r_exit=31.0),
+               dict(r_s=1.0, lambda_end=40.0, rhs_form=2, spin=0.45)):
+        cam = CAM if kw.get("rhs_form") != 2 else np.array([2.0, -24.0, 14.0])
+        kk = k if kw.get("rhs_form") != 2 else (k @ np.array([[1, 0, 0], [0, 0.5, 0.866], [0, -0.866, 0.5]]))
+        T = 64
+        traj, nv, end, flags = ctx.trajectory(kk, cam, _params(**kw), T)
+        e2, f2, s2, a2 = ctx.trace(kk, cam, _params(**kw))
+        assert np.array_equal(flags, f2) and np.array_equal(end, e2)     # same controller, bit for bit
+        tr, onv, ofl = oracle.trajectory(kk, cam, T, **kw)
+        assert np.array_equal(flags, ofl)
+        same = nv == onv
+        assert same.mean() > 0.99
+        dmax = []
+        for i in np.nonzero(same)[0][:120]:
+            dmax.append(np.abs(traj[i, :, :nv[i]] - tr[i, :, :nv[i]]).max())
+            assert np.isnan(traj[i, :, nv[i]:]).all()
+        if kw.get("rhs_form") == 2:   # Boyer-Lindquist rays near the axis / horizon amplify rounding (see the Kerr tests)
+            assert np.median(dmax) < 1e-8 and max(dmax) < 1e-2
+        else:
+            assert max(dmax) < 1e-8
