@@ -834,8 +834,15 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
     w[4] = r_new;
     w[5] = t_new;
     A.flags[idx] = (uint8_t)EV_RESUME;
-    const unsigned long long slot = atomicAdd(A.work_count_out, 1ull);
-    A.worklist_out[slot] = idx;
+    // one atomic per wavefront, not per ray: a single counter word saturates near 90 adds/us and a
+    // config-3 frame resumes most of its million rays (the lanes that reach this point add together)
+    const uint64_t act = __ballot(1);
+    const uint32_t rank = lane_rank(act);
+    unsigned long long base = 0;
+    if (rank == 0) base = atomicAdd(A.work_count_out, (unsigned long long)__builtin_popcountll(act));
+    const int leader = __builtin_ctzll(act);
+    const uint32_t blo = __shfl((uint32_t)base, leader), bhi = __shfl((uint32_t)(base >> 32), leader);
+    A.worklist_out[(((unsigned long long)bhi << 32) | blo) + rank] = idx;
 }
 
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
