@@ -212,3 +212,21 @@ def test_kerr_frame_dragging_breaks_the_mirror_symmetry(oracle):
     s = oracle.trace(k, cam, r_s=1.0, lambda_end=80.0, rtol=1e-9, atol=1e-11, rhs_form=oracle.RHS_REDUCED)
     assert np.array_equal(s["flags"], [1, 1])      # b = 2.4 < 2.598: both captured without spin
     assert sorted(o["flags"].tolist()) == [1, 4]   # with a/M = 0.9 the prograde side escapes
+
+
+def test_default_tolerance_error_against_converged_solution(oracle):
+    """T2 of SURVEY section 7: how far the DEFAULT controller (rtol 1e-3, atol 1e-6, the engine's and
+    scipy's defaults) is from a converged solve, per impact parameter -- the accuracy the reference's own
+    settings deliver.  Measured constants are asserted with slack so that a regression shows."""
+    bs = np.array([3.0, 4.0, 5.0, 7.0, 10.0, 14.0])
+    k = np.stack([bs / 30.0, np.zeros_like(bs), -np.ones_like(bs)], 1)
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    conv = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-12, atol=1e-14, rhs_form=1)
+    for rtol, bound in ((1e-3, 0.6), (1e-5, 6e-3), (1e-7, 6e-5)):
+        o = oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=rtol, atol=rtol * 1e-3, rhs_form=0)
+        err = np.abs(o["end"] - conv["end"]).max(1)
+        assert np.all(o["flags"] == 4) and err.max() < bound, (rtol, err)
+    # and the order of the method shows: 100x tighter tolerance -> ~100x smaller error
+    e3 = np.abs(oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-5, atol=1e-8)["end"] - conv["end"]).max()
+    e5 = np.abs(oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-7, atol=1e-10)["end"] - conv["end"]).max()
+    assert 10 < e3 / e5 < 1000
