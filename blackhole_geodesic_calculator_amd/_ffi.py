@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -28,6 +28,8 @@ FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
 FLAG_HIT_DISK = 128
+FLAG_HIT_OBJECT = 0x88  # composite: test with (flags & 0x88) == 0x88
+MAX_SPHERES = 8
 
 METHOD_DP54 = 0
 METHOD_RK4 = 1
@@ -40,8 +42,14 @@ EXPORTS = (
     "bhg_version", "bhg_device_count", "bhg_last_error", "bhg_default_params", "bhg_create",
     "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
-    "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory",
+    "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
+    "bhg_trace_objects_device",
 )
+
+
+def _spheres_array(spheres):
+    sp = np.ascontiguousarray(spheres, dtype=np.float64).reshape(-1, 4)
+    return sp if len(sp) else np.zeros((1, 4))[:0]
 
 
 class BhgError(RuntimeError):
@@ -115,6 +123,13 @@ def load():
     L.bhg_trace_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
+    L.bhg_trace_objects.restype = C.c_int
+    L.bhg_trace_objects.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int32, _dp, C.c_int, _dp, C.c_size_t, _dp,
+                                    _u8p, _u32p, _u32p, C.POINTER(C.c_int8)]
+    L.bhg_trace_objects_device.restype = C.c_int
+    L.bhg_trace_objects_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int32, _dp, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
     L.bhg_raygen_device.restype = C.c_int
     L.bhg_raygen_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -223,8 +238,9 @@ class Context:
         _check(load().bhg_synchronize(self._h))
 
     # -- host buffers -------------------------------------------------------------------
-    def trace(self, k0, x0, params: Params, want_accepted=True):
-        """k0[N,3], x0[3] (shared) or [N,3] -> (end[N,6], flags[N] u8, n_steps[N] u32, n_accepted[N] u32)."""
+    def trace(self, k0, x0, params: Params, want_accepted=True, spheres=None):
+        """k0[N,3], x0[3] (shared) or [N,3] -> (end[N,6], flags[N] u8, n_steps[N] u32, n_accepted[N] u32);
+        with spheres [[cx, cy, cz, radius], ...] a fifth array object_id[N] i8 is appended."""
         k0 = np.ascontiguousarray(k0, dtype=np.float64)
         if k0.ndim != 2 or k0.shape[1] != 3:
             raise ValueError("k0 must have shape [N, 3]")
@@ -240,6 +256,15 @@ class Context:
         flags = np.empty(n, np.uint8)
         steps = np.empty(n, np.uint32)
         acc = np.empty(n, np.uint32) if want_accepted else None
+        if spheres is not None:
+            sp = _spheres_array(spheres)
+            obj = np.empty(n, np.int8)
+            _check(load().bhg_trace_objects(self._h, C.byref(params), _np_dp(sp), len(sp), _np_dp(x0), 1 if shared else 0,
+                                            _np_dp(k0), n, _np_dp(end), flags.ctypes.data_as(_u8p),
+                                            steps.ctypes.data_as(_u32p),
+                                            acc.ctypes.data_as(_u32p) if acc is not None else None,
+                                            obj.ctypes.data_as(C.POINTER(C.c_int8))))
+            return end, flags, steps, acc, obj
         _check(load().bhg_trace(self._h, C.byref(params), _np_dp(x0), 1 if shared else 0, _np_dp(k0), n,
                                 _np_dp(end), flags.ctypes.data_as(_u8p), steps.ctypes.data_as(_u32p),
                                 acc.ctypes.data_as(_u32p) if acc is not None else None))
@@ -262,10 +287,18 @@ class Context:
 
     # -- device buffers (raw addresses, e.g. torch.Tensor.data_ptr()) -------------------
     def trace_device(self, params: Params, n, d_k0, d_end, x0_shared=None, d_x0=0, d_flags=0,
-                     d_n_steps=0, d_n_accepted=0, stream=0):
+                     d_n_steps=0, d_n_accepted=0, stream=0, spheres=None, d_object_id=0):
         xs = None
         if x0_shared is not None:
             xs = (C.c_double * 3)(*[float(v) for v in x0_shared])
+        if spheres is not None:
+            sp = _spheres_array(spheres)
+            _check(load().bhg_trace_objects_device(self._h, C.byref(params), _np_dp(sp), len(sp), xs,
+                                                   C.c_void_p(d_x0 or None), C.c_void_p(d_k0), int(n), C.c_void_p(d_end),
+                                                   C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),
+                                                   C.c_void_p(d_n_accepted or None), C.c_void_p(d_object_id or None),
+                                                   C.c_void_p(stream or None)))
+            return
         _check(load().bhg_trace_device(self._h, C.byref(params), xs, C.c_void_p(d_x0 or None),
                                        C.c_void_p(d_k0), int(n), C.c_void_p(d_end),
                                        C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),

@@ -23,6 +23,7 @@ static_assert(BHG_FLAG_EXITED_SPHERE == bhg::BHG_FLAG_EXITED_SPHERE_, "flag mism
 static_assert(BHG_FLAG_MAX_STEPS == bhg::BHG_FLAG_MAX_STEPS_, "flag mismatch");
 static_assert(BHG_FLAG_STEP_TOO_SMALL == bhg::BHG_FLAG_STEP_TOO_SMALL_, "flag mismatch");
 static_assert(BHG_FLAG_NAN == bhg::BHG_FLAG_NAN_, "flag mismatch");
+static_assert(BHG_FLAG_HIT_OBJECT == bhg::BHG_FLAG_HIT_OBJECT_ && BHG_MAX_SPHERES == bhg::BHG_MAX_SPHERES_, "object constants mismatch");
 static_assert(BHG_METHOD_DP54 == bhg::BHG_METHOD_DP54_ && BHG_METHOD_RK4 == bhg::BHG_METHOD_RK4_, "method mismatch");
 static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_ &&
                   BHG_RHS_KERR_BL == bhg::BHG_RHS_KERR_BL_,
@@ -255,12 +256,32 @@ int bhg_last_launch(bhg_context *c, int32_t out[4])
     return BHG_OK;
 }
 
-int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_shared, const double *d_x0,
-                     const double *d_k0, size_t n, double *d_end, uint8_t *d_flags, uint32_t *d_n_steps,
-                     uint32_t *d_n_accepted, void *stream)
+}  // extern "C"
+
+namespace {
+
+int validate_spheres(const bhg_params *p, const double *spheres, int32_t n_spheres)
+{
+    if (n_spheres < 0 || n_spheres > BHG_MAX_SPHERES) return fail(BHG_E_INVALID, "n_spheres must be in [0, BHG_MAX_SPHERES]");
+    if (n_spheres == 0) return BHG_OK;
+    if (!spheres) return fail(BHG_E_INVALID, "spheres is NULL");
+    if (p->rhs_form == BHG_RHS_KERR_BL) return fail(BHG_E_INVALID, "object spheres are not available with BHG_RHS_KERR_BL");
+    for (int j = 0; j < n_spheres; j++) {
+        const double *sp = spheres + 4 * j;
+        if (!std::isfinite(sp[0]) || !std::isfinite(sp[1]) || !std::isfinite(sp[2]) || !std::isfinite(sp[3]) || !(sp[3] > 0.0))
+            return fail(BHG_E_INVALID, "sphere centres must be finite and radii finite and > 0");
+    }
+    return BHG_OK;
+}
+
+int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                      const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
+                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    rc = validate_spheres(p, spheres, n_spheres);
     if (rc != BHG_OK) return rc;
     if (n == 0) return BHG_OK;
     if (!d_k0 || !d_end) return fail(BHG_E_INVALID, "k0 / end is NULL");
@@ -274,7 +295,9 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     //   flags   [n] bytes       when the caller does not want flags
     //   with a disk: n_steps / n_accepted [n] u32 when not wanted, two resume worklists [n] u32, two counts
     const bool has_exit = p->r_exit > 0.0;
-    const bool has_disk = p->disk_r_out > 0.0;
+    // "has_disk": the call needs the resume machinery -- disk-plane crossings outside the annulus and
+    // chords through an object sphere that the curve itself misses both hand the ray to a further pass
+    const bool has_disk = p->disk_r_out > 0.0 || n_spheres > 0;
     const size_t sz_ws = n * 8 * sizeof(double);
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
@@ -333,7 +356,11 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
-    const int evt = (has_exit ? 1 : 0) | (has_disk ? 2 : 0);
+    a.object_id = d_object_id;
+    a.n_spheres = n_spheres;
+    for (int j = 0; j < n_spheres; j++)
+        for (int q = 0; q < 4; q++) a.spheres[j][q] = spheres[4 * j + q];
+    const int evt = n_spheres > 0 ? 7 : ((has_exit ? 1 : 0) | (has_disk ? 2 : 0));
 
     int per_cu = 0;
     HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, evt, &per_cu));
@@ -396,11 +423,41 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
     return BHG_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_shared, const double *d_x0,
+                     const double *d_k0, size_t n, double *d_end, uint8_t *d_flags, uint32_t *d_n_steps,
+                     uint32_t *d_n_accepted, void *stream)
+{
+    return trace_device_impl(c, p, nullptr, 0, x0_shared, d_x0, d_k0, n, d_end, d_flags, d_n_steps, d_n_accepted, nullptr,
+                             stream);
+}
+
+int bhg_trace_objects_device(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                             const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
+                             uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id,
+                             void *stream)
+{
+    return trace_device_impl(c, p, spheres, n_spheres, x0_shared, d_x0, d_k0, n, d_end, d_flags, d_n_steps, d_n_accepted,
+                             d_object_id, stream);
+}
+
 int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
               size_t n, double *end, uint8_t *flags, uint32_t *n_steps, uint32_t *n_accepted)
 {
+    return bhg_trace_objects(c, p, nullptr, 0, x0, x0_is_shared, k0, n, end, flags, n_steps, n_accepted, nullptr);
+}
+
+int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const double *x0,
+                      int x0_is_shared, const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
+                      uint32_t *n_accepted, int8_t *object_id)
+{
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    rc = validate_spheres(p, spheres, n_spheres);
     if (rc != BHG_OK) return rc;
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !end) return fail(BHG_E_INVALID, "x0 / k0 / end is NULL");
@@ -409,7 +466,8 @@ int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_s
     const size_t off_flags = n * 6 * sizeof(double);
     const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
     const size_t off_acc = off_steps + n * sizeof(uint32_t);
-    const size_t out_bytes = off_acc + n * sizeof(uint32_t);
+    const size_t off_obj = off_acc + n * sizeof(uint32_t);
+    const size_t out_bytes = off_obj + n;
     rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
     if (rc != BHG_OK) return rc;
     rc = ensure(&c->d_out, &c->d_out_bytes, out_bytes);
@@ -419,9 +477,11 @@ int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_s
     char *o = (char *)c->d_out;
     HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = bhg_trace_device(c, p, x0_is_shared ? x0 : nullptr, d_x0, d_k0, n, (double *)o, (uint8_t *)(o + off_flags),
-                          (uint32_t *)(o + off_steps), (uint32_t *)(o + off_acc), c->stream);
+    rc = trace_device_impl(c, p, spheres, n_spheres, x0_is_shared ? x0 : nullptr, d_x0, d_k0, n, (double *)o,
+                           (uint8_t *)(o + off_flags), (uint32_t *)(o + off_steps), (uint32_t *)(o + off_acc),
+                           object_id ? (int8_t *)(o + off_obj) : nullptr, c->stream);
     if (rc != BHG_OK) return rc;
+    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, o + off_obj, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(end, o, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (flags) HIP_TRY(hipMemcpyAsync(flags, o + off_flags, n, hipMemcpyDeviceToHost, c->stream));
     if (n_steps) HIP_TRY(hipMemcpyAsync(n_steps, o + off_steps, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

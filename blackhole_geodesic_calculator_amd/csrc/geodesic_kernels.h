@@ -15,6 +15,8 @@ constexpr uint32_t BHG_FLAG_MAX_STEPS_ = 16u;
 constexpr uint32_t BHG_FLAG_STEP_TOO_SMALL_ = 32u;
 constexpr uint32_t BHG_FLAG_NAN_ = 64u;
 constexpr uint32_t BHG_FLAG_HIT_DISK_ = 128u;
+constexpr uint32_t BHG_FLAG_HIT_OBJECT_ = 0x88u;
+constexpr int BHG_MAX_SPHERES_ = 8;
 constexpr int BHG_METHOD_DP54_ = 0;
 constexpr int BHG_METHOD_RK4_ = 1;
 constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
@@ -46,6 +48,9 @@ struct TraceArgs {
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
     uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged
     unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
+    int8_t *object_id;           // [n] or nullptr: sphere index of rays that end with BHG_FLAG_HIT_OBJECT, else -1
+    int32_t n_spheres;           // object spheres inside the curved region (Schwarzschild forms only)
+    double spheres[BHG_MAX_SPHERES_][4];  // {cx, cy, cz, radius}, BH-centred
 };
 
 // camera-ray generation (frame_kernels.hip)
@@ -73,7 +78,7 @@ hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
 
 // ev: nullptr, or 4 events recorded around prepare | trace | resolve on stream s
-// evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event
+// evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event, bit 2 = object spheres (then all three)
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]

@@ -410,13 +410,52 @@ struct WaveLds {
 };
 
 // Internal values of flags[i] between the passes (never visible after the call returns):
-//   EV_PENDING | kind : the ray's last accepted step crossed an event surface; the resolve pass
-//                       locates the root(s) (kind bits below)
-//   EV_RESUME         : the crossing was not terminal (disk plane outside the annulus); the ray
-//                       carries on from the end of that step in the next trace pass
-// No final flag value has both of the top bits and any of the low three bits set.
-constexpr uint32_t EV_PENDING = 0xC0u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_RESUME = 0xC8u;
-constexpr int EVT_EXIT = 1, EVT_DISK = 2;
+//   EV_TAG | kind << 2 : the ray's last accepted step crossed (or may have crossed) an event surface;
+//                        the resolve pass locates the root(s) (kind bits below, never 0)
+//   EV_RESUME          : the step held no terminal event after all (disk plane outside the annulus, a
+//                        chord through an object the curve itself misses); the ray carries on from the
+//                        end of that step in the next trace pass
+// Both have bit 1 set and bit 0 clear, which no final value has: BHG_FLAG_START_INSIDE (2) only ever
+// comes together with BHG_FLAG_HIT_HORIZON (1).
+constexpr uint32_t EV_TAG = 2u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u, EV_RESUME = 0x42u;
+__device__ __forceinline__ uint32_t pending_kind(uint32_t fl) { return ((fl & 3u) == EV_TAG) ? ((fl >> 2) & 0xFu) : 0u; }
+constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
+
+// Does the accepted step x0 -> x1 possibly enter one of the object spheres?  A ray outside sphere j at the
+// step's start enters it if the step ends inside, or if the chord between the step ends passes through
+// (closest point of the chord at s* = b / cc in (0, 1) with squared distance d0 - b^2 / cc < rho^2, written
+// without the division).  The CPU checker states the same expressions in the same order.
+__device__ __forceinline__ bool sphere_candidate(const double sp[4], const double x0[3], const double x1[3], double &bb,
+                                                 double &cc, bool &ends_inside)
+{
+    const double rho2 = sp[3] * sp[3];
+    const double a0[3] = {x0[0] - sp[0], x0[1] - sp[1], x0[2] - sp[2]};
+    const double a1[3] = {x1[0] - sp[0], x1[1] - sp[1], x1[2] - sp[2]};
+    const double d0 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2];
+    const double d1 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+    bb = cc = 0.0;
+    ends_inside = false;
+    if (!(d0 > rho2)) return false;
+    if (d1 <= rho2) {
+        ends_inside = true;
+        return true;
+    }
+    const double ch[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
+    cc = ch[0] * ch[0] + ch[1] * ch[1] + ch[2] * ch[2];
+    bb = -(a0[0] * ch[0] + a0[1] * ch[1] + a0[2] * ch[2]);
+    return bb > 0.0 && bb < cc && (d0 - rho2) * cc < bb * bb;
+}
+
+__device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
+{
+    bool any = false;
+    for (int j = 0; j < A.n_spheres; j++) {
+        double bb, cc;
+        bool inside;
+        any |= sphere_candidate(A.spheres[j], x0, x1, bb, cc, inside);
+    }
+    return any;
+}
 // ray records in A.ws are A.ws_stride doubles apart: {a(3), w3, w4, w5} (+ {E, L} for Kerr, stride 8)  // template bitmask: which optional events are compiled in
 
 struct Lane {
@@ -771,46 +810,75 @@ __device__ __forceinline__ double dp54_factor(double errsq)
     return (errsq < 1e7) ? 0.9 * pow_m0p1(fmax(errsq, 1e-11)) : 0.2;
 }
 
-// Visit the event roots of one accepted step in time order (handle_events sorts them, ivp.py:111-122;
-// ties keep the order horizon, exit, disk).  Horizon and sphere exit always end the ray; a disk-plane
-// crossing ends it only inside the annulus R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424).
-// g_r(t, R) = r(t) - R, g_z(t) = z(t), eval(t, x, v) = interpolated state.  Returns true if the ray ended.
-template <class GR, class GZ, class EV>
+// The terminal event of one accepted step, if it holds one: of the candidates the earliest root wins
+// (handle_events sorts the roots, ivp.py:111-122; ties keep the order horizon, exit, disk, sphere 0, 1, ...).
+// Horizon and sphere exit always end the ray; a disk-plane crossing only inside the annulus
+// R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424); an object sphere when the curve enters
+// it (the reference's collision stub, RelativisticRenderEngine.py:304-305).
+// g_r(t, R) = r(t) - R, g_z(t) = z(t), pos(t, x) / eval(t, x, v) = interpolated state.  Returns true if the ray ended.
+template <class GR, class GZ, class POS, class EV>
 __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind, uint32_t idx, double t, double t_new,
-                                              const GR &g_r, const GZ &g_z, const EV &eval)
+                                              const double x0[3], const double x1[3], const GR &g_r, const GZ &g_z,
+                                              const POS &pos, const EV &eval)
 {
-    const double INF = __builtin_inf();
-    double rh = INF, re = INF, rz = INF;
-    if (kind & EV_HORIZON) rh = brent_root([&](double tt) { return g_r(tt, A.r_hor); }, t, t_new);
-    if (kind & EV_EXIT) re = brent_root([&](double tt) { return g_r(tt, A.r_exit); }, t, t_new);
-    if (kind & EV_DISK) rz = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
-    for (int it = 0; it < 2; it++) {
-        double tm;
-        uint32_t fl;
-        if (rh <= re && rh <= rz) {
-            tm = rh;
+    double best = __builtin_inf();
+    uint32_t fl = 0;
+    int obj = -1;
+    if (kind & EV_HORIZON) {
+        const double r = brent_root([&](double tt) { return g_r(tt, A.r_hor); }, t, t_new);
+        if (r < best) {
+            best = r;
             fl = BHG_FLAG_HIT_HORIZON_;
-        } else if (re <= rz) {
-            tm = re;
+        }
+    }
+    if (kind & EV_EXIT) {
+        const double r = brent_root([&](double tt) { return g_r(tt, A.r_exit); }, t, t_new);
+        if (r < best) {
+            best = r;
             fl = BHG_FLAG_EXITED_SPHERE_;
-        } else {
-            tm = rz;
+        }
+    }
+    if (kind & EV_DISK) {
+        const double r = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
+        double xe[3];
+        pos(r, xe);
+        const double R = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+        if (R >= A.disk_r_in && R <= A.disk_r_out && r < best) {
+            best = r;
             fl = BHG_FLAG_HIT_DISK_;
         }
-        if (tm == INF) break;
-        double xe[3], ve[3];
-        eval(tm, xe, ve);
-        if (fl == BHG_FLAG_HIT_DISK_) {
-            const double R = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
-            if (!(R >= A.disk_r_in && R <= A.disk_r_out)) {
-                rz = INF;  // crossed the plane outside the annulus: look at what comes later in the step
-                continue;
+    }
+    if (kind & EV_OBJ) {
+        for (int j = 0; j < A.n_spheres; j++) {
+            const double *sp = A.spheres[j];
+            double bb, cc;
+            bool inside;
+            if (!sphere_candidate(sp, x0, x1, bb, cc, inside)) continue;
+            auto g_s = [&](double tt) {
+                double xe[3];
+                pos(tt, xe);
+                const double dx = xe[0] - sp[0], dy = xe[1] - sp[1], dz = xe[2] - sp[2];
+                return sqrt(dx * dx + dy * dy + dz * dz) - sp[3];
+            };
+            double hi = t_new;
+            if (!inside) {
+                hi = t + (bb / cc) * (t_new - t);
+                if (!(g_s(hi) < 0.0)) continue;  // the curve itself stays outside there: no hit
+            }
+            const double r = brent_root(g_s, t, hi);
+            if (r < best) {
+                best = r;
+                fl = BHG_FLAG_HIT_OBJECT_;
+                obj = j;
             }
         }
-        store_event_result(A, idx, xe, ve, fl);
-        return true;
     }
-    return false;
+    if (!fl) return false;
+    double xe[3], ve[3];
+    eval(best, xe, ve);
+    store_event_result(A, idx, xe, ve, fl);
+    if (obj >= 0 && A.object_id) A.object_id[idx] = (int8_t)obj;
+    return true;
 }
 
 // The step held no terminal event after all: the ray is final if the step reached lambda_end
@@ -872,8 +940,8 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
         }
     }
     const bool ended = settle_events(
-        A, kind, idx, t, t_new, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
-        [&](double tt) { return dense_z(d, tt); },
+        A, kind, idx, t, t_new, x, xn, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
+        [&](double tt) { return dense_z(d, tt); }, [&](double tt, double xe[3]) { dense_pos(d, tt, xe); },
         [&](double tt, double xe[3], double ve[3]) {
             dense_pos(d, tt, xe);
             dense_dir(d, tt, ve);
@@ -959,11 +1027,15 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
         d.a0[c] = a1[c];
     }
     const bool ended = settle_events(
-        A, kind, idx, t, t_new, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
+        A, kind, idx, t, t_new, x, d.x1, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
             double xx[3], vv[3];
             hermite_eval(d, tt, xx, vv);
             return xx[2];
+        },
+        [&](double tt, double xe[3]) {
+            double vv[3];
+            hermite_eval(d, tt, xe, vv);
         },
         [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); });
     if (!ended) finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
@@ -990,7 +1062,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
     w[3] = t_new;
     w[4] = h;
     w[5] = L.h_abs;
-    A.flags[L.idx] = (uint8_t)(EV_PENDING | kind);
+    A.flags[L.idx] = (uint8_t)(EV_TAG | (kind << 2));
     if (A.n_steps) A.n_steps[L.idx] = L.n_att;
     if (A.n_accepted) A.n_accepted[L.idx] = L.n_acc;
 }
@@ -1105,11 +1177,14 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                     const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                    const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
+                                      (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                            ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
-                    if (ev_h || ev_e || ev_d) {
+                    const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+                    if (ev_h || ev_e || ev_d || ev_o) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
-                        park_event(A, L, h, t_new, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
+                        park_event(A, L, h, t_new,
+                                   (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u));
                         L.active = false;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
@@ -1202,12 +1277,15 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
+                const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
+                                      (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                        ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
-                if (ev_h || ev_e || ev_d) {
+                const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+                if (ev_h || ev_e || ev_d || ev_o) {
                     L.n_acc = L.n_att;
                     L.h_abs = hf;
-                    park_event(A, L, h, t_new, (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u));
+                    park_event(A, L, h, t_new,
+                               (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u));
                     L.active = false;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1252,6 +1330,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         px[2] = A.x0s[2];
     }
     double *w = A.ws + i * (uint64_t)A.ws_stride;
+    if (A.object_id) A.object_id[i] = (int8_t)-1;
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
@@ -1376,7 +1455,8 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
     if (j >= A.n_items) return;
     const uint64_t i = A.worklist ? A.worklist[j] : j;
     const uint32_t fl = A.flags[i];
-    if ((fl & 0xC0u) != EV_PENDING || (fl & 7u) == 0u) return;
+    const uint32_t kind = pending_kind(fl);
+    if (kind == 0u) return;
     const double *e = A.end + i * 6;
     const double *w = A.ws + i * (uint64_t)A.ws_stride;
     double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
@@ -1392,9 +1472,9 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
         met.L = w[7];
     }
     if (ADAPTIVE)
-        dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, fl & 7u, (uint32_t)i, met);
+        dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, (uint32_t)i, met);
     else
-        rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, fl & 7u, (uint32_t)i, met);
+        rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, (uint32_t)i, met);
 }
 
 // Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into
@@ -1678,7 +1758,8 @@ static hipError_t launch_rhs(const TraceArgs &a, int method, int evt, int grid, 
     case 0: return launch_variant<RHS, 0>(a, method, grid, s, ev);
     case 1: return launch_variant<RHS, 1>(a, method, grid, s, ev);
     case 2: return launch_variant<RHS, 2>(a, method, grid, s, ev);
-    default: return launch_variant<RHS, 3>(a, method, grid, s, ev);
+    case 3: return launch_variant<RHS, 3>(a, method, grid, s, ev);
+    default: return launch_variant<RHS, 7>(a, method, grid, s, ev);
     }
 }
 
@@ -1689,7 +1770,8 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
     case 0: return occupancy_variant<RHS, 0>(method, blocks_per_cu);
     case 1: return occupancy_variant<RHS, 1>(method, blocks_per_cu);
     case 2: return occupancy_variant<RHS, 2>(method, blocks_per_cu);
-    default: return occupancy_variant<RHS, 3>(method, blocks_per_cu);
+    case 3: return occupancy_variant<RHS, 3>(method, blocks_per_cu);
+    default: return occupancy_variant<RHS, 7>(method, blocks_per_cu);
     }
 }
 

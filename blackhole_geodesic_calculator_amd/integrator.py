@@ -59,30 +59,42 @@ class GeodesicIntegratorSchwarzschild:
                                 disk_r_out=disk[1] if disk else 0.0, spin=self.spin)
 
     # ------------------------------------------------------------------------------------
-    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None):
+    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None, spheres=None):
         """Batched solve.  k0[N,3] (or [...,3]); x0[3] shared origin or same leading shape as k0.
         r_exit: outward sphere-exit radius (Limited engine's ray_trace, Limited...py:273-278);
         disk=(R_in, R_out): thin disk in z = 0, first crossing inside the annulus ends the ray with
         FLAG_HIT_DISK and the crossing point in ray_end (checkHitDisk, Limited...py:413-438).
+        spheres=[[cx, cy, cz, radius], ...] (at most 8, BH-centred): objects inside the curved region; a ray
+        entering one ends there with FLAG_HIT_OBJECT and object_id = its index -- the collision test the
+        reference leaves as a stub ("hit = False", RelativisticRenderEngine.py:304-305).
 
         Returns dict with
             ray_end[..., 6]            position (0:3) and direction (3:6) at the end of each curve
             ray_blackhole_hit[...]     uint8, 1 where the ray ended on the horizon
             flags[...], n_steps[...], n_accepted[...]
+            object_id[...]             int8, only with spheres: index of the sphere hit, else -1
         """
         k0 = np.asarray(k0, dtype=np.float64)
         lead = k0.shape[:-1]
         k0f = k0.reshape(-1, 3)
         x0 = np.asarray(x0, dtype=np.float64)
         x0f = x0 if x0.ndim == 1 else x0.reshape(-1, 3)
-        end, flags, steps, acc = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit, disk))
-        return {
+        obj = None
+        if spheres is not None:
+            end, flags, steps, acc, obj = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit, disk),
+                                                          spheres=spheres)
+        else:
+            end, flags, steps, acc = self._ctx.trace(k0f, x0f, self.params(max_step, curve_end, r_exit, disk))
+        out = {
             "ray_end": end.reshape(lead + (6,)),
             "ray_blackhole_hit": ((flags & _ffi.FLAG_HIT_HORIZON) != 0).astype(np.uint8).reshape(lead),
             "flags": flags.reshape(lead),
             "n_steps": steps.reshape(lead),
             "n_accepted": acc.reshape(lead),
         }
+        if obj is not None:
+            out["object_id"] = obj.reshape(lead)
+        return out
 
     # ------------------------------------------------------------------------------------
     def calc_trajectory(self, k0_xyz, x0_xyz, max_step=np.inf, curve_end=50, nr_points_curve=50,

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 2
+#define BHG_ABI_VERSION 3
 
 /* return codes */
 #define BHG_OK 0
@@ -64,6 +64,11 @@ extern "C" {
 #define BHG_FLAG_STEP_TOO_SMALL 32u /* scipy's failure mode (rk.py:132-133) */
 #define BHG_FLAG_NAN 64u            /* non-finite end state */
 #define BHG_FLAG_HIT_DISK 128u      /* crossed z = 0 inside the annulus (LimitedRelativisticRenderEngine.py:413-438) */
+#define BHG_FLAG_HIT_OBJECT 0x88u   /* ended on an object sphere (bhg_trace_objects*): the reference's collision stub
+                                     * "NOW YOU DO COLLISION DETECTION", hit = False (RelativisticRenderEngine.py:304-305).
+                                     * A composite value (EXITED_SPHERE | HIT_DISK never occur together otherwise):
+                                     * test with (flags & 0x88) == 0x88 */
+#define BHG_MAX_SPHERES 8
 
 /* integrators */
 #define BHG_METHOD_DP54 0 /* Dormand-Prince 5(4) with scipy RK45's controller (README.md:196) */
@@ -141,6 +146,25 @@ int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int 
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
+
+/* Objects inside the curved region (the reference holds only the stub at
+ * RelativisticRenderEngine.py:304-305, "hit = False", and README.md:225 lists it as a goal): up to
+ * BHG_MAX_SPHERES spheres, HOST array spheres [n_spheres][4] = {cx, cy, cz, radius} in BH-centred
+ * coordinates.  A ray that is outside sphere j at the start of an accepted step and either ends the
+ * step inside it, or whose chord between the step ends passes through it while the step's dense output
+ * at the chord's closest point lies inside, enters the sphere in that step; the entry point is the root
+ * of |x(lambda) - c_j| - radius_j on the dense output (Brent, like every other event).  Of all terminal
+ * events of a step the earliest wins.  Such rays end with BHG_FLAG_HIT_OBJECT, end = entry point and
+ * direction there, object_id = j; all other rays get object_id -1.  object_id may be NULL.  Not
+ * available with BHG_RHS_KERR_BL.  Like the disk, these calls loop over resume passes and synchronise.
+ * With n_spheres = 0 they are bhg_trace / bhg_trace_device. */
+int bhg_trace_objects(bhg_context *ctx, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                      const double *x0, int x0_is_shared, const double *k0, size_t n, double *end,
+                      uint8_t *flags, uint32_t *n_steps, uint32_t *n_accepted, int8_t *object_id);
+int bhg_trace_objects_device(bhg_context *ctx, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                             const double *x0_shared, const double *d_x0, const double *d_k0, size_t n,
+                             double *d_end, uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted,
+                             int8_t *d_object_id, void *stream);
 
 /* --- the stages either side of the solve, on device ---------------------------------------- */
 /* Camera rays with the reference's multisample jitter (RelativisticRenderEngine.py:185-188,

@@ -55,6 +55,8 @@ void bhgo_set_debug(int v) { bhgo_debug = v; }
 #define BHGO_FLAG_STEP_TOO_SMALL 32u
 #define BHGO_FLAG_NAN 64u
 #define BHGO_FLAG_HIT_DISK 128u
+#define BHGO_FLAG_HIT_OBJECT 0x88u /* composite of EXITED_SPHERE | HIT_DISK, which cannot co-occur otherwise */
+#define BHGO_MAX_SPHERES 8
 
 #define BHGO_METHOD_DP54 0
 #define BHGO_METHOD_RK4 1
@@ -78,6 +80,15 @@ typedef struct {
     double disk_r_in;  /* thin disk in the plane z = 0: annulus R_in <= R <= R_out; off when R_out <= 0 */
     double disk_r_out; /* (LimitedRelativisticRenderEngine.py:283-286, :413-438) */
     double spin;       /* Kerr a (length units, |a| < M = r_s/2); used by BHGO_RHS_KERR_BL only */
+    /* objects inside the curved region: spheres {cx, cy, cz, radius} in BH-centred coordinates.  The
+       reference only holds a stub for this ("NOW YOU DO COLLISION DETECTION", hit = False,
+       RelativisticRenderEngine.py:304-305; README.md:225 lists it as done elsewhere); the build's rule:
+       a ray that is outside sphere j at the start of an accepted step and either ends the step inside it or
+       whose chord passes through it enters the sphere in that step; the entry point is the first root of
+       |x(t) - c_j| - rho_j on the step's dense output, and the earliest terminal event of the step wins */
+    int32_t n_spheres;
+    int32_t reserved2;
+    double spheres[BHGO_MAX_SPHERES][4];
 } bhgo_params;
 
 /* per-ray context: Schwarzschild-Cartesian rays need none of it; Kerr rays are integrated in
@@ -332,8 +343,9 @@ typedef struct {
     const dense_t *dn;
     const hermite_t *hm;
     double R;
-    int zmode; /* 0: g = r - R; 1: g = z (disk plane) */
+    int zmode; /* 0: g = r - R; 1: g = z (disk plane); 2: g = |x - c| - R (object sphere) */
     const rayctx *rc;
+    double c[3];
 } evfun_t;
 
 static double ev_eval(const evfun_t *e, double t)
@@ -343,7 +355,11 @@ static double ev_eval(const evfun_t *e, double t)
         dense_eval(e->dn, t, y);
     else
         hermite_eval(e->hm, t, y);
-    if (e->zmode) return y[5];
+    if (e->zmode == 1) return y[5];
+    if (e->zmode == 2) {
+        double dx = y[1] - e->c[0], dy = y[3] - e->c[1], dz = y[5] - e->c[2];
+        return sqrt(dx * dx + dy * dy + dz * dz) - e->R;
+    }
     return radius(e->rc, y) - e->R;
 }
 
@@ -416,71 +432,83 @@ static void pack_end(const double y[6], double end[6])
     end[5] = y[4];
 }
 
-/* Events after an accepted step (ivp.py:109-126, :673-694).  Horizon and sphere exit are terminal;
-   the disk-plane crossing g = z is terminal only when the crossing point lies in the annulus
-   (LimitedRelativisticRenderEngine.py:423-424), otherwise the ray carries on.  Roots are visited
-   in time order (handle_events sorts them, ivp.py:111-122); the first terminal one wins.
-   Returns 0 = carry on, else the flag bit; *t_root and y_root filled. */
+/* Events after an accepted step (ivp.py:109-126, :673-694).  Horizon, sphere exit and object spheres
+   are terminal; the disk-plane crossing g = z is terminal only when the crossing point lies in the annulus
+   (LimitedRelativisticRenderEngine.py:423-424), otherwise the ray carries on.  Of the terminal candidates
+   the earliest root wins (handle_events sorts the roots, ivp.py:111-122); ties keep the order horizon,
+   exit, disk, sphere 0, 1, ...  Returns 0 = carry on, else the flag; *t_root, y_root, *obj filled. */
 static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, double g_e,
-                             double g_e_new, double z_old, double z_new, const evfun_t *base,
-                             double t_old, double t, double *t_root, double y_root[6])
+                             double g_e_new, const double y_old[6], const double y_new[6], const evfun_t *base,
+                             double t_old, double t, double *t_root, double y_root[6], int *obj)
 {
+    const double z_old = y_old[5], z_new = y_new[5];
     int hor = ((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0));
     int ext = (p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0); /* direction = +1 */
     int dsk = (p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0)));
-    if (!hor && !ext && !dsk) return 0;
-    double root[3];
-    uint32_t flag[3];
-    int n = 0;
+    double best = INFINITY;
+    uint32_t best_flag = 0;
+    int best_obj = -1;
     evfun_t e = *base;
     if (hor) {
         e.R = e.rc->r_hor;
         e.zmode = 0;
-        root[n] = brentq(&e, t_old, t);
-        flag[n++] = BHGO_FLAG_HIT_HORIZON;
+        double r = brentq(&e, t_old, t);
+        if (r < best) { best = r; best_flag = BHGO_FLAG_HIT_HORIZON; }
     }
     if (ext) {
         e.R = p->r_exit;
         e.zmode = 0;
-        root[n] = brentq(&e, t_old, t);
-        flag[n++] = BHGO_FLAG_EXITED_SPHERE;
+        double r = brentq(&e, t_old, t);
+        if (r < best) { best = r; best_flag = BHGO_FLAG_EXITED_SPHERE; }
     }
     if (dsk) {
         e.zmode = 1;
-        root[n] = brentq(&e, t_old, t);
-        flag[n++] = BHGO_FLAG_HIT_DISK;
-    }
-    /* stable insertion sort by root time (ties keep the order horizon, exit, disk) */
-    for (int i = 1; i < n; i++)
-        for (int j = i; j > 0 && root[j] < root[j - 1]; j--) {
-            double tr = root[j];
-            root[j] = root[j - 1];
-            root[j - 1] = tr;
-            uint32_t tf = flag[j];
-            flag[j] = flag[j - 1];
-            flag[j - 1] = tf;
-        }
-    for (int i = 0; i < n; i++) {
+        double r = brentq(&e, t_old, t);
         double y[6];
-        if (e.kind == 0)
-            dense_eval(e.dn, root[i], y);
-        else
-            hermite_eval(e.hm, root[i], y);
-        if (flag[i] == BHGO_FLAG_HIT_DISK) {
-            double R = sqrt(y[1] * y[1] + y[3] * y[3]);
-            if (!(R >= p->disk_r_in && R <= p->disk_r_out)) continue; /* crossed outside the annulus */
-        }
-        *t_root = root[i];
-        memcpy(y_root, y, sizeof(double) * 6);
-        return flag[i];
+        if (e.kind == 0) dense_eval(e.dn, r, y); else hermite_eval(e.hm, r, y);
+        double R = sqrt(y[1] * y[1] + y[3] * y[3]);
+        if (R >= p->disk_r_in && R <= p->disk_r_out && r < best) { best = r; best_flag = BHGO_FLAG_HIT_DISK; }
     }
-    return 0;
+    for (int j = 0; j < p->n_spheres && !e.rc->kerr; j++) {
+        const double *sp = p->spheres[j];
+        const double rho2 = sp[3] * sp[3];
+        double a0[3] = {y_old[1] - sp[0], y_old[3] - sp[1], y_old[5] - sp[2]};
+        double a1[3] = {y_new[1] - sp[0], y_new[3] - sp[1], y_new[5] - sp[2]};
+        double d0 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]; /* squared distances: no root needed to decide */
+        double d1 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+        if (!(d0 > rho2)) continue; /* started inside (or on) this sphere: not an entry */
+        double hi = t;
+        if (!(d1 <= rho2)) {
+            /* both ends outside: does the chord pass through?  closest point of the chord to the centre at
+               s* = b / cc in (0, 1), its squared distance d0 - b^2 / cc < rho^2 (written without the division) */
+            double ch[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
+            double cc = ch[0] * ch[0] + ch[1] * ch[1] + ch[2] * ch[2];
+            double bb = -(a0[0] * ch[0] + a0[1] * ch[1] + a0[2] * ch[2]);
+            if (!(bb > 0 && bb < cc && (d0 - rho2) * cc < bb * bb)) continue;
+            hi = t_old + (bb / cc) * (t - t_old);
+            e.zmode = 2;
+            e.R = sp[3];
+            memcpy(e.c, sp, sizeof(double) * 3);
+            if (!(ev_eval(&e, hi) < 0)) continue; /* the curve itself stays outside there: no hit */
+        }
+        e.zmode = 2;
+        e.R = sp[3];
+        memcpy(e.c, sp, sizeof(double) * 3);
+        double r = brentq(&e, t_old, hi);
+        if (r < best) { best = r; best_flag = BHGO_FLAG_HIT_OBJECT; best_obj = j; }
+    }
+    if (!best_flag) return 0;
+    *t_root = best;
+    if (e.kind == 0) dense_eval(e.dn, best, y_root); else hermite_eval(e.hm, best, y_root);
+    if (obj) *obj = best_obj;
+    return best_flag;
 }
 
 typedef struct {
     double end[6];
     double t_end;
     uint32_t flags, n_attempted, n_accepted, nfev;
+    int object_id; /* sphere index for BHGO_FLAG_HIT_OBJECT, else -1 */
 } ray_result;
 
 /* optional trajectory sampler: t_eval = linspace(0, lambda_end, T) like the engine's
@@ -521,6 +549,7 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
     const double t_bound = p->lambda_end;
     double t = 0.0;
     memset(res, 0, sizeof(*res));
+    res->object_id = -1;
     rhs(p, rc, y, f);
     res->nfev = 1;
     double h_abs = select_initial_step(p, rc, y, f, t, t_bound, &res->nfev);
@@ -603,14 +632,15 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
         double g_e_new = radius(rc, y) - p->r_exit;
         double z_old = y_old[5], z_new = y[5];
         dense_t dn;
-        evfun_t base = {0, &dn, NULL, 0.0, 0, rc};
+        evfun_t base = {0, &dn, NULL, 0.0, 0, rc, {0, 0, 0}};
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
                   ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0)) ||
-                  ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0))));
+                  ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0)))) ||
+                  (p->n_spheres > 0 && !rc->kerr);
         if (any || sm) dense_build(&dn, t_old, t, y_old, K);
         if (any) {
             double t_root, y_root[6];
-            uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, z_old, z_new, &base, t_old, t, &t_root, y_root);
+            uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, y_old, y, &base, t_old, t, &t_root, y_root, &res->object_id);
             if (fl) {
                 res->flags |= fl;
                 t = t_root;
@@ -644,6 +674,7 @@ static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3]
     const double t_bound = p->lambda_end;
     double t = 0.0;
     memset(res, 0, sizeof(*res));
+    res->object_id = -1;
     rhs(p, rc, y, f);
     res->nfev = 1;
     double g_h = radius(rc, y) - rc->r_hor;
@@ -687,9 +718,9 @@ static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3]
         memcpy(f, f_new, sizeof(f));
         double g_h_new = radius(rc, y) - rc->r_hor;
         double g_e_new = radius(rc, y) - p->r_exit;
-        evfun_t base = {1, NULL, &hm, 0.0, 0, rc};
+        evfun_t base = {1, NULL, &hm, 0.0, 0, rc, {0, 0, 0}};
         double t_root, y_root[6];
-        uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, hm.y0[5], hm.y1[5], &base, t_old, t, &t_root, y_root);
+        uint32_t fl = check_events(p, g_h, g_h_new, g_e, g_e_new, hm.y0, hm.y1, &base, t_old, t, &t_root, y_root, &res->object_id);
         if (fl) {
             res->flags |= fl;
             t = t_root;
@@ -866,6 +897,32 @@ int bhgo_trace(const bhgo_params *p, const double *x0, int x0_shared, const doub
         if (n_attempted) n_attempted[i] = r.n_attempted;
         if (n_accepted) n_accepted[i] = r.n_accepted;
         if (t_end) t_end[i] = r.t_end;
+    }
+    return 0;
+}
+
+/* same as bhgo_trace, plus the sphere index of rays that ended on an object (-1 otherwise) */
+int bhgo_trace_objects(const bhgo_params *p, const double *x0, int x0_shared, const double *k0, size_t n,
+                       double *end, uint8_t *flags, uint32_t *n_attempted, uint32_t *n_accepted, int8_t *object_id,
+                       int n_threads)
+{
+    if (!p || !x0 || !k0 || !end) return -1;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    long long nn = (long long)n;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads)
+    for (long long i = 0; i < nn; i++) {
+        ray_result r;
+        r.object_id = -1;
+        trace_one(p, x0_shared ? x0 : x0 + 3 * i, k0 + 3 * i, &r, NULL);
+        memcpy(end + 6 * i, r.end, sizeof(double) * 6);
+        if (flags) flags[i] = (uint8_t)r.flags;
+        if (n_attempted) n_attempted[i] = r.n_attempted;
+        if (n_accepted) n_accepted[i] = r.n_accepted;
+        if (object_id) object_id[i] = (r.flags == BHGO_FLAG_HIT_OBJECT) ? (int8_t)r.object_id : (int8_t)-1;
     }
     return 0;
 }

@@ -23,6 +23,8 @@ FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
 FLAG_HIT_DISK = 128
+FLAG_HIT_OBJECT = 0x88
+MAX_SPHERES = 8
 
 METHOD_DP54 = 0
 METHOD_RK4 = 1
@@ -48,14 +50,25 @@ class Params(C.Structure):
         ("disk_r_in", C.c_double),
         ("disk_r_out", C.c_double),
         ("spin", C.c_double),
+        ("n_spheres", C.c_int32),
+        ("reserved2", C.c_int32),
+        ("spheres", (C.c_double * 4) * 8),
     ]
 
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
                 r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
-                disk_r_out=0.0, spin=0.0):
-    return Params(r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, method, rhs_form,
-                  max_steps, 0, disk_r_in, disk_r_out, spin)
+                disk_r_out=0.0, spin=0.0, spheres=None):
+    p = Params(r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, method, rhs_form,
+               max_steps, 0, disk_r_in, disk_r_out, spin)
+    if spheres is not None:
+        sp = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+        assert len(sp) <= MAX_SPHERES
+        p.n_spheres = len(sp)
+        for j, row in enumerate(sp):
+            for c in range(4):
+                p.spheres[j][c] = float(row[c])
+    return p
 
 
 def build(force=False):
@@ -80,6 +93,9 @@ def lib():
                                  C.POINTER(C.c_uint32), dp, C.c_int]
         L.bhgo_acceleration.restype = C.c_int
         L.bhgo_acceleration.argtypes = [C.POINTER(Params), dp, dp, C.c_size_t, dp]
+        L.bhgo_trace_objects.restype = C.c_int
+        L.bhgo_trace_objects.argtypes = [C.POINTER(Params), dp, C.c_int, dp, C.c_size_t, dp, C.POINTER(C.c_uint8),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int8), C.c_int]
         L.bhgo_trajectory.restype = C.c_int
         L.bhgo_trajectory.argtypes = [C.POINTER(Params), dp, C.c_int, dp, C.c_size_t, C.c_uint32, dp,
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]
@@ -112,7 +128,18 @@ def trace(k0, x0, n_threads=0, **kw):
                           nacc.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(tend), n_threads)
     if rc != 0:
         raise RuntimeError(f"bhgo_trace failed: {rc}")
-    return {"end": end, "flags": flags, "n_attempted": natt, "n_accepted": nacc, "t_end": tend}
+    out = {"end": end, "flags": flags, "n_attempted": natt, "n_accepted": nacc, "t_end": tend}
+    if p.n_spheres > 0:
+        obj = np.empty(n, np.int8)
+        rc = lib().bhgo_trace_objects(C.byref(p), _dp(x0), shared, _dp(k0), n, _dp(end),
+                                      flags.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      natt.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      nacc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      obj.ctypes.data_as(C.POINTER(C.c_int8)), n_threads)
+        if rc != 0:
+            raise RuntimeError(f"bhgo_trace_objects failed: {rc}")
+        out["object_id"] = obj
+    return out
 
 
 def trajectory(k0, x0, n_points, **kw):

@@ -151,10 +151,11 @@ FLAG_MAX_STEPS = 16
 FLAG_STEP_TOO_SMALL = 32
 FLAG_NAN = 64
 FLAG_HIT_DISK = 128
+FLAG_HIT_OBJECT = 0x88
 
 
 def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
-              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None, disk=None):
+              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None, disk=None, spheres=None):
     """Integrate one null geodesic with scipy.solve_ivp; returns a dict.
 
     Events: horizon r - r_s = 0 (terminal, any direction); optional outward sphere exit
@@ -189,6 +190,24 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
             return y[5]
 
         events.append(ev_disk)
+    n_obj = 0
+    if spheres is not None:
+        # object spheres inside the curved region (the reference's collision stub,
+        # RelativisticRenderEngine.py:304-305): terminal events g_j = |x - c_j| - rho_j, entering only.
+        # scipy sees only sign changes between step ends; the C oracle's chord rule adds the
+        # pass-through-in-one-step case, so the two agree when max_step is small against rho_j.
+        # Inserted BEFORE the disk event so that the disk stays events[-1].
+        def make_ev(c, rho):
+            def ev(_t, y):
+                return np.sqrt((y[1] - c[0]) ** 2 + (y[3] - c[1]) ** 2 + (y[5] - c[2]) ** 2) - rho
+            ev.terminal = True
+            ev.direction = -1.0
+            return ev
+
+        obj_events = [make_ev(np.asarray(sp[:3], float), float(sp[3])) for sp in spheres]
+        n_obj = len(obj_events)
+        pos = len(events) - (1 if disk is not None else 0)
+        events[pos:pos] = obj_events
     t_eval = None
     if nr_points_curve:
         t_eval = np.linspace(0.0, lambda_end, nr_points_curve)
@@ -196,12 +215,20 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
                     max_step=max_step, rtol=rtol, atol=atol, t_eval=t_eval)
     flags = 0
     if sol.status == 1:
-        if len(sol.t_events[0]) > 0:
+        # the terminal event that stopped the solve is the one with the LAST root time recorded
+        # (ivp.py:680-690 truncates the roots at the first terminal one)
+        cands = [(sol.t_events[i][-1], i) for i in range(len(events) - (1 if disk is not None else 0))
+                 if len(sol.t_events[i]) > 0]
+        te, i_ev = min(cands)
+        ye = sol.y_events[i_ev][-1]
+        i_obj0 = 1 + (1 if r_exit > 0.0 else 0)
+        if i_ev == 0:
             flags |= FLAG_HIT_HORIZON
-            te, ye = sol.t_events[0][-1], sol.y_events[0][-1]
-        else:
+        elif i_ev < i_obj0:
             flags |= FLAG_EXITED_SPHERE
-            te, ye = sol.t_events[1][-1], sol.y_events[1][-1]
+        else:
+            flags |= FLAG_HIT_OBJECT
+            out["object_id"] = i_ev - i_obj0
     elif sol.status == 0:
         flags |= FLAG_REACHED_END
         te, ye = (sol.t[-1], sol.y[:, -1]) if t_eval is None else (lambda_end, None)

@@ -230,3 +230,60 @@ def test_default_tolerance_error_against_converged_solution(oracle):
     e3 = np.abs(oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-5, atol=1e-8)["end"] - conv["end"]).max()
     e5 = np.abs(oracle.trace(k, CAM, r_s=1.0, lambda_end=50.0, rtol=1e-7, atol=1e-10)["end"] - conv["end"]).max()
     assert 10 < e3 / e5 < 1000
+
+
+def test_oracle_objects_match_scipy_golden(oracle):
+    """Object spheres as scipy terminal events (tests/golden/make_golden.py main_objects) beside horizon,
+    exit sphere and disk; max_step is small, so scipy's sign-change detection sees every entry."""
+    g = load_golden("objects")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=70.0, max_step=0.25, r_exit=35.0, disk_r_in=3.0,
+                     disk_r_out=7.0, spheres=g["spheres"])
+    assert np.array_equal(o["flags"], g["flags"]) and np.array_equal(o["object_id"], g["object_id"])
+    assert np.array_equal(o["n_accepted"], g["n_accepted"])
+    nd = g["flags"] != oracle.FLAG_HIT_DISK
+    assert np.array_equal(o["n_attempted"][nd], g["n_attempted"][nd])
+    assert np.abs(o["end"] - g["end"]).max() < 1e-9 and np.abs(o["t_end"] - g["t_end"]).max() < 1e-10
+    kinds = set(int(f) for f in g["flags"])
+    assert {1, 8, 128, 0x88} <= kinds and len(set(g["object_id"][g["object_id"] >= 0])) >= 3
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_oracle_objects_flat_space_exact(oracle, method):
+    """r_s = 0: straight lines; DP5(4) steps are exact and long, so spheres are mostly passed through inside
+    one step (the chord rule); entry points are the closed-form ray-sphere intersections."""
+    rng = np.random.default_rng(0)
+    n = 4000
+    k = np.stack([rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n), -np.ones(n)], 1)
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    sph = [(1.0, 0.5, 10.0, 1.5), (-2.0, 1.0, 0.0, 2.0), (0.5, -3.0, -12.0, 1.0)]
+    o = oracle.trace(k, CAM, r_s=0.0, lambda_end=60.0, rhs_form=1, method=method, h_fixed=0.37, spheres=sph)
+    best = np.full(n, np.inf)
+    bid = np.full(n, -1)
+    for j, (cx, cy, cz, rho) in enumerate(sph):
+        oc = CAM - np.array([cx, cy, cz])
+        b = k @ oc
+        disc = b * b - (oc @ oc - rho * rho)
+        t = np.where(disc > 0, -b - np.sqrt(np.maximum(disc, 0)), np.inf)
+        upd = (t > 0) & (t < best)
+        best = np.where(upd, t, best)
+        bid = np.where(upd, j, bid)
+    hit = best < 60.0
+    assert hit.sum() > 300
+    assert np.array_equal(o["flags"] == oracle.FLAG_HIT_OBJECT, hit)
+    assert np.array_equal(o["object_id"], np.where(hit, bid, -1))
+    assert np.abs(o["end"][hit, 0:3] - (CAM + best[hit, None] * k[hit])).max() < 1e-11
+    if method == 0:
+        assert o["n_attempted"].max() <= 8   # a handful of steps each: the spheres lie INSIDE steps
+
+
+def test_oracle_objects_start_inside_sphere_and_ordering(oracle):
+    """A ray that starts inside a sphere leaves it without an event; of two overlapping spheres the one
+    entered first wins; a sphere behind the horizon is never reached."""
+    k = np.array([[0.0, 0.0, -1.0]])
+    x0 = np.array([0.0, 5.0, 20.0])
+    o = oracle.trace(k, x0, r_s=1.0, lambda_end=60.0, spheres=[(0.0, 5.0, 20.0, 2.0), (0.0, 5.0, 8.0, 1.0), (0.0, 5.0, 9.0, 1.5)])
+    assert o["flags"][0] == oracle.FLAG_HIT_OBJECT and o["object_id"][0] == 2
+    assert abs(np.linalg.norm(o["end"][0, 0:3] - np.array([0.0, 5.0, 9.0])) - 1.5) < 1e-9
+    # impact parameter 2 < 2.6 r_s: captured, whatever lies behind the hole
+    o = oracle.trace(k, np.array([2.0, 0.0, 20.0]), r_s=1.0, lambda_end=60.0, spheres=[(0.0, 0.0, -6.0, 2.0), (2.0, 0.0, -6.0, 1.0)])
+    assert o["flags"][0] == oracle.FLAG_HIT_HORIZON and o["object_id"][0] == -1
