@@ -43,8 +43,51 @@ EXPORTS = (
     "bhg_destroy", "bhg_device_name", "bhg_num_cus", "bhg_trace", "bhg_trace_device",
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
     "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
-    "bhg_trace_objects_device",
+    "bhg_trace_objects_device", "bhg_shade_scene_device",
 )
+
+
+class Scene(C.Structure):
+    """struct bhg_scene (include/bhgeo.h)."""
+    _fields_ = [
+        ("d_sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32),
+        ("d_disk_tex", C.c_void_p), ("disk_w", C.c_int32), ("disk_h", C.c_int32),
+        ("disk_r_in", C.c_double), ("disk_r_out", C.c_double),
+        ("disk_phase", C.c_double), ("disk_mean", C.c_double), ("disk_stddev", C.c_double),
+        ("disk_intensity", C.c_double),
+        ("n_spheres", C.c_int32), ("n_lamps", C.c_int32),
+        ("spheres", (C.c_double * 4) * 8),
+        ("sphere_rgb", (C.c_double * 3) * 8),
+        ("lamps", (C.c_double * 4) * 4),
+    ]
+
+
+def make_scene(d_sky, sky_w, sky_h, *, d_disk_tex=0, disk_w=0, disk_h=0, disk=None, disk_phase=0.0, disk_mean=0.2,
+               disk_stddev=0.3, disk_intensity=1.0, spheres=None, sphere_rgb=None, lamps=None):
+    """disk=(R_in, R_out); spheres [[cx, cy, cz, radius]]; sphere_rgb [[r, g, b]] (default white);
+    lamps [[x, y, z, intensity]].  Defaults of the disk profile: LimitedRelativisticRenderEngine.py:495-498."""
+    sc = Scene()
+    sc.d_sky, sc.sky_w, sc.sky_h = d_sky or None, int(sky_w), int(sky_h)
+    sc.d_disk_tex, sc.disk_w, sc.disk_h = d_disk_tex or None, int(disk_w), int(disk_h)
+    if disk is not None:
+        sc.disk_r_in, sc.disk_r_out = float(disk[0]), float(disk[1])
+    sc.disk_phase, sc.disk_mean, sc.disk_stddev, sc.disk_intensity = (float(disk_phase), float(disk_mean),
+                                                                        float(disk_stddev), float(disk_intensity))
+    sp = _spheres_array(spheres if spheres is not None else [])
+    rgb = np.ones((len(sp), 3)) if sphere_rgb is None else np.asarray(sphere_rgb, dtype=np.float64).reshape(-1, 3)
+    lm = np.zeros((0, 4)) if lamps is None else np.asarray(lamps, dtype=np.float64).reshape(-1, 4)
+    if len(sp) > MAX_SPHERES or len(lm) > 4 or len(rgb) != len(sp):
+        raise ValueError("at most 8 spheres (one colour each) and 4 lamps")
+    sc.n_spheres, sc.n_lamps = len(sp), len(lm)
+    for j in range(len(sp)):
+        for q in range(4):
+            sc.spheres[j][q] = float(sp[j, q])
+        for q in range(3):
+            sc.sphere_rgb[j][q] = float(rgb[j, q])
+    for j in range(len(lm)):
+        for q in range(4):
+            sc.lamps[j][q] = float(lm[j, q])
+    return sc
 
 
 def _spheres_array(spheres):
@@ -130,6 +173,9 @@ def load():
     L.bhg_trace_objects_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int32, _dp, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
+    L.bhg_shade_scene_device.restype = C.c_int
+    L.bhg_shade_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
+                                         C.POINTER(Scene), C.c_void_p, C.c_void_p]
     L.bhg_raygen_device.restype = C.c_int
     L.bhg_raygen_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -317,6 +363,11 @@ class Context:
         _check(load().bhg_shade_device(self._h, C.c_void_p(d_end), C.c_void_p(d_flags), int(n_pixels), int(samples),
                                        C.c_void_p(d_sky), int(sky_w), int(sky_h), C.c_void_p(d_rgba),
                                        C.c_void_p(stream or None)))
+
+    def shade_scene_device(self, d_end, d_flags, n_pixels, samples, scene: "Scene", d_rgba, d_object_id=0, stream=0):
+        _check(load().bhg_shade_scene_device(self._h, C.c_void_p(d_end), C.c_void_p(d_flags),
+                                             C.c_void_p(d_object_id or None), int(n_pixels), int(samples),
+                                             C.byref(scene), C.c_void_p(d_rgba), C.c_void_p(stream or None)))
 
     def acceleration(self, x, k, params: Params):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)

@@ -545,6 +545,54 @@ int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags
     return BHG_OK;
 }
 
+int bhg_shade_scene_device(bhg_context *c, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
+                           size_t n_pixels, int32_t samples, const bhg_scene *sc, double *d_rgba, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    if (!sc) return fail(BHG_E_INVALID, "scene is NULL");
+    if (samples <= 0 || sc->sky_w <= 0 || sc->sky_h <= 0) return fail(BHG_E_INVALID, "samples, sky_w, sky_h must be > 0");
+    if (sc->n_spheres < 0 || sc->n_spheres > BHG_MAX_SPHERES || sc->n_lamps < 0 || sc->n_lamps > 4)
+        return fail(BHG_E_INVALID, "n_spheres must be in [0, BHG_MAX_SPHERES], n_lamps in [0, 4]");
+    if (sc->n_spheres > 0 && !d_object_id) return fail(BHG_E_INVALID, "object_id is NULL but the scene has spheres");
+    if (sc->disk_r_out > 0.0) {
+        if (!(sc->disk_r_out > sc->disk_r_in) || !(sc->disk_stddev > 0.0))
+            return fail(BHG_E_INVALID, "disk needs r_out > r_in and stddev > 0");
+        if (sc->d_disk_tex && (sc->disk_w <= 0 || sc->disk_h <= 0)) return fail(BHG_E_INVALID, "disk texture size must be > 0");
+    }
+    for (int j = 0; j < sc->n_spheres; j++)
+        if (!(sc->spheres[j][3] > 0.0)) return fail(BHG_E_INVALID, "sphere radii must be > 0");
+    if (n_pixels == 0) return BHG_OK;
+    if (!d_end || !d_flags || !sc->d_sky || !d_rgba) return fail(BHG_E_INVALID, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    bhg::ShadeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.end = d_end;
+    a.flags = d_flags;
+    a.sky = sc->d_sky;
+    a.rgba = d_rgba;
+    a.n_pixels = n_pixels;
+    a.samples = samples;
+    a.sky_w = sc->sky_w;
+    a.sky_h = sc->sky_h;
+    a.object_id = sc->n_spheres > 0 ? d_object_id : nullptr;
+    a.disk_tex = sc->d_disk_tex;
+    a.disk_w = sc->disk_w;
+    a.disk_h = sc->disk_h;
+    a.disk_r_in = sc->disk_r_in;
+    a.disk_r_out = sc->disk_r_out;
+    a.disk_phase = sc->disk_phase;
+    a.disk_mean = sc->disk_mean;
+    a.disk_stddev = sc->disk_stddev;
+    a.disk_intensity = sc->disk_intensity;
+    a.n_spheres = sc->n_spheres;
+    a.n_lamps = sc->n_lamps;
+    std::memcpy(a.spheres, sc->spheres, sizeof(a.spheres));
+    std::memcpy(a.sphere_rgb, sc->sphere_rgb, sizeof(a.sphere_rgb));
+    std::memcpy(a.lamps, sc->lamps, sizeof(a.lamps));
+    HIP_TRY(bhg::launch_shade(a, (hipStream_t)stream));
+    return BHG_OK;
+}
+
 int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0, size_t n,
                    uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags)
 {

@@ -3,7 +3,9 @@
 //     (raytracer/RelativisticRenderEngine.py:185-188, :224-230), from a device-resident MT19937
 //     jitter stream (produced once on the host from Python's own seeded state, bit-identical);
 //   * escaping-ray shading against an equirectangular sky (background_hit, :366-378) and the
-//     per-pixel multisample mean (sbuf += colour; buf = sbuf/(s+1), :242-250).
+//     per-pixel multisample mean (sbuf += colour; buf = sbuf/(s+1), :242-250); rays that ended on the
+//     thin disk get the Limited engine's disk colour (LimitedRelativisticRenderEngine.py:427-436, :300),
+//     rays that ended on an object sphere the Lambert lamp sum of spacetime_hit (:356-363).
 // Both are HBM-bound element-wise kernels: coalesced loads/stores, no LDS needed -- the S
 // samples of a pixel are accumulated in registers in sample order (the reference's order), so
 // the result is deterministic; there is no cross-lane reduction to stage.
@@ -78,6 +80,68 @@ __device__ __forceinline__ void sky_lookup(const float *sky, int TW, int TH, dou
     rgb[2] = w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z;
 }
 
+// Disk colour (LimitedRelativisticRenderEngine.py:427-436, :300): texture(texture_x, scale) * intensity with a
+// Gaussian radial profile.  (y_disk / |y_disk| is NaN at y = 0 there; here the sign of +0 is +.)
+__device__ __forceinline__ void disk_colour(const ShadeArgs &A, const double *e, double rgb[3])
+{
+    const double x = e[0], y = e[1];
+    const double R = sqrt(x * x + y * y);
+    const double scale = (R - A.disk_r_in) / (A.disk_r_out - A.disk_r_in);
+    const double dm = scale - A.disk_mean;
+    const double intensity = A.disk_intensity * exp(-(dm * dm) / (2.0 * A.disk_stddev * A.disk_stddev)) /
+                             sqrt(2.0 * M_PI * A.disk_stddev);
+    double cx = x / R;
+    cx = cx > 1.0 ? 1.0 : (cx < -1.0 ? -1.0 : cx);
+    const double texture_x = (A.disk_phase + acos(cx) * (y < 0.0 ? -1.0 : 1.0)) / M_PI;
+    if (A.disk_tex)
+        sky_lookup(A.disk_tex, A.disk_w, A.disk_h, texture_x, scale, rgb);
+    else
+        rgb[0] = rgb[1] = rgb[2] = 1.0;
+    rgb[0] *= intensity;
+    rgb[1] *= intensity;
+    rgb[2] *= intensity;
+}
+
+// Object colour: pure Lambert sum over point lamps with 1/d^2 falloff, light paths straight (flat space) as in
+// spacetime_hit (RelativisticRenderEngine.py:341-363: base_color = intensity, colour += base_color * intensity *
+// n.l / d^2 unless a shadow ray from loc + eps * l hits something -- here: one of the other spheres).  n.l is
+// clamped at 0 (the reference adds negative light on the far side; "This needs some serius work", :320).
+__device__ __forceinline__ void object_colour(const ShadeArgs &A, const double *e, int j, double rgb[3])
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    if (j < 0 || j >= A.n_spheres) return;
+    const double *sp = A.spheres[j];
+    const double inv_rho = 1.0 / sp[3];
+    const double n[3] = {(e[0] - sp[0]) * inv_rho, (e[1] - sp[1]) * inv_rho, (e[2] - sp[2]) * inv_rho};
+    double sum = 0.0;
+    for (int l = 0; l < A.n_lamps; l++) {
+        const double lv[3] = {A.lamps[l][0] - e[0], A.lamps[l][1] - e[1], A.lamps[l][2] - e[2]};
+        const double d2 = lv[0] * lv[0] + lv[1] * lv[1] + lv[2] * lv[2];
+        const double dist = sqrt(d2);
+        const double ld[3] = {lv[0] / dist, lv[1] / dist, lv[2] / dist};
+        const double ndl = n[0] * ld[0] + n[1] * ld[1] + n[2] * ld[2];
+        if (!(ndl > 0.0)) continue;
+        bool shadow = false;
+        for (int q = 0; q < A.n_spheres; q++) {
+            if (q == j) continue;
+            const double *sq = A.spheres[q];
+            const double oc[3] = {e[0] - sq[0], e[1] - sq[1], e[2] - sq[2]};
+            const double b = oc[0] * ld[0] + oc[1] * ld[1] + oc[2] * ld[2];
+            const double cq = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - sq[3] * sq[3];
+            const double disc = b * b - cq;
+            if (disc > 0.0) {
+                const double sd = sqrt(disc);
+                const double t0 = -b - sd, t1 = -b + sd;
+                if ((t0 > 1e-5 && t0 < dist) || (t0 <= 1e-5 && t1 > 1e-5)) shadow = true;  // enters on the way, or starts inside
+            }
+        }
+        if (!shadow) sum += A.lamps[l][3] * A.lamps[l][3] * ndl / d2;
+    }
+    rgb[0] = A.sphere_rgb[j][0] * sum;
+    rgb[1] = A.sphere_rgb[j][1] * sum;
+    rgb[2] = A.sphere_rgb[j][2] * sum;
+}
+
 // One thread per pixel; samples accumulated in sample order (:242-250).  Rays are laid out
 // [S][P] so every load is coalesced across the pixels of a wavefront.
 __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
@@ -90,6 +154,22 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
         const uint8_t fl = A.flags[i];
         if (fl & BHG_FLAG_HIT_HORIZON_) continue;  // black (:242-244)
         const double *e = A.end + i * 6;
+        if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0) {
+            double rgb[3];
+            disk_colour(A, e, rgb);
+            acc[0] += rgb[0];
+            acc[1] += rgb[1];
+            acc[2] += rgb[2];
+            continue;
+        }
+        if (fl == BHG_FLAG_HIT_OBJECT_ && A.object_id) {
+            double rgb[3];
+            object_colour(A, e, (int)A.object_id[i], rgb);
+            acc[0] += rgb[0];
+            acc[1] += rgb[1];
+            acc[2] += rgb[2];
+            continue;
+        }
         double d0 = e[3], d1 = e[4], d2 = e[5];
         // exit directions are not unit vectors; normalise like the Cam edition (CamEdition.py:433-437)
         const double inv = 1.0 / sqrt(d0 * d0 + d1 * d1 + d2 * d2);

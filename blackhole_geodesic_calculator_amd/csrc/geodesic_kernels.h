@@ -72,6 +72,15 @@ struct ShadeArgs {
     double *rgba;          // [n_pixels][4]
     uint64_t n_pixels;
     int32_t samples, sky_w, sky_h;
+    // scene shading (bhg_shade_scene_device); all zero / null for the sky-only call
+    const int8_t *object_id;  // [S*n_pixels] or nullptr
+    const float *disk_tex;    // [disk_h][disk_w][4] RGBA float32 or nullptr (white)
+    int32_t disk_w, disk_h;
+    double disk_r_in, disk_r_out, disk_phase, disk_mean, disk_stddev, disk_intensity;
+    int32_t n_spheres, n_lamps;
+    double spheres[BHG_MAX_SPHERES_][4];
+    double sphere_rgb[BHG_MAX_SPHERES_][3];
+    double lamps[4][4];  // {x, y, z, intensity}
 };
 
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);

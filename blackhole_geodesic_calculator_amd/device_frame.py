@@ -50,6 +50,14 @@ class DeviceFrame:
         self.d_rgba = torch.empty((self.P, 4), dtype=torch.float64, device=self.dev)
         self.d_sky = None
         self.sky_wh = (0, 0)
+        # scene beyond the sky (set_disk / set_objects): thin disk, object spheres with lamps
+        self.disk = None
+        self.disk_profile = dict(disk_phase=0.0, disk_mean=0.2, disk_stddev=0.3, disk_intensity=1.0)
+        self.d_disk_tex = None
+        self.spheres = None
+        self.sphere_rgb = None
+        self.lamps = None
+        self.d_obj = None
 
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -61,6 +69,27 @@ class DeviceFrame:
         self.d_sky = torch.as_tensor(sky).to(self.dev)
         self.sky_wh = (sky.shape[1], sky.shape[0])
 
+    def set_disk(self, r_in, r_out, texture_rgba_f32=None, **profile):
+        """Thin disk in z = 0 between r_in and r_out (LimitedRelativisticRenderEngine.py:283-300, :413-438);
+        profile: disk_phase, disk_mean, disk_stddev, disk_intensity (:55-58).  The trace must be run with the
+        same radii in its params (make_params(disk_r_in=..., disk_r_out=...))."""
+        self.disk = (float(r_in), float(r_out))
+        self.disk_profile.update(profile)
+        if texture_rgba_f32 is not None:
+            tex = np.ascontiguousarray(texture_rgba_f32, dtype=np.float32)
+            assert tex.ndim == 3 and tex.shape[2] == 4
+            self.d_disk_tex = torch.as_tensor(tex).to(self.dev)
+
+    def set_objects(self, spheres, sphere_rgb=None, lamps=None):
+        """Object spheres [[cx, cy, cz, radius]] (BH-centred), their colours and the point lamps
+        [[x, y, z, intensity]] that light them.  Cheap to call per frame (an animation moves them): the
+        values travel as kernel arguments."""
+        self.spheres = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+        self.sphere_rgb = sphere_rgb
+        self.lamps = lamps
+        if self.d_obj is None:
+            self.d_obj = torch.empty(self.n, dtype=torch.int8, device=self.dev)
+
     def generate_rays(self):
         self.ctx.raygen_device(self.W, self.H, self.S, self.fov_x, self.fov_y, self.d_jitter.data_ptr(),
                                self.d_k0.data_ptr(), self.P,
@@ -68,13 +97,30 @@ class DeviceFrame:
                                rot=self.rot, stream=self._stream())
 
     def trace(self, params: _ffi.Params):
+        has_obj = self.spheres is not None and len(self.spheres) > 0
         self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), x0_shared=self.origin,
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
-                              d_n_accepted=self.d_acc.data_ptr(), stream=self._stream())
+                              d_n_accepted=self.d_acc.data_ptr(), stream=self._stream(),
+                              spheres=self.spheres if has_obj else None,
+                              d_object_id=self.d_obj.data_ptr() if has_obj else 0)
+
+    def scene(self):
+        tex = self.d_disk_tex
+        return _ffi.make_scene(self.d_sky.data_ptr(), self.sky_wh[0], self.sky_wh[1],
+                               d_disk_tex=0 if tex is None else tex.data_ptr(),
+                               disk_w=0 if tex is None else tex.shape[1], disk_h=0 if tex is None else tex.shape[0],
+                               disk=self.disk, spheres=self.spheres, sphere_rgb=self.sphere_rgb, lamps=self.lamps,
+                               **self.disk_profile)
 
     def shade(self):
         if self.d_sky is None:
             raise RuntimeError("set_sky() first")
+        if self.disk is not None or (self.spheres is not None and len(self.spheres) > 0):
+            self.ctx.shade_scene_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.scene(),
+                                        self.d_rgba.data_ptr(),
+                                        d_object_id=0 if self.d_obj is None else self.d_obj.data_ptr(),
+                                        stream=self._stream())
+            return self.d_rgba
         self.ctx.shade_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
                               self.sky_wh[0], self.sky_wh[1], self.d_rgba.data_ptr(), stream=self._stream())
         return self.d_rgba

@@ -185,6 +185,28 @@ int bhg_shade_device(bhg_context *ctx, const double *d_end, const uint8_t *d_fla
                      int32_t samples, const float *d_sky, int32_t sky_w, int32_t sky_h, double *d_rgba,
                      void *stream);
 
+/* The same with the scene the later engines add: rays that ended on the thin disk
+ * (BHG_FLAG_HIT_DISK) get texture(texture_x, scale) * intensity with the Gaussian radial profile of
+ * checkHitDisk (LimitedRelativisticRenderEngine.py:427-436, :300); rays that ended on an object sphere
+ * (BHG_FLAG_HIT_OBJECT) get the Lambert point-lamp sum of spacetime_hit (RelativisticRenderEngine.py:
+ * 341-363; light paths are straight, shadowed by the other spheres, n.l clamped at 0) times the sphere's
+ * colour.  The struct lives on the HOST; d_* members are device addresses.  d_disk_tex may be NULL
+ * (white); d_object_id may be NULL when n_spheres is 0. */
+typedef struct bhg_scene {
+    const float *d_sky;      /* [sky_h][sky_w][4] RGBA float32, equirectangular */
+    int32_t sky_w, sky_h;
+    const float *d_disk_tex; /* [disk_h][disk_w][4] RGBA float32 */
+    int32_t disk_w, disk_h;
+    double disk_r_in, disk_r_out;                                  /* 0, 0 = no disk */
+    double disk_phase, disk_mean, disk_stddev, disk_intensity;     /* scene.disk_* (:55-58; defaults 0, 0.2, 0.3, 1) */
+    int32_t n_spheres, n_lamps;                                    /* <= BHG_MAX_SPHERES, <= 4 */
+    double spheres[BHG_MAX_SPHERES][4];                            /* as for bhg_trace_objects */
+    double sphere_rgb[BHG_MAX_SPHERES][3];
+    double lamps[4][4];                                            /* {x, y, z, intensity} (intensity = 10 at :317) */
+} bhg_scene;
+int bhg_shade_scene_device(bhg_context *ctx, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
+                           size_t n_pixels, int32_t samples, const bhg_scene *scene, double *d_rgba, void *stream);
+
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term. */
 int bhg_acceleration(bhg_context *ctx, const bhg_params *p, const double *x, const double *k,

@@ -63,6 +63,47 @@ def test_device_shade_and_mean_match_numpy(ctx, oracle):
     assert np.array_equal((rgba[:, :3] == 0.0).all(1), all_hit)
 
 
+def test_device_scene_shade_disk_and_objects(ctx, oracle):
+    """Disk colour (Limited engine's checkHitDisk profile) and object Lambert shading in the device shade
+    kernel against the numpy restatement, on a frame that holds horizon, sky, disk and object pixels."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
+    from oracle import shade_reference as sh
+    W, H, S = 128, 96, 3
+    sky = synthetic_sky(512, 256)
+    disk_tex = synthetic_sky(256, 64, seed=3)
+    inc = np.radians(75.0)
+    cam = np.array([30 * np.sin(inc), 0.0, 30 * np.cos(inc)])
+    fr = DeviceFrame(ctx, W, H, S, fov_x=0.9, fov_y=0.9, sampling_seed=42.0, origin=cam, rotation_euler=(0.0, inc, 0.0))
+    fr.set_sky(sky)
+    prof = dict(disk_phase=0.4, disk_mean=0.3, disk_stddev=0.25, disk_intensity=2.0)
+    fr.set_disk(3.0, 9.0, disk_tex, **prof)
+    sph = [[6.0, 3.0, 2.5, 1.5], [7.0, -4.0, 3.0, 1.0], [2.0, 6.0, -1.0, 1.2]]
+    rgb = [[1.0, 0.8, 0.6], [0.2, 0.9, 0.3], [0.5, 0.5, 1.0]]
+    lamps = [[20.0, 0.0, 20.0, 10.0], [10.0, -15.0, 5.0, 6.0]]
+    fr.set_objects(sph, rgb, lamps)
+    kw = dict(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=9.0)
+    rgba = fr.render(_params(**kw)).cpu().numpy()
+    torch.cuda.synchronize()
+    end, flags, obj = fr.d_end.cpu().numpy(), fr.d_flags.cpu().numpy(), fr.d_obj.cpu().numpy()
+    kinds = {int(f): int((flags == f).sum()) for f in np.unique(flags)}
+    assert kinds.get(1, 0) > 100 and kinds.get(8, 0) > 1000 and kinds.get(128, 0) > 1000 and kinds.get(0x88, 0) > 300, kinds
+    want = sh.shade_scene(end, flags, obj, W * H, S, sky, disk=(3.0, 9.0), disk_tex=disk_tex, disk_profile=dict(
+        phase=0.4, mean=0.3, stddev=0.25, intensity=2.0), spheres=sph, sphere_rgb=np.array(rgb), lamps=lamps)
+    assert np.abs(rgba - want).max() < 1e-11
+    # trace parity of the same frame (ids included), and the whole pipeline against oracle + numpy shade
+    k0 = fr.d_k0.cpu().numpy()
+    o = oracle.trace(k0, cam, spheres=sph, **kw)
+    assert np.array_equal(flags, o["flags"]) and np.array_equal(obj, o["object_id"])
+    want2 = sh.shade_scene(o["end"], o["flags"], o["object_id"], W * H, S, sky, disk=(3.0, 9.0), disk_tex=disk_tex,
+                           disk_profile=dict(phase=0.4, mean=0.3, stddev=0.25, intensity=2.0), spheres=sph,
+                           sphere_rgb=np.array(rgb), lamps=lamps)
+    assert np.abs(rgba - want2).max() < 1e-5
+    # some object pixels are lit, some lie in shadow or face away
+    lit = want[:, :3].sum(1)
+    assert (lit > 0).any()
+
+
 def test_frame_tracer_on_gpu_matches_oracle(ctx, oracle):
     """frame.FrameTracer (the batched ray_trace generator) with the real integrator."""
     from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild, camera_directions

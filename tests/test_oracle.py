@@ -287,3 +287,20 @@ def test_oracle_objects_start_inside_sphere_and_ordering(oracle):
     # impact parameter 2 < 2.6 r_s: captured, whatever lies behind the hole
     o = oracle.trace(k, np.array([2.0, 0.0, 20.0]), r_s=1.0, lambda_end=60.0, spheres=[(0.0, 0.0, -6.0, 2.0), (2.0, 0.0, -6.0, 1.0)])
     assert o["flags"][0] == oracle.FLAG_HIT_HORIZON and o["object_id"][0] == -1
+
+
+def test_scene_shade_reference_known_answers():
+    """oracle/shade_reference.py's disk and object colours on hand-computed cases."""
+    from oracle import shade_reference as sh
+    # disk: R = 6 between 3 and 9 -> scale 0.5; white texture; mean 0.5 -> exp(0) / sqrt(2 pi sigma)
+    e = np.array([[6.0, 0.0, 0.0, 0, 0, -1.0]])
+    c = sh.disk_colour(e, 3.0, 9.0, None, phase=0.0, mean=0.5, stddev=0.3, intensity=2.0)
+    assert np.allclose(c, 2.0 / np.sqrt(2 * np.pi * 0.3))
+    # object: lamp straight above the hit point at distance 2, intensity 10 -> 100 * 1 / 4
+    sph = [[0.0, 0.0, 0.0, 1.0], [0.0, 0.0, 2.0, 0.5]]
+    e = np.array([[0.0, 0.0, 1.0, 0, 0, -1.0]])
+    c = sh.object_colour(e, np.array([0]), sph[:1], [[1.0, 0.5, 0.25]], [[0.0, 0.0, 3.0, 10.0]])
+    assert np.allclose(c, [[25.0, 12.5, 6.25]])
+    # a second sphere between the point and the lamp: shadow; lamp behind the surface: nothing
+    assert np.all(sh.object_colour(e, np.array([0]), sph, np.ones((2, 3)), [[0.0, 0.0, 3.0, 10.0]]) == 0.0)
+    assert np.all(sh.object_colour(e, np.array([0]), sph[:1], np.ones((1, 3)), [[0.0, 0.0, -3.0, 10.0]]) == 0.0)
