@@ -45,13 +45,25 @@ def parse():
                          "fine: same with max_step 0.1; rk4: fixed step 0.1")
     ap.add_argument("--rhs", choices=["christoffel", "reduced", "kerr"], default="christoffel",
                     help="kerr = BASELINE.json configs[4]: a/M = 0.9, Boyer-Lindquist Christoffels, same camera")
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--workload", choices=["frame", "disk", "orbit"], default="frame",
+                    help="frame: BASELINE.json configs[1] (the headline; configs[4] with --rhs kerr); "
+                         "disk: configs[2], 1024x1024 + thin disk, a step = the 5 camera inclinations; "
+                         "orbit: configs[3], 2048x2048 x16 with a lit sphere orbiting the hole, a step = one "
+                         "animation frame (the sphere moves every step); N > 1 shards that one frame (strong scaling)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--lpt", type=int, default=1, help="1: visit tiles in order of decreasing expected cost")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time (0 = skip)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    dw, ds = {"frame": (1024, 5), "disk": (1024, 1), "orbit": (2048, 16)}[a.workload]
+    a.width = a.width or dw
+    a.height = a.height or a.width
+    a.samples = a.samples or ds
+    if a.workload != "frame" and a.rhs == "kerr":
+        ap.error("disk / objects are Schwarzschild-only")
+    return a
 
 
 def grid_for(n):
@@ -84,15 +96,20 @@ def main():
     from blackhole_geodesic_calculator_amd.raygen import python_random_stream
 
     ctx = _ffi.Context(local_rank)
-    nx, ny = grid_for(world)
+    nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
     W, H, S = a.width * nx, a.height * ny, a.samples
     cam = np.array([1e-4, 0.0, 30.0])
     method = "rk4" if a.regime == "rk4" else "dp54"
-    params = _ffi.make_params(
-        r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
-        h_fixed=0.1, method=_ffi.METHOD_RK4 if method == "rk4" else _ffi.METHOD_DP54,
-        rhs_form={"reduced": _ffi.RHS_REDUCED, "kerr": _ffi.RHS_KERR_BL}.get(a.rhs, _ffi.RHS_CHRISTOFFEL),
-        spin=0.45 if a.rhs == "kerr" else 0.0)
+    # oracle-style keyword set; the same dict configures the CPU baseline
+    okw = dict(r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
+               h_fixed=0.1, method=1 if method == "rk4" else 0, rhs_form={"reduced": 1, "kerr": 2}.get(a.rhs, 0),
+               spin=0.45 if a.rhs == "kerr" else 0.0)
+    DISK = (4.5, 10.5)   # 0.15 .. 0.35 x ratio 30 (tests/golden disk set; LimitedRelativisticRenderEngine.py:283-286)
+    if a.workload == "disk":
+        okw.update(lambda_end=80.0, r_exit=40.0, disk_r_in=DISK[0], disk_r_out=DISK[1])
+    elif a.workload == "orbit":
+        okw.update(lambda_end=80.0, r_exit=40.0)
+    params = _ffi.make_params(**okw)
 
     # ---- synthetic input, resident in HBM before the timed region ----------------------------
     # this rank's tiles of the frame (all samples of a pixel together); jitter stream = the
@@ -108,15 +125,37 @@ def main():
         # x_render = fov (x - W/2)/W and y_render = fov (y - H/2)/W: one pixel scale for both axes
         return -abs(np.hypot(cx - W / 2, cy - H / 2) - rho_c)
 
-    pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tile_cost if a.lpt else None)
+    pixels = bdist.rank_pixels(W, H, a.tile, rank, world,
+                               tile_cost=tile_cost if (a.lpt and a.workload == "frame") else None)
     jitter = python_random_stream(42.0, 2 * S * W * H)
-    fr = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=cam,
-                     pixels=pixels, jitter=jitter)
+    sky = synthetic_sky(2048, 1024)
+    frames = []   # the DeviceFrames one step passes over
+    if a.workload == "disk":
+        # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination)
+        for inc_deg in (85.0, 80.0, 60.0, 30.0, 5.0):
+            inc = np.radians(inc_deg)
+            f = DeviceFrame(ctx, W, H, S, fov_x=0.9, fov_y=0.9, sampling_seed=42.0,
+                            origin=(30 * np.sin(inc), 0.0, 30 * np.cos(inc)), rotation_euler=(0.0, inc, 0.0),
+                            pixels=pixels, jitter=jitter)
+            f.set_disk(DISK[0], DISK[1], synthetic_sky(1024, 128, seed=3))
+            frames.append(f)
+    else:
+        frames.append(DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=cam,
+                                  pixels=pixels, jitter=jitter))
     del jitter
-    fr.set_sky(synthetic_sky(2048, 1024))
-    fr.generate_rays()
-    n, P = fr.n, fr.P
-    dst = fr.d_steps
+    for f in frames:
+        f.set_sky(sky)
+        f.generate_rays()
+    fr = frames[0]
+    n, P = sum(f.n for f in frames), fr.P
+
+    def orbit_scene(i):
+        # config 4: a sphere of radius 1.5 on a circular orbit of radius 8 r_s, inclined 20 degrees to the line of
+        # sight plane, one revolution per 100 frames; lit by one lamp beside the camera
+        ph = 2.0 * np.pi * (i % 100) / 100.0
+        tilt = np.radians(70.0)
+        c = 8.0 * np.array([np.cos(ph), np.sin(ph) * np.cos(tilt), np.sin(ph) * np.sin(tilt)])
+        return [[c[0], c[1], c[2], 1.5]], [[1.0, 0.85, 0.7]], [[10.0, 10.0, 30.0, 30.0]]
     ts = torch.cuda.current_stream()
     k0 = None
 
@@ -127,16 +166,19 @@ def main():
     kernel_ms = []
 
     def step(i, timed):
-        if timed:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(ts)
-            fr.trace(params)
-            e1.record(ts)
-            kernel_ms.append((e0, e1))
-        else:
-            fr.trace(params)
-        gatherer.submit(i, fr.shade())
+        if a.workload == "orbit":
+            fr.set_objects(*orbit_scene(i))
+        for j, f in enumerate(frames):
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
+                f.trace(params)
+                e1.record(ts)
+                kernel_ms.append((e0, e1))
+            else:
+                f.trace(params)
+            gatherer.submit(i * len(frames) + j, f.shade())
 
     def barrier():
         gatherer.drain()
@@ -158,8 +200,9 @@ def main():
         dt = float(tmax.item())
 
     ctx.set_profiling(False)
-    ray_steps = int(dst.to(torch.int64).sum().item())
-    call_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) if kernel_ms else float("nan")
+    ray_steps = sum(int(f.d_steps.to(torch.int64).sum().item()) for f in frames)
+    # per step: the trace calls of all its frames
+    call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(a.steps, 1) if kernel_ms else float("nan")
     # the dominant kernel alone: one extra profiled call after the timed region (events on this stream)
     # (HIP events recorded by the library around prepare | trace | resolve on this same stream);
     # its share of the three-pass call is applied to the call time measured inside the timed region
@@ -173,6 +216,9 @@ def main():
     k_ms = call_ms * share
     prep_ms = call_ms * float(np.median([t["prepare"] / (t["prepare"] + t["trace"] + t["resolve"]) for t in tr]))
     res_ms = call_ms - k_ms - prep_ms
+    multipass = a.workload != "frame"   # disk / objects: the call loops over resume passes; price the whole call
+    if multipass:
+        k_ms, prep_ms, res_ms = call_ms, float("nan"), float("nan")
     tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tot)
@@ -183,7 +229,10 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
         out = {
-            "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU",
+            "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU"
+                      if a.workload == "frame" else
+                      {"disk": "Mrays/s, 1024x1024 Schwarzschild + thin disk, 5 camera inclinations per step",
+                       "orbit": "Mrays/s, 2048x2048x16 orbiting-sphere animation frame"}[a.workload],
             "value": rays_all / (dt / a.steps) / 1e6,
             "unit": "Mrays/s",
             "ray_steps_per_s": steps_all / (dt / a.steps),
@@ -192,14 +241,21 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if a.workload == "orbit" else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE.json configs[{4 if a.rhs == 'kerr' else 1}]: {a.width}x{a.height} x{S} multisample "
-                            f"{'Kerr a/M=0.9' if a.rhs == 'kerr' else 'Schwarzschild'} frame per GPU "
-                            f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50",
+                "workload": (f"BASELINE.json configs[{4 if a.rhs == 'kerr' else 1}]: {a.width}x{a.height} x{S} multisample "
+                             f"{'Kerr a/M=0.9' if a.rhs == 'kerr' else 'Schwarzschild'} frame per GPU "
+                             f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50")
+                            if a.workload == "frame" else
+                            {"disk": f"BASELINE.json configs[2]: {a.width}x{a.height} x{S} Schwarzschild + thin disk "
+                                     f"{DISK[0]}..{DISK[1]} r_s, camera r=30 at inclinations 85/80/60/30/5 deg (5 frames per "
+                                     f"step), fov 0.9, exit sphere 40, curve_end 80; frame {W}x{H} over {world} GPU(s)",
+                             "orbit": f"BASELINE.json configs[3]: {W}x{H} x{S} frame of the orbiting-sphere animation (sphere "
+                                      f"radius 1.5 on an r=8 orbit, new position every step, lamp-lit), tiles sharded "
+                                      f"over {world} GPU(s); camera (1e-4,0,30), fov 0.6, exit sphere 40, curve_end 80"}[a.workload],
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
                 "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
@@ -208,7 +264,8 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": f"trace_{method}_kernel<{a.rhs}>",
+                "kernel": f"trace_{method}_kernel<{a.rhs}>" if not multipass else
+                          f"bhg_trace call, all passes (prepare + trace_{method}_kernel<{a.rhs}> + resolve, repeated for resumed rays)",
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
@@ -223,7 +280,9 @@ def main():
             },
         }
         if a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(fr.d_k0.cpu().numpy(), cam, a, method)
+            if a.workload == "orbit":
+                okw["spheres"] = orbit_scene(a.steps - 1)[0]
+            out["cpu_baseline"] = cpu_baseline(fr.d_k0.cpu().numpy(), fr.origin, a, okw)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -236,7 +295,7 @@ def pmc_traffic(a, method):
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be
     read inside the timed run, so this is the committed measurement, or None if it does not apply."""
     import glob
-    if not (a.regime == "adaptive" and a.rhs == "christoffel" and method == "dp54" and a.width == 1024
+    if not (a.workload == "frame" and a.regime == "adaptive" and a.rhs == "christoffel" and method == "dp54" and a.width == 1024
             and a.height == 1024 and a.samples == 5):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
@@ -248,14 +307,11 @@ def pmc_traffic(a, method):
         return None
 
 
-def cpu_baseline(k0, cam, a, method):
+def cpu_baseline(k0, cam, a, kw):
     """The C oracle (a port of the algorithm, see oracle/geodesic_oracle.c) timed on this host's
     cores on a bounded sample of the same rays.  Reported baseline only; never the thing shipped."""
     from oracle import oracle as oc
     oc.build()
-    kw = dict(r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
-              h_fixed=0.1, method=1 if method == "rk4" else 0, rhs_form={"reduced": 1, "kerr": 2}.get(a.rhs, 0),
-              spin=0.45 if a.rhs == "kerr" else 0.0)
     cores = oc.num_threads()
     n = len(k0)
     probe = k0[:: max(1, n // 16384)]

@@ -446,6 +446,31 @@ __device__ __forceinline__ bool sphere_candidate(const double sp[4], const doubl
     return bb > 0.0 && bb < cc && (d0 - rho2) * cc < bb * bb;
 }
 
+// A step that crosses the disk plane z = 0 needs the resolve pass only if the crossing can lie in the annulus.
+// The crossing point of the step's dense output lies within delta of the chord's crossing point, where
+// delta = 2 |h| (|v0 - c| + |v1 - c|), c = (x1 - x0) / h the chord velocity: a curve whose velocity stays within
+// eps of c for a time |h| strays at most |h| eps from the chord, and the velocities of an accepted step lie
+// between its end velocities up to the (controlled) step error -- twice the sum of both end deviations is a
+// generous bound (the true excursion is about |h| |v1 - v0| / 8: a factor 16 to 32 of slack).  Outside [R_in - delta, R_out + delta]: not terminal,
+// the ray simply carries on, exactly as the resolve pass would have decided.
+__device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const double x0[3], const double v0[3],
+                                                      const double x1[3], const double v1[3], double h)
+{
+    const double s = x0[2] / (x0[2] - x1[2]);  // NaN when the step lies in the plane: falls through to "may hit"
+    const double xl = x0[0] + s * (x1[0] - x0[0]), yl = x0[1] + s * (x1[1] - x0[1]);
+    const double R = sqrt(xl * xl + yl * yl);
+    const double ih = 1.0 / h;
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double cv = (x1[c] - x0[c]) * ih;
+        d0 += (v0[c] - cv) * (v0[c] - cv);
+        d1 += (v1[c] - cv) * (v1[c] - cv);
+    }
+    const double delta = 2.0 * fabs(h) * (sqrt(d0) + sqrt(d1));
+    return !(R + delta < A.disk_r_in || R - delta > A.disk_r_out);
+}
+
 __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
 {
     bool any = false;
@@ -1177,10 +1202,12 @@ __global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel
                     const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
+                    bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                       (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                            ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
                     const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+                    if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) && !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                        ev_d = false;
                     if (ev_h || ev_e || ev_d || ev_o) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
                         park_event(A, L, h, t_new,
@@ -1277,10 +1304,12 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                const bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
+                bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                       (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
                                                        ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
                 const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+                if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) && !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                    ev_d = false;
                 if (ev_h || ev_e || ev_d || ev_o) {
                     L.n_acc = L.n_att;
                     L.h_abs = hf;
