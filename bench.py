@@ -9,7 +9,7 @@ timed region starts; the timed region is trace + shade/sample-mean and, for N > 
 per-pixel RGBA to rank 0 (asynchronous, overlapping the next frame's trace).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): WEAK scaling -- the frame
-grows to (1024*nx) x (1024*ny), nx*ny = N, same field of view, so every rank still traces
+grows to (1024*nx) x (1024*ny), nx*ny = N, over the same window of directions, so every rank still traces
 5,242,880 rays of the same distribution; 32x32-pixel tiles are dealt round-robin to ranks.
 
 Prints ONE JSON line on rank 0.
@@ -83,13 +83,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: BHGEO_BENCH_BACKEND=gloo exercises the N > 1 code path with several ranks on ONE GPU
+    # (RCCL refuses two ranks per device); never used by the driver's runs
+    backend = os.environ.get("BHGEO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from blackhole_geodesic_calculator_amd import _ffi
     from blackhole_geodesic_calculator_amd import dist as bdist
@@ -119,11 +127,14 @@ def main():
     from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
     # tiles in order of decreasing expected cost: steps per ray peak at the shadow edge (impact
     # parameter b_c = 2.6 r_s -> radius b_c / |cam| / fov * width pixels around the frame centre)
-    rho_c = 2.598 / 30.0 / 0.6 * W
+    # the frame always spans the same window of directions (0.6 x 0.6 in the pinhole's tangent plane): for a
+    # non-square rank grid (N = 2, 8) fov_y is widened by nx / ny, because y_render carries the aspect
+    # factor H / W (RelativisticRenderEngine.py:197-198); every rank then samples the same distribution of rays
+    fov_x, fov_y = 0.6, 0.6 * nx / ny
 
     def tile_cost(cx, cy):
-        # x_render = fov (x - W/2)/W and y_render = fov (y - H/2)/W: one pixel scale for both axes
-        return -abs(np.hypot(cx - W / 2, cy - H / 2) - rho_c)
+        ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
+        return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
 
     pixels = bdist.rank_pixels(W, H, a.tile, rank, world,
                                tile_cost=tile_cost if (a.lpt and a.workload == "frame") else None)
@@ -140,7 +151,7 @@ def main():
             f.set_disk(DISK[0], DISK[1], synthetic_sky(1024, 128, seed=3))
             frames.append(f)
     else:
-        frames.append(DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=cam,
+        frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
                                   pixels=pixels, jitter=jitter))
     del jitter
     for f in frames:
