@@ -20,19 +20,41 @@ from .raygen import camera_directions, python_random_stream
 
 
 def spacetime_ray_cast_batch(integrator, origin, directions, bh_loc=(0.0, 0.0, 0.0), max_step=np.inf,
-                             curve_end=50.0):
+                             curve_end=50.0, spheres=None, return_objects=False):
     """Batched form of spacetime_ray_cast (RelativisticRenderEngine.py:271-313).
 
     origin: camera world position [3]; directions [..., 3] unit vectors.
-    Returns (hit, hit_bh, end_dir, end_loc) with hit == False everywhere (:305), hit_bh a bool
-    array, end_dir/end_loc [..., 3].  A camera inside the hole gives hit_bh == True for every ray
-    (:311-313); end_dir/end_loc then hold the start values.
+    Returns (hit, hit_bh, end_dir, end_loc): hit_bh a bool array, end_dir/end_loc [..., 3].  Without
+    `spheres`, hit == False everywhere, as the reference's stub has it (:304-305).  With
+    spheres=[[cx, cy, cz, radius], ...] in WORLD coordinates (bh_loc is subtracted here like the
+    origin, :278), hit is True where the curve entered a sphere; end_loc is then the entry point (world
+    coordinates minus bh_loc, like every end_loc) and end_dir the direction there.  return_objects=True
+    appends (normal [..., 3], index [...]) -- the `normal`, `index` a scene.ray_cast hit carries (:441).
+    A camera inside the hole gives hit_bh == True for every ray (:311-313); end_dir/end_loc then hold
+    the start values.
     """
-    origin = np.asarray(origin, dtype=np.float64) - np.asarray(bh_loc, dtype=np.float64)  # :278
-    out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end)
+    bh = np.asarray(bh_loc, dtype=np.float64)
+    origin = np.asarray(origin, dtype=np.float64) - bh  # :278
+    if spheres is not None and len(spheres):
+        sp = np.array(spheres, dtype=np.float64).reshape(-1, 4)
+        sp[:, 0:3] -= bh
+        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end, spheres=sp)
+    else:
+        sp = None
+        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end)
     end = out["ray_end"]
     hit_bh = out["ray_blackhole_hit"].astype(bool)
-    hit = np.zeros(hit_bh.shape, dtype=bool)
+    if sp is None:
+        hit = np.zeros(hit_bh.shape, dtype=bool)
+        index = np.full(hit_bh.shape, -1, dtype=np.int8)
+        normal = np.zeros(end.shape[:-1] + (3,))
+    else:
+        index = out["object_id"]
+        hit = index >= 0
+        c = sp[np.maximum(index, 0)]
+        normal = np.where(hit[..., None], (end[..., 0:3] - c[..., 0:3]) / c[..., 3:4], 0.0)
+    if return_objects:
+        return hit, hit_bh, end[..., 3:6], end[..., 0:3], normal, index
     return hit, hit_bh, end[..., 3:6], end[..., 0:3]
 
 
@@ -41,7 +63,7 @@ class FrameTracer:
 
     def __init__(self, integrator, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
                  origin=(0.0, 0.0, 0.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0),
-                 max_step=np.inf, curve_end=50.0, mark=None):
+                 max_step=np.inf, curve_end=50.0, mark=None, spheres=None, object_hit=None):
         self.integrator = integrator
         self.width, self.height, self.samples = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
@@ -51,6 +73,10 @@ class FrameTracer:
         self.bh_loc = np.asarray(bh_loc, dtype=np.float64)
         self.max_step, self.curve_end = max_step, curve_end
         self.mark = mark  # (y_min, y_max, x_min, x_max), inclusive, or None
+        # objects in the curved region (the stub at :304-305 filled in): spheres in world coordinates and
+        # object_hit(loc[n,3], normal[n,3], index[n]) -> rgb[n,3], the vectorised spacetime_hit (:240, :317)
+        self.spheres = spheres
+        self.object_hit = object_hit
         self.last_counters = None
 
     # the jitter stream depends only on (seed, window, S): cache it across frames (:189 re-seeds
@@ -76,12 +102,16 @@ class FrameTracer:
         for s in range(S):
             if rows and len(cols):
                 d = dirs[s][np.ix_(rows, cols)]  # [R, C, 3]
-                _, hit_bh, end_dir, _ = spacetime_ray_cast_batch(
-                    self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end)
+                hit, hit_bh, end_dir, end_loc, normal, index = spacetime_ray_cast_batch(
+                    self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end,
+                    spheres=self.spheres, return_objects=True)
                 colour = np.zeros(d.shape)
-                esc = ~hit_bh
+                esc = ~hit_bh & ~hit   # :239-246: hit -> spacetime_hit, hit_bh -> black, else background
                 if esc.any():
                     colour[esc] = np.asarray(background_hit(end_dir[esc]), dtype=np.float64)
+                if hit.any() and self.object_hit is not None:
+                    colour[hit] = np.asarray(self.object_hit(end_loc[hit] + self.bh_loc, normal[hit], index[hit]),
+                                             dtype=np.float64)
                 rays += hit_bh.size
             for ri, y in enumerate(rows):
                 sbuf[y, cols, 0:3] += colour[ri]
