@@ -24,7 +24,7 @@ class DeviceFrame:
 
     def __init__(self, ctx: _ffi.Context, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
                  origin=(1e-4, 0.0, 30.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0), pixels=None,
-                 jitter=None, device=None):
+                 jitter=None, device=None, buffers=None):
         self.ctx = ctx
         self.W, self.H, self.S = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
@@ -42,11 +42,16 @@ class DeviceFrame:
             self.P = int(self.d_pixels.numel())
         n = self.S * self.P
         self.n = n
-        self.d_k0 = torch.empty((n, 3), dtype=torch.float64, device=self.dev)
-        self.d_end = torch.empty((n, 6), dtype=torch.float64, device=self.dev)
-        self.d_flags = torch.empty(n, dtype=torch.uint8, device=self.dev)
-        self.d_steps = torch.empty(n, dtype=torch.int32, device=self.dev)
-        self.d_acc = torch.empty(n, dtype=torch.int32, device=self.dev)
+        if buffers is not None:
+            # views into a caller-owned block shared by several frames (FrameBatch): one trace call for all
+            self.d_k0, self.d_end, self.d_flags, self.d_steps, self.d_acc = buffers
+            assert self.d_k0.shape == (n, 3) and self.d_end.shape == (n, 6) and self.d_flags.numel() == n
+        else:
+            self.d_k0 = torch.empty((n, 3), dtype=torch.float64, device=self.dev)
+            self.d_end = torch.empty((n, 6), dtype=torch.float64, device=self.dev)
+            self.d_flags = torch.empty(n, dtype=torch.uint8, device=self.dev)
+            self.d_steps = torch.empty(n, dtype=torch.int32, device=self.dev)
+            self.d_acc = torch.empty(n, dtype=torch.int32, device=self.dev)
         self.d_rgba = torch.empty((self.P, 4), dtype=torch.float64, device=self.dev)
         self.d_sky = None
         self.sky_wh = (0, 0)
@@ -132,6 +137,53 @@ class DeviceFrame:
             self._rays_ready = True
         self.trace(params)
         return self.shade()
+
+
+class FrameBatch:
+    """Several cameras' frames of the same size traced by ONE library call (per-ray origins, bhg_trace_device's
+    d_x0): e.g. the five inclinations of a disk study.  Each member is a DeviceFrame whose ray buffers are views
+    into one block; shading stays per frame."""
+
+    def __init__(self, ctx: _ffi.Context, cameras, width, height, samples, *, pixels=None, jitter=None, device=None,
+                 **frame_kw):
+        """cameras: list of dicts with origin=, rotation_euler= (and optionally bh_loc=)."""
+        self.ctx = ctx
+        dev = torch.device("cuda", ctx.device) if device is None else device
+        W, H, S = int(width), int(height), int(samples)
+        P = W * H if pixels is None else len(pixels)
+        n1 = S * P
+        m = len(cameras)
+        if jitter is None:
+            jitter = python_random_stream(frame_kw.get("sampling_seed", 42.0), 2 * S * W * H)
+        self.d_k0 = torch.empty((m * n1, 3), dtype=torch.float64, device=dev)
+        self.d_x0 = torch.empty((m * n1, 3), dtype=torch.float64, device=dev)
+        self.d_end = torch.empty((m * n1, 6), dtype=torch.float64, device=dev)
+        self.d_flags = torch.empty(m * n1, dtype=torch.uint8, device=dev)
+        self.d_steps = torch.empty(m * n1, dtype=torch.int32, device=dev)
+        self.d_acc = torch.empty(m * n1, dtype=torch.int32, device=dev)
+        self.frames = []
+        for j, cam in enumerate(cameras):
+            sl = slice(j * n1, (j + 1) * n1)
+            f = DeviceFrame(ctx, W, H, S, pixels=pixels, jitter=jitter, device=dev,
+                            buffers=(self.d_k0[sl], self.d_end[sl], self.d_flags[sl], self.d_steps[sl], self.d_acc[sl]),
+                            **cam, **frame_kw)
+            self.d_x0[sl] = torch.as_tensor(f.origin, device=dev)
+            self.frames.append(f)
+        self.n = m * n1
+        self.dev = dev
+
+    def generate_rays(self):
+        for f in self.frames:
+            f.generate_rays()
+
+    def trace(self, params: _ffi.Params):
+        self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), d_x0=self.d_x0.data_ptr(),
+                              d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
+                              d_n_accepted=self.d_acc.data_ptr(),
+                              stream=torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def shade(self):
+        return [f.shade() for f in self.frames]
 
 
 def synthetic_sky(width=2048, height=1024, seed=7):

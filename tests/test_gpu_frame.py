@@ -104,6 +104,35 @@ def test_device_scene_shade_disk_and_objects(ctx, oracle):
     assert (lit > 0).any()
 
 
+def test_frame_batch_equals_single_frames(ctx):
+    """Several cameras in ONE trace call (per-ray origins) give bit-identical rays, end states and pixels."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, FrameBatch, synthetic_sky
+    W, H, S = 64, 48, 2
+    sky = synthetic_sky(256, 128)
+    cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0)) for i in (1.4, 0.6, 0.1)]
+    p = _params(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)
+    fb = FrameBatch(ctx, cams, W, H, S, fov_x=0.9, fov_y=0.9, sampling_seed=42.0)
+    for f in fb.frames:
+        f.set_sky(sky)
+        f.set_disk(4.5, 10.5)
+    fb.generate_rays()
+    fb.trace(p)
+    imgs = [x.cpu().numpy().copy() for x in fb.shade()]
+    torch.cuda.synchronize()
+    for j, cam in enumerate(cams):
+        one = DeviceFrame(ctx, W, H, S, fov_x=0.9, fov_y=0.9, sampling_seed=42.0, **cam)
+        one.set_sky(sky)
+        one.set_disk(4.5, 10.5)
+        img = one.render(p).cpu().numpy()
+        f = fb.frames[j]
+        assert np.array_equal(one.d_k0.cpu().numpy(), f.d_k0.cpu().numpy())
+        assert np.array_equal(one.d_flags.cpu().numpy(), f.d_flags.cpu().numpy())
+        assert np.array_equal(one.d_end.cpu().numpy(), f.d_end.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(img, imgs[j])
+        assert (f.d_flags == 128).sum().item() > 50
+
+
 def test_frame_tracer_on_gpu_matches_oracle(ctx, oracle):
     """frame.FrameTracer (the batched ray_trace generator) with the real integrator."""
     from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild, camera_directions
