@@ -143,7 +143,13 @@ static void acc_kerr_bl(const rayctx *rc, const double q[3], const double u[3], 
     const double r = q[0], th = q[1], ur = u[0], uth = u[1], uph = u[2];
     const double E = rc->E, L = rc->L, M = rc->M, a = rc->a;
     double ar, ath, aph, ktv;
+#define KERR_RCP(x) (1.0 / (x))
+#define KERR_SIN(x) sin(x)
+#define KERR_COS(x) cos(x)
 #include "kerr_rhs.inc"
+#undef KERR_RCP
+#undef KERR_SIN
+#undef KERR_COS
     (void)ktv;
     acc[0] = ar;
     acc[1] = ath;
