@@ -221,6 +221,11 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
     double ar, ath, aph, ktv;
     double sin_th, cos_th;
     sincos_pi4(th, sin_th, cos_th);
+    {
+        // the generated statements are plain products and sums; let the front end fuse a*b + c inside each
+        // statement (a per-statement decision, the same wherever this function is inlined), unlike the rest
+        // of the library, which spells every FMA out and is built with -ffp-contract=off
+#pragma clang fp contract(on)
 #define KERR_RCP(x) rcp_nr(x)
 #define KERR_SIN(x) sin_th
 #define KERR_COS(x) cos_th
@@ -228,6 +233,7 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
 #undef KERR_RCP
 #undef KERR_SIN
 #undef KERR_COS
+    }
     (void)ktv;
     acc[0] = ar;
     acc[1] = ath;
@@ -1135,8 +1141,11 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
 #ifndef BHG_DP54_WAVES_PER_SIMD
 #define BHG_DP54_WAVES_PER_SIMD 2
 #endif
+#ifndef BHG_KERR_WAVES_PER_SIMD
+#define BHG_KERR_WAVES_PER_SIMD 2
+#endif
 template <int RHS, int EVT>
-__global__ void __launch_bounds__(64, BHG_DP54_WAVES_PER_SIMD) trace_dp54_kernel(const TraceArgs A)
+__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A)
 {
     __shared__ WaveLds Q;
     const uint32_t lane = threadIdx.x;
