@@ -113,11 +113,43 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         mark = None
         if (self.mark_y_min, self.mark_y_max, self.mark_x_min, self.mark_x_max) != (0, height, 0, width):
             mark = (self.mark_y_min, self.mark_y_max, self.mark_x_min, self.mark_x_max)
+        self.lamps = [ob for ob in depsgraph.scene.objects if ob.type == "LIGHT"]  # :175
+        spheres = self.scene_spheres(depsgraph)
         tracer = FrameTracer(
             self.GeoInt, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
             sampling_seed=self.sampling_seed, origin=origin, rotation_euler=rotation, bh_loc=self.bh_loc,
-            max_step=self.max_integration_step, curve_end=self.int_depth_curve_end, mark=mark)
+            max_step=self.max_integration_step, curve_end=self.int_depth_curve_end, mark=mark,
+            spheres=spheres if len(spheres) else None, object_hit=self.spacetime_hit_many)
         yield from tracer.ray_trace(buf, self.background_hit_many)
+
+    # ---- objects in the curved region: the collision test the reference leaves as a stub (:304-305) ----
+    def scene_spheres(self, depsgraph):
+        """Mesh objects of the scene as bounding spheres [[x, y, z, radius]] in world coordinates (the
+        README's orbiting-sphere animation, README.md:9-13, uses a UV sphere); the black-hole marker object
+        is skipped.  At most 8 (the solver's limit), the nearest to the hole first."""
+        bh = getattr(depsgraph.scene, "blackhole_obj", None)
+        out = []
+        for ob in depsgraph.scene.objects:
+            if ob.type != "MESH" or ob is bh:
+                continue
+            loc = np.array(list(ob.location), dtype=np.float64)
+            radius = 0.5 * max(float(d) for d in ob.dimensions)
+            if radius > 0.0:
+                out.append([loc[0], loc[1], loc[2], radius])
+        out.sort(key=lambda s: float(np.linalg.norm(np.array(s[:3]) - self.bh_loc)))
+        return np.array(out[:8], dtype=np.float64).reshape(-1, 4)
+
+    def spacetime_hit_many(self, loc, normal, index, intensity=10):
+        """Vectorised spacetime_hit (:317-363): white Lambert lamps with 1/d^2 falloff; no shadow rays (there
+        is no flat-space scene to cast them into here) and n.l clamped at 0."""
+        color = np.zeros(loc.shape)
+        for lamp in getattr(self, "lamps", []):
+            light_vec = np.array(list(lamp.location), dtype=np.float64) - loc
+            light_dist = (light_vec * light_vec).sum(-1)
+            light_dir = light_vec / np.sqrt(light_dist)[:, None]
+            ndl = np.maximum((normal * light_dir).sum(-1), 0.0)
+            color += (intensity * intensity * ndl / light_dist)[:, None]
+        return color
 
     # ---- shading (:366-378), Blender's own texture filter ------------------------------------
     def background_hit(self, direction):

@@ -133,6 +133,24 @@ def test_addon_plugin_surface_with_fake_bpy(monkeypatch):
     rect = np.array(eng.result.layers[0].passes["Combined"].rect)
     assert rect.shape == (12 * 8, 4) and np.all(rect[:, 3] == 1.0)
     assert eng.max_integration_step == np.inf  # -1 -> inf (:59-60)
+
+    # a mesh object and a lamp in the scene: the object is traced as its bounding sphere and lit (the stub at
+    # :304-305 filled in); the black-hole marker object and non-mesh objects are not obstacles
+    import types
+    ball = types.SimpleNamespace(type="MESH", location=(1.5, 1.0, 10.0), dimensions=(2.4, 2.4, 2.4))
+    lamp = types.SimpleNamespace(type="LIGHT", location=(5.0, 5.0, 30.0))
+    marker = types.SimpleNamespace(type="MESH", location=(0.0, 0.0, 0.0), dimensions=(1.0, 1.0, 1.0))
+    depsgraph.scene.objects[:] = [ball, lamp, marker, types.SimpleNamespace(type="CAMERA", location=(0, 0, 30), dimensions=(1, 1, 1))]
+    depsgraph.scene.blackhole_obj = marker
+    eng2 = addon.RelativisticRenderEngine()
+    eng2.render(depsgraph)
+    sph = eng2.scene_spheres(depsgraph)
+    assert sph.shape == (1, 4) and np.allclose(sph[0], [1.5, 1.0, 10.0, 1.2])
+    rect2 = np.array(eng2.result.layers[0].passes["Combined"].rect)
+    changed = np.abs(rect2 - rect).max(1) > 0
+    assert 0 < changed.sum() < len(rect) // 2
+    depsgraph.scene.objects[:] = []
+    depsgraph.scene.blackhole_obj = None
     assert (eng.mark_y_min, eng.mark_y_max, eng.mark_x_min, eng.mark_x_max) == (0, 8, 0, 12)
     # shading goes through Blender's texture evaluate with the reference's (u, v)
     col = eng.background_hit(np.array([0.0, 1.0, 0.0]))
