@@ -295,7 +295,7 @@ def main():
                 "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:   # the CPU baseline is an N = 1 figure (rank 0's host cores, nothing else running)
             if a.workload == "orbit":
                 okw["spheres"] = orbit_scene(a.steps - 1)[0]
             out["cpu_baseline"] = cpu_baseline(fr.d_k0.cpu().numpy(), fr.origin, a, okw)
