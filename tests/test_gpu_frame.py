@@ -104,6 +104,35 @@ def test_device_scene_shade_disk_and_objects(ctx, oracle):
     assert (lit > 0).any()
 
 
+def test_device_buffers_need_only_8_byte_alignment(ctx):
+    """k0 / end handed over at an address that is 8 but not 16 bytes aligned (a view into a larger
+    allocation): same results as the aligned call (the kernels use 16-byte accesses on 48-byte records)."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    from conftest import frame_rays
+    n, S = 5000, 2
+    k = torch.as_tensor(frame_rays(n, seed=5)).cuda()
+    p = _params(r_s=1.0, lambda_end=50.0)
+    outs = []
+    for off in (0, 1):
+        kb = torch.empty(n * 3 + 2, dtype=torch.float64, device="cuda")
+        eb = torch.empty(n * 6 + 2, dtype=torch.float64, device="cuda")
+        kv, ev = kb[off:off + n * 3], eb[off:off + n * 6]
+        kv.copy_(k.reshape(-1))
+        fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert kv.data_ptr() % 16 == 8 * off and ev.data_ptr() % 16 == 8 * off
+        ctx.trace_device(p, n, kv.data_ptr(), ev.data_ptr(), x0_shared=CAM, d_flags=fl.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+        sky = torch.as_tensor(synthetic_sky(128, 64)).cuda()
+        rgba = torch.empty((n // S, 4), dtype=torch.float64, device="cuda")
+        ctx.shade_device(ev.data_ptr(), fl.data_ptr(), n // S, S, sky.data_ptr(), 128, 64, rgba.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append((ev.cpu().numpy().copy(), fl.cpu().numpy().copy(), rgba.cpu().numpy().copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_frame_batch_equals_single_frames(ctx):
     """Several cameras in ONE trace call (per-ray origins) give bit-identical rays, end states and pixels."""
     import torch
