@@ -92,3 +92,25 @@ def test_integrator_argument_checks():
     gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=object())
     assert gi.r_s == 1.0
     assert gi.params(max_step=-1).max_step == float("inf")
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/bhgeo.h is the C ABI: it must compile as C99 and as C++ with nothing but the standard headers,
+    and its struct layouts are what the ctypes mirrors assume."""
+    import ctypes
+    import subprocess
+    from blackhole_geodesic_calculator_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include <stdio.h>\n#include "bhgeo.h"\n'
+                   'int main(void) { printf("%zu %zu %d %d\\n", sizeof(bhg_params), sizeof(bhg_scene), BHG_ABI_VERSION, '
+                   'BHG_MAX_SPHERES); return 0; }\n')
+    exe = tmp_path / "hdr"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-o", str(exe)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-x", "c++",
+                           "-fsyntax-only", str(src)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) == ctypes.sizeof(_ffi.Params) == 96
+    assert int(out[1]) == ctypes.sizeof(_ffi.Scene)
+    assert int(out[2]) == _ffi.ABI_VERSION and int(out[3]) == _ffi.MAX_SPHERES
