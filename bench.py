@@ -221,7 +221,7 @@ def main():
     call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(a.steps, 1) if kernel_ms else float("nan")
     # the dominant kernel alone: one extra profiled call after the timed region (events on this stream)
     # (HIP events recorded by the library around prepare | trace | resolve on this same stream);
-    # its share of the three-pass call is applied to the call time measured inside the timed region
+    # its share of the whole call (prepare | trace | resolve) is applied to the call time measured inside the timed region
     ctx.set_profiling(True)
     tr = []
     for _ in range(8):

@@ -66,7 +66,7 @@ struct bhg_context {
     size_t d_in_bytes = 0;
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
-    // per-ray workspace of the three-pass trace (prepare / event records, internal flags)
+    // per-ray workspace of the trace passes (prepare / event / resume records, internal flags)
     void *d_ws = nullptr;
     size_t d_ws_bytes = 0;
     int32_t last_launch[4] = {0, 0, 0, 0};

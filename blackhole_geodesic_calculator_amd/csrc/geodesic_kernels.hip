@@ -33,6 +33,12 @@
 
 #include "geodesic_kernels.h"
 
+// 1: the Schwarzschild trace kernels work out the start records themselves (no prepare launch); 0: every form
+// runs the prepare pass (the code is then not compiled into the trace kernels at all)
+#ifndef BHG_INLINE_PREPARE
+#define BHG_INLINE_PREPARE 1
+#endif
+
 namespace bhg {
 
 // ------------------------------------------------------------------------------------------
@@ -597,11 +603,69 @@ __device__ __forceinline__ uint64_t take_fetch(unsigned long long b, uint32_t sl
     return (local * NSLICE + slice) * 64ull;
 }
 
+// f0 = a(x0, k0), r0 and, for DP5(4), scipy's initial step (select_initial_step, common.py:68-134, order = 4)
+// for one ray that starts outside the hole.  Used converged: by the prepare pass, or by all 64 lanes of a
+// wave while it fills its ray queue.
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric &met, const double px[3],
+                                               const double pk[3], double pa[3], double &pr, double &ph)
+{
+    accel<RHS>(px, pk, met, pa, pr);
+    if (ADAPTIVE) {
+        const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
+        double isc[6];
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
+            double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
+            isc[c] = sk;
+            isc[3 + c] = sx;
+            double y0k = pk[c] * sk, y0x = px[c] * sx;
+            double f0k = pa[c] * sk, f0x = pk[c] * sx;
+            d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
+            d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
+        }
+        d0 = sqrt(d0 * (1.0 / 6.0));
+        d1 = sqrt(d1 * (1.0 / 6.0));
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, t_bound);
+        double x1[3], k1[3], f1[3], r1;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            x1[c] = __builtin_fma(h0, pk[c], px[c]);
+            k1[c] = __builtin_fma(h0, pa[c], pk[c]);
+        }
+        accel<RHS>(x1, k1, met, f1, r1);
+        double d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double dk = (f1[c] - pa[c]) * isc[c];
+            double dx = (k1[c] - pk[c]) * isc[3 + c];
+            d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
+        }
+        d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
+        double h1;
+        if (d1 <= 1e-15 && d2 <= 1e-15) {
+            h1 = fmax(1e-6, h0 * 1e-3);
+        } else {
+            double q = 0.01 / fmax(d1, d2);
+            // the fast path needs a normal fp32 range; outside it (degenerate inputs) use libm
+            h1 = (q > 1e-30 && q < 1e30) ? pow_0p2(q) : pow(q, 0.2);
+        }
+        ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, A.max_step));
+        if (!(ph >= 0.0)) ph = 0.0;  // NaN input: let the step loop fail it (STEP_TOO_SMALL / NaN flag)
+    }
+}
+
 // Fill the LDS ray queue with work items base .. base+63: coalesced loads of k0, x0 and the
 // prepare pass's record {a0, h0, r0} -- or, in a resume pass (A.worklist set), of the records the
 // resolve pass left in the rays' own slots.  Items that pass (h >= 0) are compacted with ballot/mbcnt.
+template <int RHS, bool ADAPTIVE>
 __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane, uint64_t base)
 {
+    // first pass of the Schwarzschild forms: no prepare pass has run, the wave works the records out itself
+    const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && A.inline_prepare;
     const uint64_t j = base + lane;
     double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0, pt = 0.0;
     double pE = 0.0, pL = 0.0;
@@ -633,12 +697,14 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
                 nacc = A.n_accepted[i];
             }
         } else {
-            const double *w = A.ws + i * (uint64_t)A.ws_stride;
-            pa[0] = w[0];
-            pa[1] = w[1];
-            pa[2] = w[2];
-            ph = w[3];
-            pr = w[4];
+            if (!inline_prepare) {
+                const double *w = A.ws + i * (uint64_t)A.ws_stride;
+                pa[0] = w[0];
+                pa[1] = w[1];
+                pa[2] = w[2];
+                ph = w[3];
+                pr = w[4];
+            }
             pk[0] = A.k0[i * 3 + 0];
             pk[1] = A.k0[i * 3 + 1];
             pk[2] = A.k0[i * 3 + 2];
@@ -657,6 +723,21 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
     // to assume they may still be in flight on the not-valid path and puts a vmcnt(0) in front of
     // the step code, which then waits for the previous iteration's result stores every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && j < A.n_items) {
+        if (A.object_id) A.object_id[i] = (int8_t)-1;
+        const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+        if (r0 <= A.r_hor) {
+            // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313): final at once, never queued
+            store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+        } else {
+            Metric met;
+            met.r_s = A.r_s;
+            met.M = 0.5 * A.r_s;
+            met.a = met.E = met.L = 0.0;
+            ph = 0.0;
+            initial_record<RHS, ADAPTIVE>(A, met, px, pk, pa, pr, ph);
+        }
+    }
     const bool valid = ph >= 0.0;
     const uint64_t vmask = __ballot(valid);
     if (valid) {
@@ -682,6 +763,7 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
 }
 
 // Give idle lanes new rays.  Returns the idle mask afterwards (all ones: nothing left at all).
+template <int RHS, bool ADAPTIVE>
 __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave &W, Lane &L, uint32_t lane,
                                            uint64_t idle)
 {
@@ -697,7 +779,7 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
                 if (++W.dry == NSLICE) W.exhausted = true;
                 continue;
             }
-            fill_batch(A, Q, W, lane, base);
+            fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, base);
             if (W.q_count == 0) continue;
         }
         const int n_idle = __builtin_popcountll(idle);
@@ -1139,7 +1221,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
 // Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
 // ------------------------------------------------------------------------------------------
 #ifndef BHG_DP54_WAVES_PER_SIMD
-#define BHG_DP54_WAVES_PER_SIMD 2
+#define BHG_DP54_WAVES_PER_SIMD 4
 #endif
 #ifndef BHG_KERR_WAVES_PER_SIMD
 #define BHG_KERR_WAVES_PER_SIMD 2
@@ -1180,7 +1262,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
-            idle = refill(A, Q, W, L, lane, idle);
+            idle = refill<RHS, true>(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
         }
 #ifdef BHG_DIAG
@@ -1324,7 +1406,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
-            idle = refill(A, Q, W, L, lane, idle);
+            idle = refill<RHS, false>(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;
         }
         if (L.active) {
@@ -1453,52 +1535,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         w[3] = -1.0;
         return;
     }
-    accel<RHS>(px, pk, met, pa, pr);
-    if (ADAPTIVE) {
-        const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;
-        double isc[6];
-        double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double sk = rcp_nr(__builtin_fma(fabs(pk[c]), rtol, atol));
-            double sx = rcp_nr(__builtin_fma(fabs(px[c]), rtol, atol));
-            isc[c] = sk;
-            isc[3 + c] = sx;
-            double y0k = pk[c] * sk, y0x = px[c] * sx;
-            double f0k = pa[c] * sk, f0x = pk[c] * sx;
-            d0 = __builtin_fma(y0k, y0k, __builtin_fma(y0x, y0x, d0));
-            d1 = __builtin_fma(f0k, f0k, __builtin_fma(f0x, f0x, d1));
-        }
-        d0 = sqrt(d0 * (1.0 / 6.0));
-        d1 = sqrt(d1 * (1.0 / 6.0));
-        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-        h0 = fmin(h0, t_bound);
-        double x1[3], k1[3], f1[3], r1;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            x1[c] = __builtin_fma(h0, pk[c], px[c]);
-            k1[c] = __builtin_fma(h0, pa[c], pk[c]);
-        }
-        accel<RHS>(x1, k1, met, f1, r1);
-        double d2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            double dk = (f1[c] - pa[c]) * isc[c];
-            double dx = (k1[c] - pk[c]) * isc[3 + c];
-            d2 = __builtin_fma(dk, dk, __builtin_fma(dx, dx, d2));
-        }
-        d2 = sqrt(d2 * (1.0 / 6.0)) / h0;
-        double h1;
-        if (d1 <= 1e-15 && d2 <= 1e-15) {
-            h1 = fmax(1e-6, h0 * 1e-3);
-        } else {
-            double q = 0.01 / fmax(d1, d2);
-            // the fast path needs a normal fp32 range; outside it (degenerate inputs) use libm
-            h1 = (q > 1e-30 && q < 1e30) ? pow_0p2(q) : pow(q, 0.2);
-        }
-        ph = fmin(fmin(100.0 * h0, h1), fmin(t_bound, A.max_step));
-        if (!(ph >= 0.0)) ph = 0.0;  // NaN input: let the step loop fail it (STEP_TOO_SMALL / NaN flag)
-    }
+    initial_record<RHS, ADAPTIVE>(A, met, px, pk, pa, pr, ph);
     w[0] = pa[0];
     w[1] = pa[1];
     w[2] = pa[2];
@@ -1791,12 +1828,17 @@ __global__ void accel_kernel(const double *x, const double *k, double r_s, uint6
 // Launchers
 // ------------------------------------------------------------------------------------------
 template <int RHS, int EVT>
-static hipError_t launch_variant(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev)
+static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    const unsigned gp = (unsigned)((a.n_items + 255) / 256), gr = (unsigned)((a.n_items + 63) / 64);
-    const bool first = a.worklist == nullptr;  // resume passes skip the prepare pass
+    const unsigned gp = (unsigned)((a_in.n_items + 255) / 256), gr = (unsigned)((a_in.n_items + 63) / 64);
+    const bool first = a_in.worklist == nullptr;  // resume passes skip the prepare pass
+    // Schwarzschild forms: the trace kernel's waves work out the start records themselves while they fill
+    // their ray queues (converged, 64 lanes wide) -- no prepare launch, no 40-byte record round trip per ray.
+    // Kerr keeps the prepare pass (Cartesian -> Boyer-Lindquist, E and L: trig-heavy, 200 registers).
+    TraceArgs a = a_in;
+    a.inline_prepare = (first && RHS != BHG_RHS_KERR_BL_ && BHG_INLINE_PREPARE) ? 1 : 0;
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (first) {
+    if (first && !a.inline_prepare) {
         if (method == BHG_METHOD_RK4_)
             hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
         else

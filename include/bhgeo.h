@@ -218,8 +218,9 @@ int bhg_synchronize(bhg_context *ctx);
 /* The context's own non-blocking stream (a hipStream_t), used by the host-buffer calls. */
 void *bhg_context_stream(bhg_context *ctx);
 
-/* Per-pass timing of the trace calls.  A trace call runs three passes on the caller's stream:
- * PREPARE (per-ray setup: f0, initial step), TRACE (the integrate loop; the dominant kernel) and
+/* Per-pass timing of the trace calls.  A trace call runs up to three passes on the caller's stream:
+ * PREPARE (per-ray setup: f0, initial step -- its own launch for BHG_RHS_KERR_BL only; the Schwarzschild
+ * forms do it inside TRACE and report 0 here), TRACE (the integrate loop; the dominant kernel) and
  * RESOLVE (root search for rays that ended on an event).  With profiling enabled the library
  * records HIP events around each pass on that stream; bhg_last_pass_ms() waits for the last call's
  * events and returns {prepare, trace, resolve} in milliseconds. */
