@@ -19,8 +19,24 @@ import numpy as np
 from .raygen import camera_directions, python_random_stream
 
 
+def disk_colour(loc, r_in, r_out, texture=None, disk_phase=0.0, disk_mean=0.2, disk_stddev=0.3, disk_intensity=1.0):
+    """Colour of thin-disk hits, the Limited engine's checkHitDisk + :300
+    (LimitedRelativisticRenderEngine.py:427-436): rgb = texture(texture_x, scale) * intensity with
+    scale = (R - R_in)/(R_out - R_in), a Gaussian radial profile and texture_x = (phase + acos(x/R) sign(y))/pi.
+    loc [n, 3] are crossing points (BH-centred); texture(u[n], v[n]) -> rgb[n, 3] or None for white.
+    (sign(0) is taken as +1 where the reference divides 0/0.)"""
+    loc = np.asarray(loc, dtype=np.float64)
+    x, y = loc[..., 0], loc[..., 1]
+    R = np.sqrt(x * x + y * y)
+    scale = (R - r_in) / (r_out - r_in)
+    intensity = disk_intensity * np.exp(-((scale - disk_mean) ** 2) / (2 * disk_stddev ** 2)) / np.sqrt(2 * np.pi * disk_stddev)
+    texture_x = (disk_phase + np.arccos(np.clip(x / R, -1.0, 1.0)) * np.where(y < 0.0, -1.0, 1.0)) / np.pi
+    rgb = np.ones(loc.shape[:-1] + (3,)) if texture is None else np.asarray(texture(texture_x, scale), dtype=np.float64)
+    return rgb * intensity[..., None]
+
+
 def spacetime_ray_cast_batch(integrator, origin, directions, bh_loc=(0.0, 0.0, 0.0), max_step=np.inf,
-                             curve_end=50.0, spheres=None, return_objects=False):
+                             curve_end=50.0, spheres=None, return_objects=False, disk=None):
     """Batched form of spacetime_ray_cast (RelativisticRenderEngine.py:271-313).
 
     origin: camera world position [3]; directions [..., 3] unit vectors.
@@ -30,18 +46,21 @@ def spacetime_ray_cast_batch(integrator, origin, directions, bh_loc=(0.0, 0.0, 0
     origin, :278), hit is True where the curve entered a sphere; end_loc is then the entry point (world
     coordinates minus bh_loc, like every end_loc) and end_dir the direction there.  return_objects=True
     appends (normal [..., 3], index [...]) -- the `normal`, `index` a scene.ray_cast hit carries (:441).
+    disk=(R_in, R_out): thin disk in the hole's z = 0 plane (LimitedRelativisticRenderEngine.py:283-286); rays
+    that end on it have index == -2, hit == False, and end_loc = the crossing point.
     A camera inside the hole gives hit_bh == True for every ray (:311-313); end_dir/end_loc then hold
     the start values.
     """
     bh = np.asarray(bh_loc, dtype=np.float64)
     origin = np.asarray(origin, dtype=np.float64) - bh  # :278
+    kw = {} if disk is None else {"disk": (float(disk[0]), float(disk[1]))}
     if spheres is not None and len(spheres):
         sp = np.array(spheres, dtype=np.float64).reshape(-1, 4)
         sp[:, 0:3] -= bh
-        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end, spheres=sp)
+        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end, spheres=sp, **kw)
     else:
         sp = None
-        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end)
+        out = integrator.trace(directions, origin, max_step=max_step, curve_end=curve_end, **kw)
     end = out["ray_end"]
     hit_bh = out["ray_blackhole_hit"].astype(bool)
     if sp is None:
@@ -53,6 +72,8 @@ def spacetime_ray_cast_batch(integrator, origin, directions, bh_loc=(0.0, 0.0, 0
         hit = index >= 0
         c = sp[np.maximum(index, 0)]
         normal = np.where(hit[..., None], (end[..., 0:3] - c[..., 0:3]) / c[..., 3:4], 0.0)
+    if disk is not None:
+        index = np.where(out["flags"] == 128, np.int8(-2), index).astype(np.int8)   # BHG_FLAG_HIT_DISK
     if return_objects:
         return hit, hit_bh, end[..., 3:6], end[..., 0:3], normal, index
     return hit, hit_bh, end[..., 3:6], end[..., 0:3]
@@ -63,7 +84,8 @@ class FrameTracer:
 
     def __init__(self, integrator, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
                  origin=(0.0, 0.0, 0.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0),
-                 max_step=np.inf, curve_end=50.0, mark=None, spheres=None, object_hit=None):
+                 max_step=np.inf, curve_end=50.0, mark=None, spheres=None, object_hit=None, disk=None,
+                 disk_hit=None):
         self.integrator = integrator
         self.width, self.height, self.samples = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
@@ -77,6 +99,10 @@ class FrameTracer:
         # object_hit(loc[n,3], normal[n,3], index[n]) -> rgb[n,3], the vectorised spacetime_hit (:240, :317)
         self.spheres = spheres
         self.object_hit = object_hit
+        # thin disk (Limited engine, :283-300): disk=(R_in, R_out), disk_hit(loc[n,3]) -> rgb[n,3]
+        # (default: disk_colour with a white texture)
+        self.disk = disk
+        self.disk_hit = disk_hit
         self.last_counters = None
 
     # the jitter stream depends only on (seed, window, S): cache it across frames (:189 re-seeds
@@ -104,9 +130,13 @@ class FrameTracer:
                 d = dirs[s][np.ix_(rows, cols)]  # [R, C, 3]
                 hit, hit_bh, end_dir, end_loc, normal, index = spacetime_ray_cast_batch(
                     self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end,
-                    spheres=self.spheres, return_objects=True)
+                    spheres=self.spheres, return_objects=True, disk=self.disk)
                 colour = np.zeros(d.shape)
-                esc = ~hit_bh & ~hit   # :239-246: hit -> spacetime_hit, hit_bh -> black, else background
+                on_disk = index == -2
+                esc = ~hit_bh & ~hit & ~on_disk   # :239-246: hit -> spacetime_hit, hit_bh -> black, else background
+                if on_disk.any():
+                    shade = self.disk_hit or (lambda loc: disk_colour(loc, self.disk[0], self.disk[1]))
+                    colour[on_disk] = np.asarray(shade(end_loc[on_disk]), dtype=np.float64)
                 if esc.any():
                     colour[esc] = np.asarray(background_hit(end_dir[esc]), dtype=np.float64)
                 if hit.any() and self.object_hit is not None:

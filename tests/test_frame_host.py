@@ -14,12 +14,20 @@ class StubIntegrator:
     def __init__(self, cone=0.05):
         self.cone, self.calls = cone, 0
 
-    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, spheres=None):
+    def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, spheres=None, disk=None):
         self.calls += 1
         k0 = np.asarray(k0, float)
         end = np.concatenate([np.asarray(x0) + curve_end * k0, k0], axis=-1)
         hit = (np.hypot(k0[..., 0], k0[..., 1]) < self.cone).astype(np.uint8)
-        out = {"ray_end": end, "ray_blackhole_hit": hit, "flags": hit, "n_steps": hit * 0, "n_accepted": hit * 0}
+        flags = hit.copy()
+        if disk is not None:   # straight lines through the plane z = 0
+            t = -np.asarray(x0)[2] / k0[..., 2]
+            loc = np.asarray(x0) + t[..., None] * k0
+            R = np.hypot(loc[..., 0], loc[..., 1])
+            on = (t > 0) & (t < curve_end) & (R >= disk[0]) & (R <= disk[1]) & (hit == 0)
+            end[on, 0:3] = loc[on]
+            flags = np.where(on, np.uint8(128), flags).astype(np.uint8)
+        out = {"ray_end": end, "ray_blackhole_hit": hit, "flags": flags, "n_steps": hit * 0, "n_accepted": hit * 0}
         if spheres is not None:   # closed-form straight-line entry points
             t_best = np.full(k0.shape[:-1], np.inf)
             idx = np.full(k0.shape[:-1], -1, np.int8)
@@ -207,3 +215,26 @@ def test_frame_tracer_objects_fill_the_collision_stub():
     assert not hit.any()                                                                     # the stub's `hit = False`
     hit, *_ = spacetime_ray_cast_batch(StubIntegrator(), CAM + bh, d, bh, spheres=sph_world)
     assert hit.any() and not (hit & hit_bh).any()
+
+
+def test_frame_tracer_disk_colour():
+    """disk=(R_in, R_out): pixels whose ray ends on the disk get the Limited engine's disk colour
+    (checkHitDisk profile); everything else is unchanged."""
+    from blackhole_geodesic_calculator_amd.frame import FrameTracer, disk_colour
+    W, H, S = 24, 20, 1
+    base = FrameTracer(StubIntegrator(), W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM)
+    withdisk = FrameTracer(StubIntegrator(), W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM, disk=(3.0, 7.0))
+    b0, b1 = np.ones((H, W, 4)), np.ones((H, W, 4))
+    list(base.ray_trace(b0, sky))
+    list(withdisk.ray_trace(b1, sky))
+    d = base.directions()[0]
+    t = -CAM[2] / d[..., 2]
+    loc = CAM + t[..., None] * d
+    R = np.hypot(loc[..., 0], loc[..., 1])
+    on = (R >= 3.0) & (R <= 7.0)
+    assert on.sum() > 20
+    assert np.allclose(b1[on][:, 0:3], disk_colour(loc[on], 3.0, 7.0))
+    assert np.array_equal(b1[~on], b0[~on])
+    # the profile: white texture, peak where scale == mean
+    c = disk_colour(np.array([[3.0 + 0.2 * 4.0, 0.0, 0.0]]), 3.0, 7.0)
+    assert np.allclose(c, 1.0 / np.sqrt(2 * np.pi * 0.3))
