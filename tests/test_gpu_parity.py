@@ -475,7 +475,11 @@ def test_randomised_kerr(ctx, oracle, seed):
     d = np.abs(end - o["end"]).max(1)
     tol = 1e-9 + 1e4 * _sensitivity(oracle, k, cam, o["end"], **kw) + np.where((o["flags"] & 1) != 0, 1e-5, 0.0)
     ok = same & np.isfinite(o["end"]).all(1)
-    assert (d[ok] > tol[ok]).mean() <= 0.01 and np.median(d[ok]) < 1e-7
+    assert (d[ok] > tol[ok]).mean() <= 0.01
+    # the typical agreement, over rays that do not end on the horizon (there the Boyer-Lindquist end state is
+    # singular: u^r, u^phi grow without bound and differences of 1e-6 are rounding, see the tolerance above)
+    away = ok & ((o["flags"] & 1) == 0)
+    assert np.median(d[away]) < 1e-7 if away.any() else True
 
 
 def test_gpu_error_against_converged_solution(ctx, oracle):
