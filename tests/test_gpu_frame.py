@@ -198,3 +198,20 @@ def test_relativistic_camera_on_gpu(ctx, oracle, tmp_path):
     assert cam.ray_blackhole_hit.sum() > 20 and cam.ray_end[0, 0, 3:6].shape == (3,)
     cam.save(tmp_path / "c.pkl")
     assert np.array_equal(RelativisticCamera().load(tmp_path / "c.pkl").ray_end, cam.ray_end)
+
+
+def test_c_example_runs_on_the_gpu(tmp_path):
+    """examples/trace_frame.c: the C ABI from plain C, end to end."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "blackhole_geodesic_calculator_amd")
+    exe = tmp_path / "trace_frame"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "trace_frame.c"), "-L", libdir, "-lbhgeo",
+                           "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    head = r.stdout.splitlines()[0]
+    assert "6144 rays" in head and " 0 other" in head
+    assert "#" in r.stdout and "o" in r.stdout.split("\n", 1)[1]

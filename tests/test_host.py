@@ -114,3 +114,20 @@ def test_public_header_is_plain_c(tmp_path):
     assert int(out[0]) == ctypes.sizeof(_ffi.Params) == 96
     assert int(out[1]) == ctypes.sizeof(_ffi.Scene)
     assert int(out[2]) == _ffi.ABI_VERSION and int(out[3]) == _ffi.MAX_SPHERES
+
+
+def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    """examples/trace_frame.c links against libbhgeo.so from plain C; without a device it must stop with the
+    no-device message (exit code 3), never produce results."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "blackhole_geodesic_calculator_amd")
+    exe = tmp_path / "trace_frame"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "trace_frame.c"), "-L", libdir, "-lbhgeo",
+                           "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)])
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the example would run")
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
