@@ -213,5 +213,5 @@ def test_c_example_runs_on_the_gpu(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     head = r.stdout.splitlines()[0]
-    assert "6144 rays" in head and " 0 other" in head
+    assert "6144 rays" in head and " 0 left the region" in head   # curve_end 60 ends the far-side rays before r = 40
     assert "#" in r.stdout and "o" in r.stdout.split("\n", 1)[1]
