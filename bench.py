@@ -295,6 +295,17 @@ def main():
                 "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
+        if world == 1 and a.workload == "frame":
+            # the host-buffer entry point (numpy in, numpy out: what the reference's Python caller would use),
+            # H2D + passes + D2H over PCIe -- reported beside `value`, never as `value`
+            k_host = fr.d_k0.cpu().numpy()
+            ctx.trace(k_host[:65536], cam, params)
+            t = time.perf_counter()
+            ctx.trace(k_host, cam, params)
+            th = time.perf_counter() - t
+            out["host_buffer_call"] = {"value": n / th / 1e6, "unit": "Mrays/s", "ms": th * 1e3,
+                                       "what": "bhg_trace on pageable numpy arrays, PCIe-inclusive (H2D k0, D2H end/flags/steps)"}
+            del k_host
         if a.cpu_seconds > 0 and world == 1:   # the CPU baseline is an N = 1 figure (rank 0's host cores, nothing else running)
             if a.workload == "orbit":
                 okw["spheres"] = orbit_scene(a.steps - 1)[0]
@@ -323,30 +334,62 @@ def pmc_traffic(a, method):
         return None
 
 
+def effective_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs under a 16-CPU quota; 128 OpenMP threads there only add throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def cpu_baseline(k0, cam, a, kw):
     """The C oracle (a port of the algorithm, see oracle/geodesic_oracle.c) timed on this host's
     cores on a bounded sample of the same rays.  Reported baseline only; never the thing shipped."""
     from oracle import oracle as oc
     oc.build()
-    cores = oc.num_threads()
+    cores = min(oc.num_threads(), effective_cores())
     n = len(k0)
     probe = k0[:: max(1, n // 16384)]
     t = time.perf_counter()
-    oc.trace(probe, cam, **kw)
+    oc.trace(probe, cam, n_threads=cores, **kw)
     rate = len(probe) / (time.perf_counter() - t)
     m = int(min(n, max(len(probe), rate * a.cpu_seconds)))
     stride = max(1, n // m)
     sample = np.ascontiguousarray(k0[::stride])
     t = time.perf_counter()
-    o = oc.trace(sample, cam, **kw)
+    o = oc.trace(sample, cam, n_threads=cores, **kw)
     dt = time.perf_counter() - t
+    # the same port on ONE core (SURVEY.md section 8d asks for both): a smaller sample of the same rays
+    m1 = int(max(256, min(len(sample), len(sample) / dt / max(cores, 1) * 3.0)))   # about 3 s
+    s1 = np.ascontiguousarray(sample[:: max(1, len(sample) // m1)])
+    t = time.perf_counter()
+    o1 = oc.trace(s1, cam, n_threads=1, **kw)
+    dt1 = time.perf_counter() - t
     return {
         "value": len(sample) / dt / 1e6,
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
         "ray_steps_per_s": float(o["n_attempted"].sum()) / dt,
-        "sample": f"every {stride}th ray of rank 0's {n} rays ({len(sample)} rays, {dt:.1f} s, OpenMP over rays)",
+        "sample": f"every {stride}th ray of rank 0's {n} rays ({len(sample)} rays, {dt:.1f} s, OpenMP over rays, {cores} threads = "
+                  f"affinity/cgroup-quota cores of {os.cpu_count()} logical CPUs)",
+        "single_core": {"value": len(s1) / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                        "ray_steps_per_s": float(o1["n_attempted"].sum()) / dt1,
+                        "sample": f"{len(s1)} of those rays, {dt1:.1f} s, one thread"},
     }
 
 
