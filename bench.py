@@ -61,8 +61,8 @@ def parse():
     a.width = a.width or dw
     a.height = a.height or a.width
     a.samples = a.samples or ds
-    if a.workload != "frame" and a.rhs == "kerr":
-        ap.error("disk / objects are Schwarzschild-only")
+    if a.workload == "orbit" and a.rhs == "kerr":
+        ap.error("object spheres are Schwarzschild-only")
     return a
 
 

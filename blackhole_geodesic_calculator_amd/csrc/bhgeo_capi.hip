@@ -114,7 +114,6 @@ int validate(const bhg_params *p)
     if (p->rhs_form == BHG_RHS_KERR_BL) {
         if (!std::isfinite(p->spin) || !(std::fabs(p->spin) < 0.5 * p->r_s))
             return fail(BHG_E_INVALID, "Kerr needs |spin| < M = r_s/2");
-        if (p->disk_r_out > 0.0) return fail(BHG_E_INVALID, "the disk event is not available with BHG_RHS_KERR_BL");
     }
     if (!(p->disk_r_in >= 0.0) || !(p->disk_r_out >= 0.0) || !std::isfinite(p->disk_r_in) || !std::isfinite(p->disk_r_out))
         return fail(BHG_E_INVALID, "disk radii must be finite and >= 0");
@@ -416,6 +415,10 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
             HIP_TRY(hipMemsetAsync(&w_count[(pass + 1) & 1], 0, sizeof(cnt), s));
             HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)g2, s, nullptr));
         }
+    }
+    if (p->rhs_form == BHG_RHS_KERR_BL) {
+        a.n_items = n;
+        HIP_TRY(bhg::launch_kerr_finalize(a, s));
     }
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;

@@ -91,6 +91,8 @@ hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
 // evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event, bit 2 = object spheres (then all three)
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
+// Kerr: after the last pass of a call, Boyer-Lindquist end states -> Cartesian
+hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,

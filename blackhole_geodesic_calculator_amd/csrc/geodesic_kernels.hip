@@ -495,6 +495,21 @@ __device__ __forceinline__ bool sphere_candidate(const double sp[4], const doubl
     return bb > 0.0 && bb < cc && (d0 - rho2) * cc < bb * bb;
 }
 
+// Did the step cross the disk plane z = 0?  Cartesian forms: sign change of z (either end on the plane counts,
+// like a scipy event).  Boyer-Lindquist: z = r cos(theta) with r > 0 changes sign when theta moves from one
+// interval [pi/2 + k pi, pi/2 + (k+1) pi) to another -- an integer comparison, no trigonometry in the loop
+// (cos(theta) is never exactly 0 for a double theta, so the closed/open ends cannot matter).
+template <int RHS>
+__device__ __forceinline__ bool crossed_disk_plane(const double x0[3], const double x1[3])
+{
+    if (RHS == BHG_RHS_KERR_BL_) {
+        const double k0 = floor((x0[1] - 1.5707963267948966) * 0.3183098861837907);
+        const double k1 = floor((x1[1] - 1.5707963267948966) * 0.3183098861837907);
+        return k0 != k1;
+    }
+    return ((x0[2] <= 0.0) && (x1[2] >= 0.0)) || ((x0[2] >= 0.0) && (x1[2] <= 0.0));
+}
+
 // A step that crosses the disk plane z = 0 needs the resolve pass only if the crossing can lie in the annulus.
 // The crossing point of the step's dense output lies within delta of the chord's crossing point, where
 // delta = 2 |h| (|v0 - c| + |v1 - c|), c = (x1 - x0) / h the chord velocity: a curve whose velocity stays within
@@ -969,7 +984,7 @@ __device__ __forceinline__ double dp54_factor(double errsq)
 template <class GR, class GZ, class POS, class EV>
 __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind, uint32_t idx, double t, double t_new,
                                               const double x0[3], const double x1[3], const GR &g_r, const GZ &g_z,
-                                              const POS &pos, const EV &eval)
+                                              const POS &pos, const EV &eval, bool bl)
 {
     double best = __builtin_inf();
     uint32_t fl = 0;
@@ -992,7 +1007,8 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
         const double r = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
         double xe[3];
         pos(r, xe);
-        const double R = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+        // cylindrical radius of the crossing point; Boyer-Lindquist: sqrt(x^2 + y^2) = sqrt(r^2 + a^2) |sin theta|
+        const double R = bl ? sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sin(xe[1])) : sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
         if (R >= A.disk_r_in && R <= A.disk_r_out && r < best) {
             best = r;
             fl = BHG_FLAG_HIT_DISK_;
@@ -1091,11 +1107,18 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
     }
     const bool ended = settle_events(
         A, kind, idx, t, t_new, x, xn, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
-        [&](double tt) { return dense_z(d, tt); }, [&](double tt, double xe[3]) { dense_pos(d, tt, xe); },
+        [&](double tt) {
+            if (RHS != BHG_RHS_KERR_BL_) return dense_z(d, tt);
+            double q[3];
+            dense_pos(d, tt, q);
+            return cos(q[1]);  // z = r cos(theta), r > 0
+        },
+        [&](double tt, double xe[3]) { dense_pos(d, tt, xe); },
         [&](double tt, double xe[3], double ve[3]) {
             dense_pos(d, tt, xe);
             dense_dir(d, tt, ve);
-        });
+        },
+        RHS == BHG_RHS_KERR_BL_);
     if (!ended) finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
 }
 
@@ -1181,13 +1204,13 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
         [&](double tt) {
             double xx[3], vv[3];
             hermite_eval(d, tt, xx, vv);
-            return xx[2];
+            return RHS == BHG_RHS_KERR_BL_ ? cos(xx[1]) : xx[2];
         },
         [&](double tt, double xe[3]) {
             double vv[3];
             hermite_eval(d, tt, xe, vv);
         },
-        [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); });
+        [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); }, RHS == BHG_RHS_KERR_BL_);
     if (!ended) finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
 }
 
@@ -1330,11 +1353,11 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                       ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                    bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
-                                      (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
-                                                           ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
+                    bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
+                                crossed_disk_plane<RHS>(L.x, xn);
                     const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                    if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) && !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                    if ((EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && ev_d && !(ev_h || ev_e || ev_o) &&
+                        !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
                         ev_d = false;
                     if (ev_h || ev_e || ev_d || ev_o) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
@@ -1432,11 +1455,10 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
                                   ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                bool ev_d = (EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
-                                      (((L.x[2] <= 0.0) && (xn[2] >= 0.0)) ||
-                                                       ((L.x[2] >= 0.0) && (xn[2] <= 0.0)));
+                bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
                 const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) && !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                if ((EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && ev_d && !(ev_h || ev_e || ev_o) &&
+                    !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
                     ev_d = false;
                 if (ev_h || ev_e || ev_d || ev_o) {
                     L.n_acc = L.n_att;
@@ -1854,9 +1876,15 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
         hipLaunchKernelGGL((resolve_kernel<RHS, false>), dim3(gr), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL((resolve_kernel<RHS, true>), dim3(gr), dim3(64), 0, s, a);
-    if (RHS == BHG_RHS_KERR_BL_)
-        hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
     if (ev) (void)hipEventRecord(ev[3], s);
+    return hipGetLastError();
+}
+
+// Kerr: once ALL passes of a call are done, turn the Boyer-Lindquist end states into Cartesian ones
+hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1894,18 +1922,26 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
 
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    if (rhs == BHG_RHS_KERR_BL_)  // Kerr: horizon + optional exit sphere only (the C-ABI layer rejects a disk)
-        return (evt & 1) ? launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev)
-                         : launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
+    if (rhs == BHG_RHS_KERR_BL_) {  // Kerr: horizon, optional exit sphere, optional disk (no object spheres)
+        switch (evt & 3) {
+        case 0: return launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
+        case 1: return launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev);
+        default: return launch_variant<BHG_RHS_KERR_BL_, 3>(a, method, grid, s, ev);
+        }
+    }
     return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
 
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {
-    if (rhs == BHG_RHS_KERR_BL_)
-        return (evt & 1) ? occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu)
-                         : occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
+    if (rhs == BHG_RHS_KERR_BL_) {
+        switch (evt & 3) {
+        case 0: return occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
+        case 1: return occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu);
+        default: return occupancy_variant<BHG_RHS_KERR_BL_, 3>(method, blocks_per_cu);
+        }
+    }
     return rhs == BHG_RHS_REDUCED_ ? occupancy_rhs<BHG_RHS_REDUCED_>(method, evt, blocks_per_cu)
                                    : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }

@@ -98,7 +98,9 @@ typedef struct bhg_params {
     uint32_t reserved;  /* must be 0 */
     double disk_r_in;   /* thin disk in the plane z = 0 (BH-centred frame): the ray ends at its first */
     double disk_r_out;  /* crossing with R_in <= sqrt(x^2+y^2) <= R_out; off when disk_r_out == 0
-                           (disk_on / R_in / R_out of LimitedRelativisticRenderEngine.py:283-286) */
+                           (disk_on / R_in / R_out of LimitedRelativisticRenderEngine.py:283-286).  With
+                           BHG_RHS_KERR_BL: the equatorial plane theta = pi/2 (z = r cos theta = 0), the
+                           annulus in the cylindrical radius sqrt(r^2 + a^2) */
     double spin;        /* Kerr a in length units, |a| < M = r_s/2 (BHG_RHS_KERR_BL only) */
 } bhg_params;
 

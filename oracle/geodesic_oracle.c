@@ -361,7 +361,7 @@ static double ev_eval(const evfun_t *e, double t)
         dense_eval(e->dn, t, y);
     else
         hermite_eval(e->hm, t, y);
-    if (e->zmode == 1) return y[5];
+    if (e->zmode == 1) return e->rc->kerr ? cos(y[3]) : y[5]; /* z = r cos(theta), r > 0 */
     if (e->zmode == 2) {
         double dx = y[1] - e->c[0], dy = y[3] - e->c[1], dz = y[5] - e->c[2];
         return sqrt(dx * dx + dy * dy + dz * dz) - e->R;
@@ -443,11 +443,14 @@ static void pack_end(const double y[6], double end[6])
    (LimitedRelativisticRenderEngine.py:423-424), otherwise the ray carries on.  Of the terminal candidates
    the earliest root wins (handle_events sorts the roots, ivp.py:111-122); ties keep the order horizon,
    exit, disk, sphere 0, 1, ...  Returns 0 = carry on, else the flag; *t_root, y_root, *obj filled. */
+static int e_kerr(const evfun_t *b) { return b->rc->kerr; }
+
 static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, double g_e,
                              double g_e_new, const double y_old[6], const double y_new[6], const evfun_t *base,
                              double t_old, double t, double *t_root, double y_root[6], int *obj)
 {
-    const double z_old = y_old[5], z_new = y_new[5];
+    /* disk plane z = 0: Cartesian z, or the sign of cos(theta) in Boyer-Lindquist coordinates */
+    const double z_old = e_kerr(base) ? cos(y_old[3]) : y_old[5], z_new = e_kerr(base) ? cos(y_new[3]) : y_new[5];
     int hor = ((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0));
     int ext = (p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0); /* direction = +1 */
     int dsk = (p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0)));
@@ -472,7 +475,7 @@ static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, d
         double r = brentq(&e, t_old, t);
         double y[6];
         if (e.kind == 0) dense_eval(e.dn, r, y); else hermite_eval(e.hm, r, y);
-        double R = sqrt(y[1] * y[1] + y[3] * y[3]);
+        double R = e.rc->kerr ? sqrt(y[1] * y[1] + e.rc->a * e.rc->a) * fabs(sin(y[3])) : sqrt(y[1] * y[1] + y[3] * y[3]);
         if (R >= p->disk_r_in && R <= p->disk_r_out && r < best) { best = r; best_flag = BHGO_FLAG_HIT_DISK; }
     }
     for (int j = 0; j < p->n_spheres && !e.rc->kerr; j++) {
@@ -636,7 +639,7 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
 
         double g_h_new = radius(rc, y) - rc->r_hor;
         double g_e_new = radius(rc, y) - p->r_exit;
-        double z_old = y_old[5], z_new = y[5];
+        double z_old = rc->kerr ? cos(y_old[3]) : y_old[5], z_new = rc->kerr ? cos(y[3]) : y[5];
         dense_t dn;
         evfun_t base = {0, &dn, NULL, 0.0, 0, rc, {0, 0, 0}};
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||

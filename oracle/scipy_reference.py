@@ -365,8 +365,12 @@ def kerr_constants(q, u, M, a):
 KERR_HORIZON_MARGIN = 1e-3  # terminal event at r = r_plus (1 + margin): BL coordinates are singular at r_plus
 
 
-def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, method="RK45"):
-    """One null geodesic in Kerr; state y = [ur, r, uth, th, uph, ph]; Cartesian in, Cartesian out."""
+def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, method="RK45",
+                   disk=None):
+    """One null geodesic in Kerr; state y = [ur, r, uth, th, uph, ph]; Cartesian in, Cartesian out.
+    disk=(R_in, R_out): thin disk in the equatorial plane z = r cos(th) = 0, annulus in the cylindrical
+    radius sqrt(x^2 + y^2) = sqrt(r^2 + a^2) |sin th|; a NON-terminal event g = cos(th), the first crossing
+    inside the annulus ends the ray there (same rule as trace_ray's disk)."""
     fn = kerr_rhs_lambdified()
     q0, u0 = cart_to_bl(x0, k0, a)
     r_plus = M + np.sqrt(M * M - a * a)
@@ -385,16 +389,33 @@ def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol
         return y[1] - r_h
 
     ev.terminal = True
+    events = [ev]
+    if disk is not None:
+        def ev_disk(_t, y):
+            return np.cos(y[3])
+
+        events.append(ev_disk)
     y0 = np.array([u0[0], q0[0], u0[1], q0[1], u0[2], q0[2]])
-    sol = solve_ivp(rhs, (0.0, lambda_end), y0, method=method, events=[ev], max_step=max_step, rtol=rtol, atol=atol)
+    sol = solve_ivp(rhs, (0.0, lambda_end), y0, method=method, events=events, max_step=max_step, rtol=rtol, atol=atol)
+    n_acc_disk = None
     if sol.status == 1:
         flags, te, ye = FLAG_HIT_HORIZON, sol.t_events[0][-1], sol.y_events[0][-1]
     elif sol.status == 0:
         flags, te, ye = FLAG_REACHED_END, sol.t[-1], sol.y[:, -1]
     else:
         flags, te, ye = FLAG_STEP_TOO_SMALL, sol.t[-1], sol.y[:, -1]
+    if disk is not None:
+        for td, yd in zip(sol.t_events[1], sol.y_events[1]):
+            R = np.sqrt(yd[1] * yd[1] + a * a) * abs(np.sin(yd[3]))
+            if disk[0] <= R <= disk[1] and td <= te:
+                flags, te, ye = FLAG_HIT_DISK, td, yd
+                n_acc_disk = int(np.searchsorted(sol.t, td, side="left"))
+                break
     xe, ke = bl_to_cart((ye[1], ye[3], ye[5]), (ye[0], ye[2], ye[4]), a)
     out.update(flags=flags, end=np.concatenate([xe, ke]), end_bl=np.array([ye[1], ye[3], ye[5], ye[0], ye[2], ye[4]]),
                t_end=float(te), nfev=int(sol.nfev), n_attempted=(int(sol.nfev) - 2) // 6 if method == "RK45" else -1,
                n_accepted=len(sol.t) - 1, E=E, L=L, sol=sol)
+    if n_acc_disk is not None:
+        out["n_accepted"] = n_acc_disk
+        out["n_attempted"] = -1  # scipy integrated on past the disk
     return out

@@ -221,6 +221,27 @@ def main_kerr():
          n_accepted=np.array([s[5] for s in sets], np.uint32), t_end=np.array([s[6] for s in sets]))
 
 
+def main_kerr_disk():
+    # ---- 12. Kerr a/M = 0.9 with a thin disk in the equatorial plane (config 3 x config 5): scipy event
+    # g = cos(theta) on the Boyer-Lindquist solve, annulus in the cylindrical radius; three inclinations ----
+    M, a = 0.5, 0.45
+    rng = np.random.default_rng(12)
+    ks, xs = [], []
+    for inc_deg in (80.0, 60.0, 20.0):
+        inc = math.radians(inc_deg)
+        cam = np.array([30 * math.sin(inc), 0.5, 30 * math.cos(inc)])
+        aim = rng.normal(size=(40, 3)) * np.array([8.0, 8.0, 1.0])
+        d = aim - cam
+        ks.append(d / np.linalg.norm(d, axis=1)[:, None])
+        xs.append(np.tile(cam, (40, 1)))
+    k0, x0 = np.concatenate(ks), np.concatenate(xs)
+    res = [sr.trace_ray_kerr(k0[i], x0[i], M, a, lambda_end=80.0, disk=(3.0, 10.0)) for i in range(len(k0))]
+    save("kerr_disk", k0=k0, x0=x0, r_s=1.0, spin=a, lambda_end=80.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
+         disk_r_in=3.0, disk_r_out=10.0, end=np.array([r["end"] for r in res]),
+         flags=np.array([r["flags"] for r in res], np.uint8),
+         n_accepted=np.array([r["n_accepted"] for r in res], np.uint32), t_end=np.array([r["t_end"] for r in res]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all",):
@@ -231,3 +252,5 @@ if __name__ == "__main__":
         main_kerr()
     if which in ("all", "objects"):
         main_objects()
+    if which in ("all", "kerr_disk"):
+        main_kerr_disk()

@@ -267,9 +267,10 @@ def test_kerr_seeded_rays_and_rk4(ctx, oracle):
     e, f, s_, a_ = ctx.trace(k[:4], np.array([0.3, 0.2, 0.6]), _params(r_s=1.0, rhs_form=2, spin=0.45))
     assert np.all(f == 3)
     from blackhole_geodesic_calculator_amd import _ffi
-    for bad in (dict(spin=0.5), dict(spin=0.45, disk_r_in=2.0, disk_r_out=5.0)):
-        with pytest.raises(_ffi.BhgError):
-            ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, **bad))
+    with pytest.raises(_ffi.BhgError):
+        ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, spin=0.5))          # |a| must stay below M
+    with pytest.raises(_ffi.BhgError):
+        ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, spin=0.45), spheres=[[0, 0, 5, 1.0]])   # no objects in Kerr
 
 
 def test_kerr_integrator_and_camera_adaptors(ctx, oracle):
@@ -318,6 +319,31 @@ def test_randomised_configurations(ctx, oracle, seed):
         kw["max_steps"] = int(rng.integers(1, 40))
     tight = kw.get("rtol", 1e-3) <= 1e-6 and kw["rhs_form"] == 0
     _compare(ctx, oracle, k, x0, allow_flips=(0.02 if tight else False), outliers=2e-3, **kw)
+
+
+def test_kerr_disk_golden_and_frames(ctx, oracle):
+    """Kerr a/M = 0.9 with the thin disk in the equatorial plane (resume passes in Boyer-Lindquist records)."""
+    g = load_golden("kerr_disk")
+    kw = dict(r_s=1.0, lambda_end=80.0, rhs_form=2, spin=float(g["spin"]), disk_r_in=3.0, disk_r_out=10.0)
+    end, flags, steps, acc = ctx.trace(g["k0"], g["x0"], _params(**kw))
+    assert np.array_equal(flags, g["flags"]) and np.array_equal(acc, g["n_accepted"])
+    assert np.all(np.abs(end - g["end"]).max(1) < np.where((g["flags"] & 1) != 0, 1e-5, 1e-8))
+    # seeded frames from three inclinations against the oracle (ids of the rays that differ: horizon / axis only)
+    for inc, seed in ((1.45, 81), (1.0, 82), (0.3, 83)):
+        cam = np.array([30 * np.sin(inc), 0.3, 30 * np.cos(inc)])
+        aim = np.random.default_rng(seed).normal(size=(6000, 3)) * np.array([9.0, 9.0, 1.5])
+        k = aim - cam
+        k /= np.linalg.norm(k, axis=1)[:, None]
+        kw2 = dict(kw, r_exit=40.0)
+        o = oracle.trace(k, cam, **kw2)
+        end, flags, steps, acc = ctx.trace(k, cam, _params(**kw2))
+        same = (flags == o["flags"]) & (steps == o["n_attempted"]) & (acc == o["n_accepted"])
+        assert (flags != o["flags"]).mean() <= 0.002 and (~same).mean() <= 0.03
+        assert np.all((o["flags"][~same] & 1) != 0) or (~same).sum() <= 12
+        d = np.abs(end - o["end"]).max(1)
+        on = same & (o["flags"] == 128)
+        assert on.sum() > 1000 and np.median(d[on]) < 1e-10 and d[on].max() < 1e-6
+        assert np.abs(end[on, 2]).max() < 1e-9
 
 
 def test_objects_golden_vectors(ctx, oracle):
@@ -461,6 +487,9 @@ def test_randomised_kerr(ctx, oracle, seed):
         kw["r_exit"] = float(rng.uniform(0.6, 1.4)) * dist_cam
     if rng.random() < 0.2:
         kw["max_steps"] = int(rng.integers(1, 60))
+    if rng.random() < 0.35:
+        rin = float(rng.uniform(1.5, 5.0)) * r_s
+        kw.update(disk_r_in=rin, disk_r_out=rin * float(rng.uniform(1.2, 3.0)))
     # Boyer-Lindquist coordinates are singular on the horizon (1/Delta) and on the polar axis (cot theta):
     # rays that end on the horizon or pass close to the axis (small L_z) have rounding-sensitive step
     # sequences in the oracle and on the GPU alike.  Everything else must agree step for step.

@@ -304,3 +304,17 @@ def test_scene_shade_reference_known_answers():
     # a second sphere between the point and the lamp: shadow; lamp behind the surface: nothing
     assert np.all(sh.object_colour(e, np.array([0]), sph, np.ones((2, 3)), [[0.0, 0.0, 3.0, 10.0]]) == 0.0)
     assert np.all(sh.object_colour(e, np.array([0]), sph[:1], np.ones((1, 3)), [[0.0, 0.0, -3.0, 10.0]]) == 0.0)
+
+
+def test_oracle_kerr_disk_matches_scipy_golden(oracle):
+    """Kerr with the thin disk in the equatorial plane: scipy event g = cos(theta) on the Boyer-Lindquist solve."""
+    g = load_golden("kerr_disk")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=80.0, rhs_form=oracle.RHS_KERR_BL, spin=float(g["spin"]),
+                     disk_r_in=float(g["disk_r_in"]), disk_r_out=float(g["disk_r_out"]))
+    assert np.array_equal(o["flags"], g["flags"]) and np.array_equal(o["n_accepted"], g["n_accepted"])
+    disk = o["flags"] == oracle.FLAG_HIT_DISK
+    assert disk.sum() > 30 and (o["flags"] == 1).sum() > 3
+    tol = np.where((g["flags"] & 1) != 0, 1e-5, 1e-8)   # horizon: the Boyer-Lindquist end state is singular
+    assert np.all(np.abs(o["end"] - g["end"]).max(1) < tol)
+    R = np.hypot(o["end"][disk, 0], o["end"][disk, 1])
+    assert np.abs(o["end"][disk, 2]).max() < 1e-12 and R.min() >= 3.0 and R.max() <= 10.0
