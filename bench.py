@@ -194,7 +194,9 @@ def main():
             else:
                 f.trace(params)
         for j, f in enumerate(frames):
-            gatherer.submit(i * len(frames) + j, f.shade())
+            # shade + sample mean written as float RGBA straight into the gather slab (N > 1) or, single rank,
+            # into the frame image in frame order
+            gatherer.submit_with(i * len(frames) + j, f.shade_f32)
 
     def barrier():
         gatherer.drain()

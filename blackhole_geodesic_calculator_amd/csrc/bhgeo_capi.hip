@@ -548,8 +548,38 @@ int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags
     return BHG_OK;
 }
 
+}  // extern "C"
+
+namespace {
+int shade_scene_impl(bhg_context *c, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
+                     size_t n_pixels, int32_t samples, const bhg_scene *sc, double *d_rgba, float *d_rgba_f32,
+                     const int64_t *d_scatter, void *stream);
+}
+
+extern "C" {
+
 int bhg_shade_scene_device(bhg_context *c, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
                            size_t n_pixels, int32_t samples, const bhg_scene *sc, double *d_rgba, void *stream)
+{
+    if (n_pixels && !d_rgba) return fail(BHG_E_INVALID, "NULL device pointer");
+    return shade_scene_impl(c, d_end, d_flags, d_object_id, n_pixels, samples, sc, d_rgba, nullptr, nullptr, stream);
+}
+
+int bhg_shade_scene_f32_device(bhg_context *c, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
+                               size_t n_pixels, int32_t samples, const bhg_scene *sc, float *d_rgba_f32,
+                               const int64_t *d_scatter, void *stream)
+{
+    if (n_pixels && !d_rgba_f32) return fail(BHG_E_INVALID, "NULL device pointer");
+    return shade_scene_impl(c, d_end, d_flags, d_object_id, n_pixels, samples, sc, nullptr, d_rgba_f32, d_scatter, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int shade_scene_impl(bhg_context *c, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
+                     size_t n_pixels, int32_t samples, const bhg_scene *sc, double *d_rgba, float *d_rgba_f32,
+                     const int64_t *d_scatter, void *stream)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     if (!sc) return fail(BHG_E_INVALID, "scene is NULL");
@@ -565,7 +595,7 @@ int bhg_shade_scene_device(bhg_context *c, const double *d_end, const uint8_t *d
     for (int j = 0; j < sc->n_spheres; j++)
         if (!(sc->spheres[j][3] > 0.0)) return fail(BHG_E_INVALID, "sphere radii must be > 0");
     if (n_pixels == 0) return BHG_OK;
-    if (!d_end || !d_flags || !sc->d_sky || !d_rgba) return fail(BHG_E_INVALID, "NULL device pointer");
+    if (!d_end || !d_flags || !sc->d_sky) return fail(BHG_E_INVALID, "NULL device pointer");
     HIP_TRY(hipSetDevice(c->device));
     bhg::ShadeArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -573,6 +603,8 @@ int bhg_shade_scene_device(bhg_context *c, const double *d_end, const uint8_t *d
     a.flags = d_flags;
     a.sky = sc->d_sky;
     a.rgba = d_rgba;
+    a.rgba_f32 = d_rgba_f32;
+    a.scatter = d_scatter;
     a.n_pixels = n_pixels;
     a.samples = samples;
     a.sky_w = sc->sky_w;
@@ -595,6 +627,10 @@ int bhg_shade_scene_device(bhg_context *c, const double *d_end, const uint8_t *d
     HIP_TRY(bhg::launch_shade(a, (hipStream_t)stream));
     return BHG_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0, size_t n,
                    uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags)

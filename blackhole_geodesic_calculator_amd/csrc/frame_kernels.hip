@@ -185,9 +185,18 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
         acc[2] += rgb[2];
     }
     const double inv_s = 1.0 / (double)A.samples;  // buf = sbuf / (s+1) after the last sample (:250)
-    double *o = A.rgba + p * 4;
-    reinterpret_cast<double2 *>(o)[0] = make_double2(acc[0] * inv_s, acc[1] * inv_s);
-    reinterpret_cast<double2 *>(o)[1] = make_double2(acc[2] * inv_s, 1.0);
+    if (A.rgba) {
+        double *o = A.rgba + p * 4;
+        reinterpret_cast<double2 *>(o)[0] = make_double2(acc[0] * inv_s, acc[1] * inv_s);
+        reinterpret_cast<double2 *>(o)[1] = make_double2(acc[2] * inv_s, 1.0);
+    }
+    if (A.rgba_f32) {
+        // what Blender's layer.rect holds (:163-164): float RGBA, alpha 1; optionally scattered straight to the
+        // pixel's place in the frame (scatter[p] = y*W + x of this rank's p-th pixel)
+        const uint64_t q = A.scatter ? (uint64_t)A.scatter[p] : p;
+        reinterpret_cast<float4 *>(A.rgba_f32)[q] =
+            make_float4((float)(acc[0] * inv_s), (float)(acc[1] * inv_s), (float)(acc[2] * inv_s), 1.0f);
+    }
 }
 
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s)

@@ -70,7 +70,9 @@ struct ShadeArgs {
     const double *end;     // [S*n_pixels][6]
     const uint8_t *flags;  // [S*n_pixels]
     const float *sky;      // [sky_h][sky_w][4] RGBA float32, equirectangular
-    double *rgba;          // [n_pixels][4]
+    double *rgba;          // [n_pixels][4] fp64, or nullptr
+    float *rgba_f32;       // [n_pixels or frame pixels][4] fp32, or nullptr
+    const int64_t *scatter;  // nullptr, or where pixel p goes in rgba_f32
     uint64_t n_pixels;
     int32_t samples, sky_w, sky_h;
     // scene shading (bhg_shade_scene_device); all zero / null for the sky-only call

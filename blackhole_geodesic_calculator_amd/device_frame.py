@@ -130,6 +130,17 @@ class DeviceFrame:
                               self.sky_wh[0], self.sky_wh[1], self.d_rgba.data_ptr(), stream=self._stream())
         return self.d_rgba
 
+    def shade_f32(self, out, scatter=None):
+        """Shade + sample mean written as float32 RGBA into `out` ([P, 4], or [H*W, 4] with scatter = this shard's
+        flat pixel ids): what layer.rect takes, without the fp64 intermediate."""
+        if self.d_sky is None:
+            raise RuntimeError("set_sky() first")
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        self.ctx.shade_scene_f32_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.scene(),
+                                        out.data_ptr(), d_object_id=0 if self.d_obj is None else self.d_obj.data_ptr(),
+                                        d_scatter=0 if scatter is None else scatter.data_ptr(), stream=self._stream())
+        return out
+
     def render(self, params: _ffi.Params, regenerate_rays=False):
         """rays (cached: the engine re-seeds identically every frame) -> trace -> shade."""
         if regenerate_rays or not getattr(self, "_rays_ready", False):

@@ -134,6 +134,20 @@ class FrameGatherer:
             self.frame[self.pix_of[0]] = self.slabs[b][: self.P]
             self.frames_done += 1
 
+    def submit_with(self, i, fill):
+        """Like submit(), but the producer writes its [P, C] result itself: fill(out, scatter) is called with
+        either (this rank's slab, None) when a gather follows, or -- single rank -- (the frame image [H*W, C],
+        this rank's flat pixel ids), so that the result lands in frame order without an intermediate copy."""
+        b = i & 1
+        self.finish(b)
+        self.last = b
+        if self.world > 1:
+            fill(self.slabs[b][: self.P], None)
+            self.pending[b] = self.dist.gather(self.slabs[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
+        else:
+            fill(self.frame, self.pix_of[0])
+            self.frames_done += 1
+
     def drain(self):
         """Finish what is in flight, oldest frame first."""
         last = getattr(self, "last", 1)

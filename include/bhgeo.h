@@ -208,6 +208,12 @@ typedef struct bhg_scene {
 } bhg_scene;
 int bhg_shade_scene_device(bhg_context *ctx, const double *d_end, const uint8_t *d_flags, const int8_t *d_object_id,
                            size_t n_pixels, int32_t samples, const bhg_scene *scene, double *d_rgba, void *stream);
+/* The same, written as float RGBA -- what Blender's layer.rect takes (RelativisticRenderEngine.py:163-164) --
+ * and optionally scattered: d_scatter [n_pixels] (or NULL) gives, for each of this call's pixels, its index in
+ * d_rgba_f32 (e.g. y*width + x for a GPU's tile shard, so the shard lands in frame order). */
+int bhg_shade_scene_f32_device(bhg_context *ctx, const double *d_end, const uint8_t *d_flags,
+                               const int8_t *d_object_id, size_t n_pixels, int32_t samples, const bhg_scene *scene,
+                               float *d_rgba_f32, const int64_t *d_scatter, void *stream);
 
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term. */

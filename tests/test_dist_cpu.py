@@ -75,7 +75,13 @@ px = bd.rank_pixels(W, H, T, rank, world)
 assert g.P == len(px)
 for frame in range(5):   # five frames through the two rotating slabs
     local = torch.tensor(np.stack([px + 1000 * frame, np.full_like(px, rank), px // W, px % W], 1), dtype=torch.float32)
-    g.submit(frame, local)
+    if frame % 2 == 0:
+        g.submit(frame, local)
+    else:                 # the producer fills the slab itself (what bench.py's frame end does)
+        def fill(out, scatter, local=local):
+            assert scatter is None and out.shape == local.shape
+            out.copy_(local)
+        g.submit_with(frame, fill)
 g.drain()
 dist.barrier()
 if rank == 0:
@@ -119,6 +125,12 @@ def test_frame_gatherer_single_process():
     g.drain()
     img = g.image().numpy()
     assert np.array_equal(img[..., 0].reshape(-1), np.arange(64 * 32)) and g.frames_done == 1
+
+    def fill(out, scatter):   # single rank: the producer scatters straight into the frame image
+        out[scatter] = torch.tensor(np.stack([3 * px, px], 1), dtype=torch.float64)
+    g.submit_with(1, fill)
+    g.drain()
+    assert np.array_equal(g.image().numpy()[..., 0].reshape(-1), 3 * np.arange(64 * 32)) and g.frames_done == 2
 
 
 def test_gather_frame_world2_gloo(tmp_path):

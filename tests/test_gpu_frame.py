@@ -133,6 +133,32 @@ def test_device_buffers_need_only_8_byte_alignment(ctx):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_shade_f32_scatter_matches_fp64_path(ctx):
+    """The float32 / scattered output of the shade kernel (what the bench's frame end uses) equals the fp64
+    output cast to float32 and scattered by pixel id."""
+    import torch
+    from blackhole_geodesic_calculator_amd import dist as bdist
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
+    W, H, S = 96, 64, 2
+    pix = bdist.rank_pixels(W, H, 32, 0, 1)
+    fr = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM, pixels=pix)
+    fr.set_sky(synthetic_sky(256, 128))
+    rgba = fr.render(_params(r_s=1.0, lambda_end=50.0)).clone()
+    d_pix = torch.as_tensor(pix).cuda()
+    frame = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+    fr.shade_f32(frame, d_pix)
+    slab = torch.zeros((fr.P, 4), dtype=torch.float32, device="cuda")
+    fr.shade_f32(slab)
+    torch.cuda.synchronize()
+    want = torch.zeros_like(frame)
+    want[d_pix] = rgba.to(torch.float32)
+    assert torch.equal(frame, want) and torch.equal(slab, rgba.to(torch.float32))
+    g = bdist.FrameGatherer(W, H, 32, channels=4, dtype=torch.float32, device="cuda")
+    g.submit_with(0, fr.shade_f32)
+    g.drain()
+    assert torch.equal(g.image().reshape(-1, 4), want) and g.frames_done == 1
+
+
 def test_frame_batch_equals_single_frames(ctx):
     """Several cameras in ONE trace call (per-ray origins) give bit-identical rays, end states and pixels."""
     import torch
