@@ -149,9 +149,21 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= A.n_pixels) return;
     double acc[3] = {0.0, 0.0, 0.0};
+    // software pipeline: the next sample's flag and exit direction are in flight while this sample's
+    // acos / atan2 / texel gathers run (the samples of a pixel are n_pixels records apart)
+    uint8_t fl_next = A.flags[p];
+    double dn0 = A.end[p * 6 + 3], dn1 = A.end[p * 6 + 4], dn2 = A.end[p * 6 + 5];
     for (int s = 0; s < A.samples; s++) {
         const uint64_t i = (uint64_t)s * A.n_pixels + p;
-        const uint8_t fl = A.flags[i];
+        const uint8_t fl = fl_next;
+        const double c0 = dn0, c1 = dn1, c2 = dn2;
+        if (s + 1 < A.samples) {
+            const uint64_t in = i + A.n_pixels;
+            fl_next = A.flags[in];
+            dn0 = A.end[in * 6 + 3];
+            dn1 = A.end[in * 6 + 4];
+            dn2 = A.end[in * 6 + 5];
+        }
         if (fl & BHG_FLAG_HIT_HORIZON_) continue;  // black (:242-244)
         const double *e = A.end + i * 6;
         if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0) {
@@ -170,7 +182,7 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
             acc[2] += rgb[2];
             continue;
         }
-        double d0 = e[3], d1 = e[4], d2 = e[5];
+        double d0 = c0, d1 = c1, d2 = c2;
         // exit directions are not unit vectors; normalise like the Cam edition (CamEdition.py:433-437)
         const double inv = 1.0 / sqrt(d0 * d0 + d1 * d1 + d2 * d2);
         d0 *= inv;
