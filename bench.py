@@ -297,7 +297,7 @@ def main():
                 "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
-        if world == 1 and a.workload == "frame":
+        if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
             # the host-buffer entry point (numpy in, numpy out: what the reference's Python caller would use),
             # H2D + passes + D2H over PCIe -- reported beside `value`, never as `value`
             k_host = fr.d_k0.cpu().numpy()
