@@ -535,6 +535,32 @@ __device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const 
     return !(R + delta < A.disk_r_in || R - delta > A.disk_r_out);
 }
 
+// The same question in Boyer-Lindquist coordinates (x = (r, theta, phi)): the plane is theta* = pi/2 + k pi, the
+// annulus is in sqrt(r^2 + a^2).  With the chord bounds d_r, d_th of the r and theta components (as above), the
+// dense curve reaches theta* within d_th / |th1 - th0| of the chord's crossing parameter, so its r there lies
+// within D = d_r + |r1 - r0| d_th / |th1 - th0| of the chord's r.  More than one plane crossed in the step, or a
+// step nearly tangent to the plane (D blows up): may hit.
+__device__ __forceinline__ bool disk_crossing_may_hit_bl(const TraceArgs &A, const double x0[3], const double v0[3],
+                                                         const double x1[3], const double v1[3], double h)
+{
+    const double k0 = floor((x0[1] - 1.5707963267948966) * 0.3183098861837907);
+    const double k1 = floor((x1[1] - 1.5707963267948966) * 0.3183098861837907);
+    if (fabs(k1 - k0) != 1.0) return true;
+    const double th_star = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
+    const double dth = x1[1] - x0[1], dr = x1[0] - x0[0];
+    const double ih = 1.0 / h, idth = 1.0 / dth;
+    const double s = (th_star - x0[1]) * idth;
+    const double r_lin = __builtin_fma(s, dr, x0[0]);
+    const double cr = dr * ih, cth = dth * ih;
+    const double d_r = 2.0 * fabs(h) * (fabs(v0[0] - cr) + fabs(v1[0] - cr));
+    const double d_th = 2.0 * fabs(h) * (fabs(v0[1] - cth) + fabs(v1[1] - cth));
+    const double D = __builtin_fma(fabs(dr), d_th * fabs(idth), d_r);
+    const double a2 = A.spin * A.spin;
+    const double r_lo = fmax(r_lin - D, 0.0), r_hi = r_lin + D;
+    const double R_lo = sqrt(__builtin_fma(r_lo, r_lo, a2)), R_hi = sqrt(__builtin_fma(r_hi, r_hi, a2));
+    return !(R_hi < A.disk_r_in || R_lo > A.disk_r_out);  // NaN anywhere: may hit
+}
+
 __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
 {
     bool any = false;
@@ -1356,8 +1382,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                 crossed_disk_plane<RHS>(L.x, xn);
                     const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                    if ((EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && ev_d && !(ev_h || ev_e || ev_o) &&
-                        !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                    if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) &&
+                        !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
+                                                  : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                         ev_d = false;
                     if (ev_h || ev_e || ev_d || ev_o) {
                         // x, v, a1, t still hold the step's start: the resolve pass recomputes it
@@ -1457,8 +1484,9 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                 bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
                 const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                if ((EVT & EVT_DISK) && RHS != BHG_RHS_KERR_BL_ && ev_d && !(ev_h || ev_e || ev_o) &&
-                    !disk_crossing_may_hit(A, L.x, L.v, xn, vn, h))
+                if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) &&
+                    !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
+                                              : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                     ev_d = false;
                 if (ev_h || ev_e || ev_d || ev_o) {
                     L.n_acc = L.n_att;
