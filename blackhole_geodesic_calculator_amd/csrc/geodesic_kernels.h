@@ -95,6 +95,11 @@ hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int gr
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
 // Kerr: after the last pass of a call, Boyer-Lindquist end states -> Cartesian
 hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s);
+// the Kerr instantiations live in their own translation unit (geodesic_kernels_kerr.hip: same source, built with
+// machine LICM on, which suits the big Kerr kernels; the Schwarzschild unit is built with it off)
+hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev);
+hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu);
+hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,

@@ -1522,7 +1522,6 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_items) return;
-    const double r_s = A.r_s;
     double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
     pk[0] = A.k0[i * 3 + 0];
     pk[1] = A.k0[i * 3 + 1];
@@ -1639,6 +1638,7 @@ __global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
         rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, (uint32_t)i, met);
 }
 
+#ifdef BHG_TU_KERR
 // Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into
 // the Cartesian frame the boundary speaks (rays that started inside were stored Cartesian already).
 __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
@@ -1659,6 +1659,8 @@ __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
     if (bad) A.flags[i] |= (uint8_t)BHG_FLAG_NAN_;
 }
 
+
+#endif  // BHG_TU_KERR
 
 // ------------------------------------------------------------------------------------------
 // Sampled trajectories: what calc_trajectory returns with nr_points_curve (RelativisticRenderEngine.py:
@@ -1836,14 +1838,21 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
     store_result(A, (uint32_t)i, xe, ve, flags, n_att, n_acc);  // Kerr: still Boyer-Lindquist, finalised next
 }
 
-hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+#ifdef BHG_TU_KERR
+hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
-    if (rhs == BHG_RHS_KERR_BL_) {
-        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
-        hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a);
-    } else if (rhs == BHG_RHS_REDUCED_) {
+    hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+    hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+#else
+hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+{
+    if (rhs == BHG_RHS_KERR_BL_) return launch_trajectory_kerr(a, traj, n_valid, T, s);
+    const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
+    if (rhs == BHG_RHS_REDUCED_) {
         hipLaunchKernelGGL((prepare_kernel<BHG_RHS_REDUCED_, true>), dim3(gp), dim3(256), 0, s, a);
         hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
     } else {
@@ -1852,6 +1861,7 @@ hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t
     }
     return hipGetLastError();
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Acceleration probe (tests compare the device RHS with the oracle's)
@@ -1908,6 +1918,7 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
     return hipGetLastError();
 }
 
+#ifdef BHG_TU_KERR
 // Kerr: once ALL passes of a call are done, turn the Boyer-Lindquist end states into Cartesian ones
 hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s)
 {
@@ -1915,6 +1926,7 @@ hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s)
     hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+#endif
 
 template <int RHS, int EVT>
 static hipError_t occupancy_variant(int method, int *blocks_per_cu)
@@ -1924,6 +1936,26 @@ static hipError_t occupancy_variant(int method, int *blocks_per_cu)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, trace_dp54_kernel<RHS, EVT>, 64, 0);
 }
 
+#ifdef BHG_TU_KERR
+// Kerr: horizon, optional exit sphere, optional disk (no object spheres)
+hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev)
+{
+    switch (evt & 3) {
+    case 0: return launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
+    case 1: return launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev);
+    default: return launch_variant<BHG_RHS_KERR_BL_, 3>(a, method, grid, s, ev);
+    }
+}
+
+hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu)
+{
+    switch (evt & 3) {
+    case 0: return occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
+    case 1: return occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu);
+    default: return occupancy_variant<BHG_RHS_KERR_BL_, 3>(method, blocks_per_cu);
+    }
+}
+#else
 template <int RHS>
 static hipError_t launch_rhs(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
@@ -1950,26 +1982,14 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
 
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    if (rhs == BHG_RHS_KERR_BL_) {  // Kerr: horizon, optional exit sphere, optional disk (no object spheres)
-        switch (evt & 3) {
-        case 0: return launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
-        case 1: return launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev);
-        default: return launch_variant<BHG_RHS_KERR_BL_, 3>(a, method, grid, s, ev);
-        }
-    }
+    if (rhs == BHG_RHS_KERR_BL_) return launch_trace_kerr(a, method, evt, grid, s, ev);
     return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
 
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {
-    if (rhs == BHG_RHS_KERR_BL_) {
-        switch (evt & 3) {
-        case 0: return occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
-        case 1: return occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu);
-        default: return occupancy_variant<BHG_RHS_KERR_BL_, 3>(method, blocks_per_cu);
-        }
-    }
+    if (rhs == BHG_RHS_KERR_BL_) return trace_occupancy_kerr(method, evt, blocks_per_cu);
     return rhs == BHG_RHS_REDUCED_ ? occupancy_rhs<BHG_RHS_REDUCED_>(method, evt, blocks_per_cu)
                                    : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }
@@ -1985,5 +2005,6 @@ hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n
         hipLaunchKernelGGL((accel_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
     return hipGetLastError();
 }
+#endif  // BHG_TU_KERR
 
 }  // namespace bhg

@@ -3,4 +3,12 @@
 name=$1; shift
 mkdir -p build/variants
 cd blackhole_geodesic_calculator_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -mllvm -amdgpu-atomic-optimizer-strategy=None -mllvm -disable-machine-licm -Wno-unused-function "$@" -shared -o ../../build/variants/libbhgeo_$name.so geodesic_kernels.hip frame_kernels.hip bhgeo_capi.hip
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-function"
+T=$(mktemp -d)
+/opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c geodesic_kernels.hip -o $T/a.o &
+/opt/rocm/bin/hipcc $F "$@" -c geodesic_kernels_kerr.hip -o $T/b.o &
+/opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c frame_kernels.hip -o $T/c.o &
+/opt/rocm/bin/hipcc $F "$@" -c bhgeo_capi.hip -o $T/d.o &
+wait
+/opt/rocm/bin/hipcc $F -shared -o ../../build/variants/libbhgeo_$name.so $T/a.o $T/b.o $T/c.o $T/d.o
+rm -rf $T
