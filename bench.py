@@ -277,7 +277,7 @@ def main():
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
                 "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
-                "tile": a.tile, "frame_end": "device shade + per-pixel sample mean (RGBA)" + (" + 1 async RCCL gather to rank 0" if world > 1 else ""),
+                "tile": a.tile, "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0" if world > 1 else "in frame order"),
                 "launch": ctx.last_launch(),
             },
             "roofline": {
