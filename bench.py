@@ -38,8 +38,12 @@ BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accept
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ramp-seconds", type=float, default=0.3,
+                    help="untimed steps run before the W warm-up steps until this much wall time has passed: the "
+                         "GPU's clocks take tens of milliseconds of load to settle (a 20-step timed region right "
+                         "after start-up measures 5 %% low); 0 = off")
     ap.add_argument("--regime", choices=["adaptive", "fine", "rk4"], default="adaptive",
                     help="adaptive: DP5(4) rtol 1e-3 atol 1e-6 max_step inf (engine + scipy defaults); "
                          "fine: same with max_step 0.1; rk4: fixed step 0.1")
@@ -204,6 +208,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.ramp_seconds > 0:      # clock ramp (untimed, not counted in W or K)
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < a.ramp_seconds:
+            for i in range(4):
+                step(i, False)
+            torch.cuda.synchronize()
+        barrier()
     for i in range(a.warmup):
         step(i, False)
     barrier()
