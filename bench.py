@@ -180,7 +180,11 @@ def main():
     # frame end: per-pixel RGBA (fp32, what Blender's layer.rect holds) handed to the frame owner.
     # N > 1: ONE gather per frame over RCCL, issued asynchronously so it overlaps the next frame's
     # trace (dist.FrameGatherer: two slabs in rotation; rank 0 scatters into frame order).
-    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda")
+    def assemble(slabs, perm, frame):   # rank 0, N > 1: slabs -> frame order in one kernel
+        ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
+                                      stream=torch.cuda.current_stream().cuda_stream)
+
+    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=assemble)
     kernel_ms = []
 
     def step(i, timed):

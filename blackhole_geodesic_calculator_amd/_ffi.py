@@ -44,6 +44,7 @@ EXPORTS = (
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
     "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
+    "bhg_assemble_frame_f32_device",
 )
 
 
@@ -179,6 +180,8 @@ def load():
     L.bhg_shade_scene_f32_device.restype = C.c_int
     L.bhg_shade_scene_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32,
                                              C.POINTER(Scene), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bhg_assemble_frame_f32_device.restype = C.c_int
+    L.bhg_assemble_frame_f32_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.bhg_raygen_device.restype = C.c_int
     L.bhg_raygen_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -378,6 +381,10 @@ class Context:
                                                  C.c_void_p(d_object_id or None), int(n_pixels), int(samples),
                                                  C.byref(scene), C.c_void_p(d_rgba_f32), C.c_void_p(d_scatter or None),
                                                  C.c_void_p(stream or None)))
+
+    def assemble_frame_f32_device(self, d_slabs, d_index, n_pixels, d_frame, stream=0):
+        _check(load().bhg_assemble_frame_f32_device(self._h, C.c_void_p(d_slabs), C.c_void_p(d_index), int(n_pixels),
+                                                    C.c_void_p(d_frame), C.c_void_p(stream or None)))
 
     def acceleration(self, x, k, params: Params):
         x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)

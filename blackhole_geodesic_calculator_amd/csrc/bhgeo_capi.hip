@@ -632,6 +632,17 @@ int shade_scene_impl(bhg_context *c, const double *d_end, const uint8_t *d_flags
 
 extern "C" {
 
+int bhg_assemble_frame_f32_device(bhg_context *c, const float *d_slabs, const int64_t *d_index, size_t n_pixels,
+                                  float *d_frame, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    if (n_pixels == 0) return BHG_OK;
+    if (!d_slabs || !d_index || !d_frame) return fail(BHG_E_INVALID, "NULL device pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(bhg::launch_gather_rows4(d_slabs, d_index, n_pixels, d_frame, (hipStream_t)stream));
+    return BHG_OK;
+}
+
 int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0, size_t n,
                    uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags)
 {

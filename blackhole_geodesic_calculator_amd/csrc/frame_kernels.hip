@@ -211,6 +211,22 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
     }
 }
 
+// dst[i] = src[index[i]] for rows of four floats: puts the gathered per-rank slabs into frame order on the
+// root GPU (index = the frame's permutation, computed once).  HBM-bound: 8 + 16 + 16 bytes per pixel.
+__global__ void __launch_bounds__(256) gather_rows4_kernel(const float4 *src, const int64_t *index, uint64_t n, float4 *dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[index[i]];
+}
+
+hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4 *>(src), index, n, reinterpret_cast<float4 *>(dst));
+    return hipGetLastError();
+}
+
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s)
 {
     const uint64_t n = a.n_pixels * (uint64_t)a.samples;

@@ -88,6 +88,7 @@ struct ShadeArgs {
 
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
+hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s);
 
 // ev: nullptr, or 4 events recorded around prepare | trace | resolve on stream s
 // evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event, bit 2 = object spheres (then all three)

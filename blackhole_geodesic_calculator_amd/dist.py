@@ -85,11 +85,15 @@ class FrameGatherer:
     rotation so a slab in flight is never overwritten.  Rank dst scatters the slabs into frame order.
     Works over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests)."""
 
-    def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0):
+    def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0, assemble=None):
+        """assemble(slabs [world*pmax, C], perm [H*W] int64, frame [H*W, C]): optional device routine for the
+        root's frame assembly, frame[p] = slabs[perm[p]] (bench.py passes libbhgeo's kernel); default: torch."""
         import torch
         import torch.distributed as dist
 
         self.dist = dist if dist.is_initialized() else None
+        self.torch = torch
+        self.assemble = assemble
         self.group, self.dst = group, dst
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank = dist.get_rank(group) if self.dist else 0
@@ -103,11 +107,20 @@ class FrameGatherer:
         self.pix_of = None
         self.frame = None
         if self.is_dst:
+            pix = [rank_pixels(self.W, self.H, tile, r, self.world) for r in range(self.world)]
+            self.pix_of = [torch.from_numpy(p).to(device) for p in pix]
             if self.world > 1:
-                self.recv = [[torch.empty((self.pmax, channels), dtype=dtype, device=device) for _ in range(self.world)]
-                             for _ in range(2)]
-            self.pix_of = [torch.from_numpy(rank_pixels(self.W, self.H, tile, r, self.world)).to(device)
-                           for r in range(self.world)]
+                # the ranks' slabs arrive in ONE block [world * pmax, C]; frame order is a single gather through
+                # `perm` (perm[pixel] = r * pmax + position of the pixel in rank r's list): one kernel per frame
+                # on the root instead of one scatter per rank
+                self.recv_all = [torch.empty((self.world * self.pmax, channels), dtype=dtype, device=device)
+                                 for _ in range(2)]
+                self.recv = [[ra[r * self.pmax:(r + 1) * self.pmax] for r in range(self.world)] for ra in self.recv_all]
+                import numpy as _np
+                perm = _np.empty(self.H * self.W, dtype=_np.int64)
+                for r, p in enumerate(pix):
+                    perm[p] = r * self.pmax + _np.arange(len(p), dtype=_np.int64)
+                self.perm = torch.from_numpy(perm).to(device)
             self.frame = torch.zeros((self.H * self.W, channels), dtype=dtype, device=device)
         self.pending = [None, None]
         self.frames_done = 0
@@ -118,8 +131,11 @@ class FrameGatherer:
             self.pending[b].wait()
             self.pending[b] = None
             if self.is_dst:
-                for r in range(self.world):
-                    self.frame[self.pix_of[r]] = self.recv[b][r][: len(self.pix_of[r])]
+                if self.assemble is not None:   # libbhgeo's gather kernel (float RGBA rows on a GPU)
+                    self.assemble(self.recv_all[b], self.perm, self.frame)
+                else:
+                    for r in range(self.world):
+                        self.frame[self.pix_of[r]] = self.recv[b][r][: len(self.pix_of[r])]
                 self.frames_done += 1
 
     def submit(self, i, local):

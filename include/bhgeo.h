@@ -215,6 +215,12 @@ int bhg_shade_scene_f32_device(bhg_context *ctx, const double *d_end, const uint
                                const int8_t *d_object_id, size_t n_pixels, int32_t samples, const bhg_scene *scene,
                                float *d_rgba_f32, const int64_t *d_scatter, void *stream);
 
+/* Frame end on the root GPU of a sharded frame: the ranks' float RGBA slabs, gathered into one block
+ * d_slabs [n_ranks * slab_pixels][4], are put into frame order, d_frame[p] = d_slabs[d_index[p]] for the n_pixels
+ * pixels of the frame (d_index: the frame's permutation, computed once by the host from the tile dealing). */
+int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const int64_t *d_index, size_t n_pixels,
+                                  float *d_frame, void *stream);
+
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term. */
 int bhg_acceleration(bhg_context *ctx, const bhg_params *p, const double *x, const double *k,

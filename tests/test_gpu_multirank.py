@@ -37,7 +37,10 @@ def make(pixels):
     return f
 
 mine = make(bd.rank_pixels(W, H, T, rank, world))
-g = bd.FrameGatherer(W, H, T, channels=4, dtype=torch.float32, device="cuda")
+def assemble(slabs, perm, frame):
+    ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream)
+g = bd.FrameGatherer(W, H, T, channels=4, dtype=torch.float32, device="cuda", assemble=assemble)
 for frame in range(3):                      # three frames through the two rotating slabs
     mine.trace(params)
     g.submit_with(frame, mine.shade_f32)
