@@ -17,14 +17,18 @@
 //     filled 64 rays at a time by ALL lanes together (coalesced k0 loads, the scipy initial-step
 //     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
 //     always runs converged and the integrate loop always runs (nearly) full;
-//   * three passes per call, all on one stream: PREPARE (one thread per ray, converged: f0, r0,
-//     scipy's initial step) -> TRACE (persistent lane-refill waves, the hot loop, ~110 VGPRs) ->
-//     RESOLVE (rays whose last step crossed the horizon / exit sphere: recompute that step,
-//     quartic dense output, Brent root).  Keeping setup and root search out of the hot kernel
-//     halves its register footprint (248 -> ~110 VGPRs: 4 waves per SIMD instead of 2);
-//   * a lane whose accepted step crosses an event parks the step's start state in its own
-//     output slots and refills at once, so the rare root search never runs one lane wide;
-//   * work is handed out in 64-ray batches from one device counter, fetched one batch ahead;
+//   * passes of one call, all on one stream: TRACE (persistent lane-refill waves, the hot loop, ~120 VGPRs =
+//     4 waves per SIMD; for the Schwarzschild forms the waves also work out each batch's start records --
+//     f0, r0, scipy's initial step -- while they fill their queue) -> RESOLVE (rays whose last step crossed
+//     or may have crossed an event surface: recompute that step, quartic dense output, Brent roots, earliest
+//     terminal root wins; a step that holds none after all hands its ray to another TRACE + RESOLVE pass over
+//     a worklist).  Kerr runs a PREPARE pass first (Cartesian -> Boyer-Lindquist, E, L) and a finalize pass
+//     last.  Keeping the root search out of the hot kernel halves its register footprint (248 -> ~120 VGPRs);
+//   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord touches an
+//     object sphere, parks the step's start state in its own output slots and refills at once, so the root
+//     search never runs one lane wide;
+//   * work is handed out in 64-ray batches from eight sliced device counters (a wave starts on the slice of its
+//     XCD and steals from the others), each batch claimed just before the queue runs out;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
 //     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
 //     element-wise ODE, not a contraction.
@@ -446,7 +450,8 @@ __device__ __forceinline__ double pow_0p2(double x)
 // of steps that crossed the horizon / exit sphere (filled lane by lane, drained converged).
 // ------------------------------------------------------------------------------------------
 struct WaveLds {
-    // prepared rays (filled converged from the prepare pass's records, drained lane by lane)
+    // prepared rays (filled converged -- start records worked out in place or read from the prepare / resume
+    // records -- and drained lane by lane)
     double qx[3][64];
     double qk[3][64];
     double qa[3][64];  // FSAL acceleration at the start point
@@ -1606,7 +1611,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
-// Resolve pass (one thread per ray, almost all exit at once): rays parked with EV_PENDING get
+// Resolve pass (one thread per ray, almost all exit at once): rays parked with a pending-event code get
 // their crossing step recomputed, the quartic dense output built and the root located by Brent.
 // ------------------------------------------------------------------------------------------
 template <int RHS, bool ADAPTIVE>
