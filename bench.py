@@ -214,10 +214,16 @@ def main():
 
     if a.ramp_seconds > 0:      # clock ramp (untimed, not counted in W or K)
         t_ramp = time.perf_counter()
-        while time.perf_counter() - t_ramp < a.ramp_seconds:
+        while True:
             for i in range(4):
                 step(i, False)
             torch.cuda.synchronize()
+            # every rank must run the same number of frames (each one is a collective): rank 0's clock decides
+            go = torch.tensor([1.0 if time.perf_counter() - t_ramp < a.ramp_seconds else 0.0], device="cuda")
+            if world > 1:
+                dist.broadcast(go, src=0)
+            if float(go.item()) == 0.0:
+                break
         barrier()
     for i in range(a.warmup):
         step(i, False)
