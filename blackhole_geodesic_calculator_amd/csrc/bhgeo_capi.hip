@@ -95,7 +95,6 @@ int ensure(void **p, size_t *have, size_t need)
 int validate(const bhg_params *p)
 {
     if (!p) return fail(BHG_E_INVALID, "params is NULL");
-    if (p->reserved != 0) return fail(BHG_E_INVALID, "params.reserved must be 0");
     if (!(p->r_s >= 0.0) || !std::isfinite(p->r_s)) return fail(BHG_E_INVALID, "r_s must be finite and >= 0");
     if (!(p->lambda_end >= 0.0) || !std::isfinite(p->lambda_end))
         return fail(BHG_E_INVALID, "lambda_end must be finite and >= 0");
@@ -153,7 +152,7 @@ void bhg_default_params(bhg_params *p)
     p->method = BHG_METHOD_DP54;
     p->rhs_form = BHG_RHS_CHRISTOFFEL;
     p->max_steps = 0;
-    p->reserved = 0;
+    p->order_blocks = 0;
     p->disk_r_in = 0.0;
     p->disk_r_out = 0.0;  // no disk
     p->spin = 0.0;
@@ -355,6 +354,12 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
+    // work-order hint: honoured when the call is that many equal blocks of whole 64-ray batches
+    if (p->order_blocks > 1 && n % p->order_blocks == 0 && (n / p->order_blocks) % 64 == 0 &&
+        !std::getenv("BHGEO_NO_ORDER_HINT")) {  // (the env switch is a tuning / A-B aid)
+        a.order_blocks = (int32_t)p->order_blocks;
+        a.order_block_len = n / p->order_blocks;
+    }
     a.object_id = d_object_id;
     a.n_spheres = n_spheres;
     for (int j = 0; j < n_spheres; j++)
@@ -406,6 +411,7 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
             if (cnt == 0) break;
             c->last_launch[3] = pass + 2;
             a.n_items = cnt;
+            a.order_blocks = 0;
             a.worklist = w_list[pass & 1];
             a.worklist_out = w_list[(pass + 1) & 1];
             a.work_count_out = &w_count[(pass + 1) & 1];

@@ -45,6 +45,8 @@ struct TraceArgs {
     int32_t ws_stride;           // doubles per ray record in ws: 6, or 8 for Kerr ({E, L} appended)
     int32_t from_records;        // pass 0 starts rays from records the prepare pass wrote (Kerr)
     int32_t inline_prepare;      // set by the launcher: first pass without a prepare launch (Schwarzschild forms)
+    int32_t order_blocks;        // work-order hint (first pass only): n = order_blocks * order_block_len, batches are
+    uint64_t order_block_len;    // handed out chunk-major over the blocks; 0/1 = plain order
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
     uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged

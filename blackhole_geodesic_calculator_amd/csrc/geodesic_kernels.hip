@@ -825,7 +825,17 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave 
                 if (++W.dry == NSLICE) W.exhausted = true;
                 continue;
             }
-            fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, base);
+            uint64_t first = base;
+            if (A.order_blocks > 1) {
+                // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
+                // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
+                // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
+                // the caller's pixels sorted longest-first the long rays then all start early, instead of once
+                // per block through the whole launch.  A pure permutation of the batch order.
+                const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
+                first = sblk * A.order_block_len + (q << 6);
+            }
+            fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
             if (W.q_count == 0) continue;
         }
         const int n_idle = __builtin_popcountll(idle);

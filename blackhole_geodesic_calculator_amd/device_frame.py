@@ -15,6 +15,13 @@ from . import _ffi
 from .raygen import euler_xyz_matrix, python_random_stream
 
 
+def _copy_params(p: _ffi.Params) -> _ffi.Params:
+    q = _ffi.Params()
+    import ctypes
+    ctypes.memmove(ctypes.byref(q), ctypes.byref(p), ctypes.sizeof(_ffi.Params))
+    return q
+
+
 class DeviceFrame:
     """All buffers of one frame shard on one GPU.
 
@@ -102,6 +109,11 @@ class DeviceFrame:
                                rot=self.rot, stream=self._stream())
 
     def trace(self, params: _ffi.Params):
+        # work-order hint: the rays are S blocks of P (sample-major); lets the library start all samples of a
+        # region together (the pixels of a shard are usually sorted longest-first, dist.rank_pixels(tile_cost=))
+        if params.order_blocks == 0 and self.S > 1:
+            params = _copy_params(params)
+            params.order_blocks = self.S
         has_obj = self.spheres is not None and len(self.spheres) > 0
         self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), x0_shared=self.origin,
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),

@@ -95,7 +95,10 @@ typedef struct bhg_params {
     int32_t method;     /* BHG_METHOD_* */
     int32_t rhs_form;   /* BHG_RHS_* */
     uint32_t max_steps; /* cap on attempted steps per ray; 0 = library default (1<<20) */
-    uint32_t reserved;  /* must be 0 */
+    uint32_t order_blocks; /* work-order hint, 0 = none: the n rays are this many equal blocks (e.g. the samples of a
+                              frame laid out [sample][pixel]) and the library may start the corresponding parts of all
+                              blocks together (better balance when the pixels are sorted longest-first); ignored unless
+                              n / order_blocks is a multiple of 64.  Never changes a result. */
     double disk_r_in;   /* thin disk in the plane z = 0 (BH-centred frame): the ray ends at its first */
     double disk_r_out;  /* crossing with R_in <= sqrt(x^2+y^2) <= R_out; off when disk_r_out == 0
                            (disk_on / R_in / R_out of LimitedRelativisticRenderEngine.py:283-286).  With

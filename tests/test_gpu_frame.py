@@ -159,6 +159,27 @@ def test_shade_f32_scatter_matches_fp64_path(ctx):
     assert torch.equal(g.image().reshape(-1, 4), want) and g.frames_done == 1
 
 
+def test_work_order_hint_never_changes_results(ctx):
+    """params.order_blocks only permutes the order in which 64-ray batches are started."""
+    import torch
+    from conftest import frame_rays
+    n = 64 * 50 * 4
+    k = torch.as_tensor(frame_rays(n, seed=9)).cuda()
+    outs = []
+    for ob in (0, 4, 7, 50):      # 7: n / 7 is not whole -> ignored; 50: blocks of 4 batches
+        p = _params(r_s=1.0, lambda_end=50.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=8.0, order_blocks=ob)
+        end = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+        fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+        st = torch.empty(n, dtype=torch.int32, device="cuda")
+        ctx.trace_device(p, n, k.data_ptr(), end.data_ptr(), x0_shared=CAM, d_flags=fl.data_ptr(), d_n_steps=st.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append((end.cpu().numpy(), fl.cpu().numpy(), st.cpu().numpy()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_frame_batch_equals_single_frames(ctx):
     """Several cameras in ONE trace call (per-ray origins) give bit-identical rays, end states and pixels."""
     import torch
