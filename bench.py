@@ -140,8 +140,8 @@ def main():
         ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
         return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
 
-    pixels = bdist.rank_pixels(W, H, a.tile, rank, world,
-                               tile_cost=tile_cost if (a.lpt and a.workload == "frame") else None)
+    tcost = tile_cost if (a.lpt and a.workload == "frame") else None
+    pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
     jitter = python_random_stream(42.0, 2 * S * W * H)
     sky = synthetic_sky(2048, 1024)
     frames = []   # the DeviceFrames one step passes over
@@ -184,7 +184,9 @@ def main():
         ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
                                       stream=torch.cuda.current_stream().cuda_stream)
 
-    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=assemble)
+    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=assemble,
+                                   tile_cost=tcost)   # the gatherer must know the shards' pixel order
+    assert np.array_equal(gatherer.pixels, pixels)
     kernel_ms = []
 
     def step(i, timed):

@@ -70,10 +70,11 @@ struct bhg_context {
     void *d_ws = nullptr;
     size_t d_ws_bytes = 0;
     int32_t last_launch[4] = {0, 0, 0, 0};
+    int occupancy[48] = {0};  // resident waves per CU of each trace-kernel variant (0 = not asked yet)
     // optional per-pass timing (bhg_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around prepare | trace
 };
 
 namespace {
@@ -201,7 +202,7 @@ void bhg_destroy(bhg_context *c)
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->counter) (void)hipFree(c->counter);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 3; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -229,7 +230,7 @@ int bhg_set_profiling(bhg_context *c, int enable)
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (enable && !c->ev[0])
-        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     c->profiling = enable != 0;
     c->ev_valid = false;
     return BHG_OK;
@@ -240,8 +241,9 @@ int bhg_last_pass_ms(bhg_context *c, float out_ms[3])
     if (!c || !out_ms) return fail(BHG_E_INVALID, "bad argument");
     if (!c->ev_valid) return fail(BHG_E_INVALID, "no profiled trace call yet (bhg_set_profiling)");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[3]));
-    for (int i = 0; i < 3; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
+    out_ms[2] = 0.0f;  // events are resolved inside the trace kernel: there is no separate pass any more
     return BHG_OK;
 }
 
@@ -289,29 +291,24 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     hipStream_t s = (hipStream_t)stream;
 
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
-    //   ws      [n][6] doubles  per-ray records handed between the passes
+    //   ws      [n][8] doubles  per-ray records (Kerr prepare records; parked steps and resume records of the trace kernel)
     //   flags   [n] bytes       when the caller does not want flags
-    //   with a disk: n_steps / n_accepted [n] u32 when not wanted, two resume worklists [n] u32, two counts
+    //   n_steps / n_accepted [n] u32 when not wanted but a ray can be resumed (its counts then travel with its record)
     const bool has_exit = p->r_exit > 0.0;
-    // "has_disk": the call needs the resume machinery -- disk-plane crossings outside the annulus and
-    // chords through an object sphere that the curve itself misses both hand the ray to a further pass
-    const bool has_disk = p->disk_r_out > 0.0 || n_spheres > 0;
+    // "can_resume": a disk-plane crossing outside the annulus and a chord through an object sphere that the curve
+    // itself misses both send the ray back into the step loop
+    const bool can_resume = p->disk_r_out > 0.0 || n_spheres > 0;
     const size_t sz_ws = n * 8 * sizeof(double);
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
-    const size_t sz_steps = (has_disk && !d_n_steps) ? sz_u32 : 0;
-    const size_t sz_acc = (has_disk && !d_n_accepted) ? sz_u32 : 0;
-    const size_t sz_wl = has_disk ? 2 * sz_u32 + 64 : 0;
-    rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + sz_wl + 64);
+    const size_t sz_steps = (can_resume && !d_n_steps) ? sz_u32 : 0;
+    const size_t sz_acc = (can_resume && !d_n_accepted) ? sz_u32 : 0;
+    rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + 64);
     if (rc != BHG_OK) return rc;
     char *wsb = (char *)c->d_ws;
     uint8_t *w_flags = (uint8_t *)(wsb + sz_ws);
     uint32_t *w_steps = (uint32_t *)(wsb + sz_ws + sz_flags);
     uint32_t *w_acc = (uint32_t *)(wsb + sz_ws + sz_flags + sz_steps);
-    char *w_wl = wsb + sz_ws + sz_flags + sz_steps + sz_acc;
-    w_wl += (8 - ((uintptr_t)w_wl & 7)) & 7;
-    unsigned long long *w_count = (unsigned long long *)w_wl;  // two counters
-    uint32_t *w_list[2] = {(uint32_t *)(w_wl + 16), (uint32_t *)(w_wl + 16 + sz_u32)};
 
     bhg::TraceArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -320,14 +317,10 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.end = d_end;
     a.ws = (double *)c->d_ws;
     a.flags = d_flags ? d_flags : w_flags;
-    a.n_steps = d_n_steps ? d_n_steps : (has_disk ? w_steps : nullptr);
-    a.n_accepted = d_n_accepted ? d_n_accepted : (has_disk ? w_acc : nullptr);
+    a.n_steps = d_n_steps ? d_n_steps : (can_resume ? w_steps : nullptr);
+    a.n_accepted = d_n_accepted ? d_n_accepted : (can_resume ? w_acc : nullptr);
     a.counter = c->counter;
     a.n = n;
-    a.n_items = n;
-    a.worklist = nullptr;
-    a.worklist_out = has_disk ? w_list[0] : nullptr;
-    a.work_count_out = has_disk ? &w_count[0] : nullptr;
     if (!d_x0) {
         a.x0s[0] = x0_shared[0];
         a.x0s[1] = x0_shared[1];
@@ -355,8 +348,11 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
     // work-order hint: honoured when the call is that many equal blocks of whole 64-ray batches
-    if (p->order_blocks > 1 && n % p->order_blocks == 0 && (n / p->order_blocks) % 64 == 0 &&
-        !std::getenv("BHGEO_NO_ORDER_HINT")) {  // (the env switch is a tuning / A-B aid)
+    bool order_hint = p->order_blocks > 1 && n % p->order_blocks == 0 && (n / p->order_blocks) % 64 == 0;
+#ifdef BHG_TUNING
+    if (std::getenv("BHGEO_NO_ORDER_HINT")) order_hint = false;  // A/B aid, tuning builds only
+#endif
+    if (order_hint) {
         a.order_blocks = (int32_t)p->order_blocks;
         a.order_block_len = n / p->order_blocks;
     }
@@ -364,16 +360,23 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.n_spheres = n_spheres;
     for (int j = 0; j < n_spheres; j++)
         for (int q = 0; q < 4; q++) a.spheres[j][q] = spheres[4 * j + q];
-    const int evt = n_spheres > 0 ? 7 : ((has_exit ? 1 : 0) | (has_disk ? 2 : 0));
+    const int evt = n_spheres > 0 ? 7 : ((has_exit ? 1 : 0) | (p->disk_r_out > 0.0 ? 2 : 0));
 
-    int per_cu = 0;
-    HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, evt, &per_cu));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 32) per_cu = 32;
-    if (const char *ov = std::getenv("BHGEO_WAVES_PER_CU")) {  // tuning/diagnostic override
+    // resident waves per CU of the trace kernel variant: asked of the runtime once per variant and context
+    const int vkey = ((p->method & 1) * 3 + (p->rhs_form % 3)) * 8 + evt;
+    int per_cu = c->occupancy[vkey];
+    if (per_cu == 0) {
+        HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, evt, &per_cu));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 32) per_cu = 32;
+        c->occupancy[vkey] = per_cu;
+    }
+#ifdef BHG_TUNING
+    if (const char *ov = std::getenv("BHGEO_WAVES_PER_CU")) {  // tuning / diagnostic override
         int v = std::atoi(ov);
         if (v >= 1 && v <= 64) per_cu = v;
     }
+#endif
     // persistent waves: fill every resident wave slot once; never more waves than 64-ray batches
     size_t batches = (n + 63) / 64;
     size_t grid = (size_t)per_cu * (size_t)c->num_cus;
@@ -395,37 +398,13 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
         }
     }
 #endif
+    // ONE persistent launch finishes every ray: events are resolved and rays resumed inside the trace kernel, so
+    // the call only enqueues (Kerr: prepare, trace, finalize) and returns
     HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));  // 8 slice counters, one 256-byte line each
-    if (has_disk) HIP_TRY(hipMemsetAsync(w_count, 0, 16, s));
     HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
     c->ev_valid = c->profiling;
     c->last_launch[3] = 1;
-    if (has_disk) {
-        // Rays whose step crossed the disk plane outside the annulus carry on: the resolve pass has
-        // listed them; trace + resolve again over that list until it is empty.  Reading the count
-        // synchronises the stream, so with a disk this entry point is not asynchronous.
-        for (int pass = 0; pass < 4096; pass++) {
-            unsigned long long cnt = 0;
-            HIP_TRY(hipMemcpyAsync(&cnt, &w_count[pass & 1], sizeof(cnt), hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            if (cnt == 0) break;
-            c->last_launch[3] = pass + 2;
-            a.n_items = cnt;
-            a.order_blocks = 0;
-            a.worklist = w_list[pass & 1];
-            a.worklist_out = w_list[(pass + 1) & 1];
-            a.work_count_out = &w_count[(pass + 1) & 1];
-            size_t g2 = (size_t)per_cu * (size_t)c->num_cus, b2 = ((size_t)cnt + 63) / 64;
-            if (g2 > b2) g2 = b2;
-            HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));
-            HIP_TRY(hipMemsetAsync(&w_count[(pass + 1) & 1], 0, sizeof(cnt), s));
-            HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)g2, s, nullptr));
-        }
-    }
-    if (p->rhs_form == BHG_RHS_KERR_BL) {
-        a.n_items = n;
-        HIP_TRY(bhg::launch_kerr_finalize(a, s));
-    }
+    if (p->rhs_form == BHG_RHS_KERR_BL) HIP_TRY(bhg::launch_kerr_finalize(a, s));
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;
@@ -690,7 +669,6 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.n_accepted = (uint32_t *)(o + off_acc);
     a.counter = c->counter;
     a.n = n;
-    a.n_items = n;
     if (!d_x0) {
         a.x0s[0] = x0[0];
         a.x0s[1] = x0[1];

@@ -28,24 +28,21 @@ struct TraceArgs {
     const double *k0;            // [n][3]
     const double *x0;            // [n][3] or nullptr -> x0s
     double *end;                 // [n][6]
-    uint8_t *flags;              // [n] (never null inside the kernels: the C-ABI layer substitutes a workspace)
-    uint32_t *n_steps;           // [n] or nullptr
-    uint32_t *n_accepted;        // [n] or nullptr
+    uint8_t *flags;              // [n] (never null inside the kernels: the C-ABI layer substitutes a workspace); only ever holds final values
+    uint32_t *n_steps;           // [n] or nullptr (never null when a ray can be resumed: disk or object spheres)
+    uint32_t *n_accepted;        // [n] or nullptr (ditto)
     unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
     double *ws;                  // [n][ws_stride] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
+                                 // (park / resume records are written and read back by ONE wavefront of the trace kernel)
     uint64_t n;                  // rays in the call
-    uint64_t n_items;            // work items of this pass: n, or the length of worklist
-    const uint32_t *worklist;    // nullptr (item j = ray j) or ray indices to resume
-    uint32_t *worklist_out;      // rays the resolve pass hands to the next pass
-    unsigned long long *work_count_out;
     double x0s[3];
     double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, disk_r_in, disk_r_out;
     double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
     double r_hor;                // horizon event radius: r_s, or r_plus (1 + margin) for Kerr
     int32_t ws_stride;           // doubles per ray record in ws: 6, or 8 for Kerr ({E, L} appended)
-    int32_t from_records;        // pass 0 starts rays from records the prepare pass wrote (Kerr)
-    int32_t inline_prepare;      // set by the launcher: first pass without a prepare launch (Schwarzschild forms)
-    int32_t order_blocks;        // work-order hint (first pass only): n = order_blocks * order_block_len, batches are
+    int32_t from_records;        // rays start from the records the prepare pass wrote (Kerr)
+    int32_t inline_prepare;      // set by the launcher: no prepare launch, the trace waves work the start records out (Schwarzschild forms)
+    int32_t order_blocks;        // work-order hint: n = order_blocks * order_block_len, batches are
     uint64_t order_block_len;    // handed out chunk-major over the blocks; 0/1 = plain order
     uint32_t max_steps;
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
@@ -92,7 +89,7 @@ hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
 hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s);
 
-// ev: nullptr, or 4 events recorded around prepare | trace | resolve on stream s
+// ev: nullptr, or 3 events recorded around prepare | trace on stream s
 // evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event, bit 2 = object spheres (then all three)
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);

@@ -446,33 +446,37 @@ __device__ __forceinline__ double pow_0p2(double x)
 }
 
 // ------------------------------------------------------------------------------------------
-// Per-wave LDS: a queue of prepared rays (filled converged, drained lane by lane) and a queue
-// of steps that crossed the horizon / exit sphere (filled lane by lane, drained converged).
+// Per-wave LDS: a queue of prepared rays (filled converged, drained lane by lane), the list of rays
+// whose last step is parked for the event drain (filled lane by lane, drained converged) and the
+// list of rays the drain hands back for more steps.
 // ------------------------------------------------------------------------------------------
+// Rays a wave owns at any time: <= 64 in its lanes, <= 64 queued, the rest parked or waiting to resume.  A new batch
+// is only claimed when the resume list is empty and fewer than 64 events are parked, so a wave never owns more
+// than 64 + 63 + 64 = 191 rays: neither list can overflow its 192 slots.
+constexpr int EVQ_CAP = 192;
+
+template <int RHS>
 struct WaveLds {
+    static constexpr int NK = (RHS == BHG_RHS_KERR_BL_) ? 64 : 1;
     // prepared rays (filled converged -- start records worked out in place or read from the prepare / resume
-    // records -- and drained lane by lane)
+    // records -- and drained lane by lane); while the event drain runs, the lanes' own rays are kept here
     double qx[3][64];
     double qk[3][64];
     double qa[3][64];  // FSAL acceleration at the start point
     double qh[64];     // |h| to try first (initial step, common.py:68-134; or the controller's next step)
     double qr[64];     // r at the start point
     double qt[64];     // lambda at the start point (0 unless the ray is resumed)
-    double qE[64], qL[64];  // Kerr: the ray's Killing constants
+    double qE[NK], qL[NK];  // Kerr: the ray's Killing constants
     uint32_t qidx[64];
     uint32_t qnatt[64], qnacc[64];
+    uint32_t ev_idx[EVQ_CAP];   // rays whose last accepted step (may have) crossed an event surface
+    uint32_t res_idx[EVQ_CAP];  // rays whose parked step held no terminal event after all: they carry on
+    uint8_t ev_kind[EVQ_CAP];   // EV_* bits of the parked step
+    uint8_t qflag[64];          // lane state kept across the event drain: bit 0 active, bit 1 rejected
 };
 
-// Internal values of flags[i] between the passes (never visible after the call returns):
-//   EV_TAG | kind << 2 : the ray's last accepted step crossed (or may have crossed) an event surface;
-//                        the resolve pass locates the root(s) (kind bits below, never 0)
-//   EV_RESUME          : the step held no terminal event after all (disk plane outside the annulus, a
-//                        chord through an object the curve itself misses); the ray carries on from the
-//                        end of that step in the next trace pass
-// Both have bit 1 set and bit 0 clear, which no final value has: BHG_FLAG_START_INSIDE (2) only ever
-// comes together with BHG_FLAG_HIT_HORIZON (1).
-constexpr uint32_t EV_TAG = 2u, EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u, EV_RESUME = 0x42u;
-__device__ __forceinline__ uint32_t pending_kind(uint32_t fl) { return ((fl & 3u) == EV_TAG) ? ((fl >> 2) & 0xFu) : 0u; }
+// Kinds of event a parked step may hold (bits of WaveLds::ev_kind; they never reach flags[]).
+constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 
 // Does the accepted step x0 -> x1 possibly enter one of the object spheres?  A ray outside sphere j at the
@@ -588,6 +592,7 @@ struct Lane {
 
 struct Wave {
     int q_head, q_count;
+    int ev_count, res_count;     // entries of the parked-event list and of the resume list
     bool exhausted;
     uint32_t slice, dry;         // current slice, number of slices found dry so far
     bool have_pending;
@@ -704,22 +709,19 @@ __device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric 
     }
 }
 
-// Fill the LDS ray queue with work items base .. base+63: coalesced loads of k0, x0 and the
-// prepare pass's record {a0, h0, r0} -- or, in a resume pass (A.worklist set), of the records the
-// resolve pass left in the rays' own slots.  Items that pass (h >= 0) are compacted with ballot/mbcnt.
+// Fill the LDS ray queue with rays base .. base+63: coalesced loads of k0, x0 and -- Kerr -- of the prepare
+// pass's record {a0, h0, r0, 0, E, L}; the Schwarzschild forms work the records out here, all lanes together.
+// Items that pass (h >= 0) are compacted with ballot/mbcnt.
 template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave &W, uint32_t lane, uint64_t base)
+__device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane, uint64_t base)
 {
-    // first pass of the Schwarzschild forms: no prepare pass has run, the wave works the records out itself
+    // Schwarzschild forms: no prepare pass has run, the wave works the records out itself
     const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && A.inline_prepare;
-    const uint64_t j = base + lane;
-    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0, pt = 0.0;
+    const uint64_t i = base + lane;
+    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0;
     double pE = 0.0, pL = 0.0;
-    uint32_t natt = 0, nacc = 0;
-    uint64_t i = j;
-    if (j < A.n_items) {
-        if (A.worklist || A.from_records) {
-            if (A.worklist) i = A.worklist[j];
+    if (i < A.n) {
+        if (A.from_records) {
             const double *e = A.end + i * 6;
             px[0] = e[0];
             px[1] = e[1];
@@ -733,14 +735,9 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
             pa[2] = w[2];
             ph = w[3];
             pr = w[4];
-            pt = w[5];
             if (A.ws_stride == 8) {
                 pE = w[6];
                 pL = w[7];
-            }
-            if (A.worklist) {
-                natt = A.n_steps[i];
-                nacc = A.n_accepted[i];
             }
         } else {
             if (!inline_prepare) {
@@ -769,7 +766,7 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
     // to assume they may still be in flight on the not-valid path and puts a vmcnt(0) in front of
     // the step code, which then waits for the previous iteration's result stores every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && j < A.n_items) {
+    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && i < A.n) {
         if (A.object_id) A.object_id[i] = (int8_t)-1;
         const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
         if (r0 <= A.r_hor) {
@@ -796,85 +793,77 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds &Q, Wave 
         }
         Q.qh[s] = ph;
         Q.qr[s] = pr;
-        Q.qt[s] = pt;
-        Q.qE[s] = pE;
-        Q.qL[s] = pL;
+        Q.qt[s] = 0.0;
+        if (RHS == BHG_RHS_KERR_BL_) {
+            Q.qE[s] = pE;
+            Q.qL[s] = pL;
+        }
         Q.qidx[s] = (uint32_t)i;
-        Q.qnatt[s] = natt;
-        Q.qnacc[s] = nacc;
+        Q.qnatt[s] = 0;
+        Q.qnacc[s] = 0;
     }
     wave_lds_sync();
     W.q_head = 0;
     W.q_count = __builtin_popcountll(vmask);
 }
 
-// Give idle lanes new rays.  Returns the idle mask afterwards (all ones: nothing left at all).
-template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds &Q, Wave &W, Lane &L, uint32_t lane,
-                                           uint64_t idle)
+// Fill the ray queue from the wave's resume list (up to 64 rays): the event drain left each of them a record
+// {x, k} in its end[] slot and {a, h_next, r, lambda, (E, L)} in its ws[] slot, step counts in n_steps / n_accepted.
+// Written and read by this one wavefront (in-order through the CU's vector cache): no other wave ever sees them.
+template <int RHS>
+__device__ __forceinline__ void fill_resumed(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane)
 {
-    for (;;) {
-        if (W.q_count == 0) {
-            if (W.exhausted) break;
-            if (!W.have_pending) W.pending = issue_fetch(A, lane, W.slice);
-            W.have_pending = false;
-            const uint64_t base = take_fetch(W.pending, W.slice);
-            if (base >= A.n_items) {
-                // this slice is dry: steal from the next one
-                W.slice = (W.slice + 1) % NSLICE;
-                if (++W.dry == NSLICE) W.exhausted = true;
-                continue;
-            }
-            uint64_t first = base;
-            if (A.order_blocks > 1) {
-                // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
-                // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
-                // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
-                // the caller's pixels sorted longest-first the long rays then all start early, instead of once
-                // per block through the whole launch.  A pure permutation of the batch order.
-                const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
-                first = sblk * A.order_block_len + (q << 6);
-            }
-            fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
-            if (W.q_count == 0) continue;
+    const int take = W.res_count < 64 ? W.res_count : 64;
+    const int base = W.res_count - take;
+    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = 0.0, pt = 0.0;
+    double pE = 0.0, pL = 0.0;
+    uint32_t natt = 0, nacc = 0, i = 0;
+    if ((int)lane < take) {
+        i = Q.res_idx[base + lane];
+        const double *e = A.end + (uint64_t)i * 6;
+        px[0] = e[0];
+        px[1] = e[1];
+        px[2] = e[2];
+        pk[0] = e[3];
+        pk[1] = e[4];
+        pk[2] = e[5];
+        const double *w = A.ws + (uint64_t)i * (uint64_t)A.ws_stride;
+        pa[0] = w[0];
+        pa[1] = w[1];
+        pa[2] = w[2];
+        ph = w[3];
+        pr = w[4];
+        pt = w[5];
+        if (RHS == BHG_RHS_KERR_BL_) {
+            pE = w[6];
+            pL = w[7];
         }
-        const int n_idle = __builtin_popcountll(idle);
-        const int take = n_idle < W.q_count ? n_idle : W.q_count;
-        if (!L.active) {
-            const int rk = (int)lane_rank(idle);
-            if (rk < take) {
-                const int s = W.q_head + rk;
+        natt = A.n_steps[i];
+        nacc = A.n_accepted[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (see fill_batch)
+    if ((int)lane < take) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    L.x[c] = Q.qx[c][s];
-                    L.v[c] = Q.qk[c][s];
-                    L.a1[c] = Q.qa[c][s];
-                }
-                L.h_abs = Q.qh[s];
-                L.r_cur = Q.qr[s];
-                L.idx = Q.qidx[s];
-                L.t = Q.qt[s];
-                L.E = Q.qE[s];
-                L.Lz = Q.qL[s];
-                L.n_att = Q.qnatt[s];
-                L.n_acc = Q.qnacc[s];
-                L.rejected = false;
-                L.active = true;
-            }
+        for (int c = 0; c < 3; c++) {
+            Q.qx[c][lane] = px[c];
+            Q.qk[c][lane] = pk[c];
+            Q.qa[c][lane] = pa[c];
         }
-        wave_lds_sync();
-        W.q_head += take;
-        W.q_count -= take;
-        idle = __ballot(!L.active);
-        if (!idle) break;
+        Q.qh[lane] = ph;
+        Q.qr[lane] = pr;
+        Q.qt[lane] = pt;
+        if (RHS == BHG_RHS_KERR_BL_) {
+            Q.qE[lane] = pE;
+            Q.qL[lane] = pL;
+        }
+        Q.qidx[lane] = i;
+        Q.qnatt[lane] = natt;
+        Q.qnacc[lane] = nacc;
     }
-    // claim the next batch just before it is needed: the fetch is in flight while the last few
-    // queued rays are handed out, and no wave sits on unstarted batches at the end of the kernel
-    if (!W.have_pending && !W.exhausted && W.q_count <= 8) {
-        W.pending = issue_fetch(A, lane, W.slice);
-        W.have_pending = true;
-    }
-    return idle;
+    wave_lds_sync();
+    W.res_count = base;
+    W.q_head = 0;
+    W.q_count = take;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1089,13 +1078,14 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
 }
 
 // The step held no terminal event after all: the ray is final if the step reached lambda_end
-// (base.py:203-204), otherwise it is handed to the next trace pass, resuming at the step's end.
-__device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t idx, const double xn[3], const double vn[3],
+// (base.py:203-204); otherwise it carries on from the step's end -- its resume record is left in its own end[] /
+// ws[] slots and the caller puts it on the wave's resume list (returns true).
+__device__ __forceinline__ bool finish_or_resume(const TraceArgs &A, uint32_t idx, const double xn[3], const double vn[3],
                                                  const double an[3], double t_new, double r_new, double h_next)
 {
     if (t_new - A.lambda_end >= 0.0) {
         store_event_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_);
-        return;
+        return false;
     }
     double *e = A.end + (size_t)idx * 6;
     reinterpret_cast<double2 *>(e)[0] = make_double2(xn[0], xn[1]);
@@ -1108,22 +1098,13 @@ __device__ __forceinline__ void finish_or_resume(const TraceArgs &A, uint32_t id
     w[3] = h_next;
     w[4] = r_new;
     w[5] = t_new;
-    A.flags[idx] = (uint8_t)EV_RESUME;
-    // one atomic per wavefront, not per ray: a single counter word saturates near 90 adds/us and a
-    // config-3 frame resumes most of its million rays (the lanes that reach this point add together)
-    const uint64_t act = __ballot(1);
-    const uint32_t rank = lane_rank(act);
-    unsigned long long base = 0;
-    if (rank == 0) base = atomicAdd(A.work_count_out, (unsigned long long)__builtin_popcountll(act));
-    const int leader = __builtin_ctzll(act);
-    const uint32_t blo = __shfl((uint32_t)base, leader), bhi = __shfl((uint32_t)(base >> 32), leader);
-    A.worklist_out[(((unsigned long long)bhi << 32) | blo) + rank] = idx;
+    return true;
 }
 
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
 template <int RHS>
-__device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
+__device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                    const double a1[3], double t, double t_new, double h,
                                                    double h_next, uint32_t kind, uint32_t idx, const Metric &m)
 {
@@ -1160,7 +1141,7 @@ __device__ __forceinline__ void dp54_resolve_event(const TraceArgs &A, const dou
             dense_dir(d, tt, ve);
         },
         RHS == BHG_RHS_KERR_BL_);
-    if (!ended) finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
+    return ended ? false : finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1225,7 +1206,7 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
 }
 
 template <int RHS>
-__device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
+__device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                   const double a1[3], double t, double t_new, double h,
                                                   double h_next, uint32_t kind, uint32_t idx, const Metric &m)
 {
@@ -1252,15 +1233,15 @@ __device__ __forceinline__ void rk4_resolve_event(const TraceArgs &A, const doub
             hermite_eval(d, tt, xe, vv);
         },
         [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); }, RHS == BHG_RHS_KERR_BL_);
-    if (!ended) finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
+    return ended ? false : finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
 }
 
 // ------------------------------------------------------------------------------------------
-// A lane whose accepted step crossed the horizon / exit sphere parks the step's START state in
-// global memory (its own end[] slot and its prepare-record slot, both free by now) and refills at
-// once; the resolve pass recomputes that step converged and locates the root.
+// A lane whose accepted step crossed (or may have crossed) an event surface parks the step's START state in
+// global memory (its own end[] slot and its ws[] record slot, both free by now) and refills at once; the ray's
+// index goes on the wave's parked-event list and the event drain below recomputes that step converged.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, double t_new, uint32_t kind)
+__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, double t_new)
 {
     // ws[idx] = {a1, t_new, h, |h| the controller chose for the NEXT step (L.h_abs, already updated)}.
     // t_new is stored as the integrate loop computed it (possibly clipped to lambda_end): t + h need
@@ -1276,9 +1257,188 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
     w[3] = t_new;
     w[4] = h;
     w[5] = L.h_abs;
-    A.flags[L.idx] = (uint8_t)(EV_TAG | (kind << 2));
     if (A.n_steps) A.n_steps[L.idx] = L.n_att;
     if (A.n_accepted) A.n_accepted[L.idx] = L.n_acc;
+}
+
+// Put this iteration's parked rays on the wave's event list.  Called from uniform control flow with kind != 0 on
+// the lanes that parked.
+template <int RHS>
+__device__ __forceinline__ void push_events(WaveLds<RHS> &Q, Wave &W, uint32_t idx, uint32_t kind)
+{
+    const uint64_t pm = __ballot(kind != 0u);
+    if (pm) {
+        if (kind) {
+            const uint32_t s = (uint32_t)W.ev_count + lane_rank(pm);
+            Q.ev_idx[s] = idx;
+            Q.ev_kind[s] = (uint8_t)kind;
+        }
+        W.ev_count += __builtin_popcountll(pm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Event drain: up to 64 parked steps are recomputed, one per lane, their dense output built and the event roots
+// located by Brent (scipy's solve_event_equation); the earliest terminal root ends the ray.  A step that holds no
+// terminal event after all (disk plane crossed outside the annulus, a chord through an object sphere that the
+// curve itself misses) sends its ray to the wave's resume list.  Runs only when the ray queue is empty: the
+// lanes' own rays wait in the queue's storage meanwhile, so the drain has the whole register budget and the
+// root search always runs (nearly) 64 lanes wide -- never one lane wide inside the step loop.
+// ------------------------------------------------------------------------------------------
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        Q.qx[c][lane] = L.x[c];
+        Q.qk[c][lane] = L.v[c];
+        Q.qa[c][lane] = L.a1[c];
+    }
+    Q.qh[lane] = L.h_abs;
+    Q.qr[lane] = L.r_cur;
+    Q.qt[lane] = L.t;
+    if (RHS == BHG_RHS_KERR_BL_) {
+        Q.qE[lane] = L.E;
+        Q.qL[lane] = L.Lz;
+    }
+    Q.qidx[lane] = L.idx;
+    Q.qnatt[lane] = L.n_att;
+    Q.qnacc[lane] = L.n_acc;
+    Q.qflag[lane] = (uint8_t)((L.active ? 1u : 0u) | (L.rejected ? 2u : 0u));
+    wave_lds_sync();
+
+    const int take = W.ev_count < 64 ? W.ev_count : 64;
+    const int base = W.ev_count - take;
+    bool resumed = false;
+    uint32_t i = 0;
+    if ((int)lane < take) {
+        i = Q.ev_idx[base + lane];
+        const uint32_t kind = Q.ev_kind[base + lane];
+        const double *e = A.end + (uint64_t)i * 6;
+        const double *w = A.ws + (uint64_t)i * (uint64_t)A.ws_stride;
+        double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
+        const double t_new = w[3], h = w[4], h_next = w[5];
+        const double t = t_new - h;  // the step's start, good to an ulp: only brackets the root search
+        Metric met;
+        met.r_s = A.r_s;
+        met.M = 0.5 * A.r_s;
+        met.a = A.spin;
+        met.E = met.L = 0.0;
+        if (RHS == BHG_RHS_KERR_BL_) {
+            met.E = w[6];
+            met.L = w[7];
+        }
+        if (ADAPTIVE)
+            resumed = dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+        else
+            resumed = rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+    }
+    const uint64_t rm = __ballot(resumed);
+    if (resumed) Q.res_idx[(uint32_t)W.res_count + lane_rank(rm)] = i;
+    W.ev_count = base;
+    W.res_count += __builtin_popcountll(rm);
+    wave_lds_sync();
+
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        L.x[c] = Q.qx[c][lane];
+        L.v[c] = Q.qk[c][lane];
+        L.a1[c] = Q.qa[c][lane];
+    }
+    L.h_abs = Q.qh[lane];
+    L.r_cur = Q.qr[lane];
+    L.t = Q.qt[lane];
+    if (RHS == BHG_RHS_KERR_BL_) {
+        L.E = Q.qE[lane];
+        L.Lz = Q.qL[lane];
+    }
+    L.idx = Q.qidx[lane];
+    L.n_att = Q.qnatt[lane];
+    L.n_acc = Q.qnacc[lane];
+    const uint32_t fl = Q.qflag[lane];
+    L.active = (fl & 1u) != 0u;
+    L.rejected = (fl & 2u) != 0u;
+    wave_lds_sync();
+}
+
+// Give idle lanes new rays.  Returns the idle mask afterwards (all ones: the wave is done -- nothing in flight,
+// queued, parked or waiting to resume, and no batch left to claim).
+template <int RHS, bool ADAPTIVE>
+__device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane,
+                                           uint64_t idle)
+{
+    for (;;) {
+        if (W.q_count == 0) {
+            // The queue's storage is free: the moment to work off parked events 64 lanes wide -- whenever 64 have
+            // piled up, or, at the very end (no batch left, nothing to resume, every lane idle), whatever is left.
+            while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull))
+                drain_events<RHS, ADAPTIVE>(A, Q, W, L, lane);
+            if (W.res_count > 0) {
+                fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
+            } else {
+                if (W.exhausted) break;
+                if (!W.have_pending) W.pending = issue_fetch(A, lane, W.slice);
+                W.have_pending = false;
+                const uint64_t base = take_fetch(W.pending, W.slice);
+                if (base >= A.n) {
+                    // this slice is dry: steal from the next one
+                    W.slice = (W.slice + 1) % NSLICE;
+                    if (++W.dry == NSLICE) W.exhausted = true;
+                    continue;
+                }
+                uint64_t first = base;
+                if (A.order_blocks > 1) {
+                    // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
+                    // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
+                    // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
+                    // the caller's pixels sorted longest-first the long rays then all start early, instead of once
+                    // per block through the whole launch.  A pure permutation of the batch order.
+                    const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
+                    first = sblk * A.order_block_len + (q << 6);
+                }
+                fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
+                if (W.q_count == 0) continue;
+            }
+        }
+        const int n_idle = __builtin_popcountll(idle);
+        const int take = n_idle < W.q_count ? n_idle : W.q_count;
+        if (!L.active) {
+            const int rk = (int)lane_rank(idle);
+            if (rk < take) {
+                const int s = W.q_head + rk;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    L.x[c] = Q.qx[c][s];
+                    L.v[c] = Q.qk[c][s];
+                    L.a1[c] = Q.qa[c][s];
+                }
+                L.h_abs = Q.qh[s];
+                L.r_cur = Q.qr[s];
+                L.idx = Q.qidx[s];
+                L.t = Q.qt[s];
+                if (RHS == BHG_RHS_KERR_BL_) {
+                    L.E = Q.qE[s];
+                    L.Lz = Q.qL[s];
+                }
+                L.n_att = Q.qnatt[s];
+                L.n_acc = Q.qnacc[s];
+                L.rejected = false;
+                L.active = true;
+            }
+        }
+        wave_lds_sync();
+        W.q_head += take;
+        W.q_count -= take;
+        idle = __ballot(!L.active);
+        if (!idle) break;
+    }
+    // claim the next batch just before it is needed: the fetch is in flight while the last few
+    // queued rays are handed out, and no wave sits on unstarted batches at the end of the kernel
+    if (!W.have_pending && !W.exhausted && W.q_count <= 8 && W.res_count == 0) {
+        W.pending = issue_fetch(A, lane, W.slice);
+        W.have_pending = true;
+    }
+    return idle;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1293,7 +1453,7 @@ __device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, do
 template <int RHS, int EVT>
 __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A)
 {
-    __shared__ WaveLds Q;
+    __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
     const double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     const double max_step = A.max_step;
@@ -1312,6 +1472,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     L.active = L.rejected = false;
     Wave W;
     W.q_head = W.q_count = 0;
+    W.ev_count = W.res_count = 0;
     W.exhausted = false;
 #ifdef BHG_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1334,6 +1495,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         diag_lanes += __builtin_popcountll(__ballot(L.active));
 #endif
 
+        uint32_t parked = 0;  // EV_* bits if this lane parks its step in this iteration
         if (L.active) {
             // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
             uint32_t term = 0;
@@ -1402,9 +1564,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                                                   : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                         ev_d = false;
                     if (ev_h || ev_e || ev_d || ev_o) {
-                        // x, v, a1, t still hold the step's start: the resolve pass recomputes it
-                        park_event(A, L, h, t_new,
-                                   (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u));
+                        // x, v, a1, t still hold the step's start: the event drain recomputes it
+                        park_event(A, L, h, t_new);
+                        parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
                         L.active = false;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
@@ -1425,6 +1587,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 }
             }
         }
+        push_events<RHS>(Q, W, L.idx, parked);
     }
 #ifdef BHG_DIAG
     if (lane == 0 && A.diag) {
@@ -1444,7 +1607,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 template <int RHS, int EVT>
 __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 {
-    __shared__ WaveLds Q;
+    __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
     const double r_s = A.r_hor, t_bound = A.lambda_end, hf = A.h_fixed;  // r_s: horizon EVENT radius
     Metric met;
@@ -1462,6 +1625,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     L.active = L.rejected = false;
     Wave W;
     W.q_head = W.q_count = 0;
+    W.ev_count = W.res_count = 0;
     W.exhausted = false;
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
@@ -1474,6 +1638,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
             idle = refill<RHS, false>(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;
         }
+        uint32_t parked = 0;
         if (L.active) {
             uint32_t term = 0;
             if (L.t >= t_bound)
@@ -1506,8 +1671,8 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 if (ev_h || ev_e || ev_d || ev_o) {
                     L.n_acc = L.n_att;
                     L.h_abs = hf;
-                    park_event(A, L, h, t_new,
-                               (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u));
+                    park_event(A, L, h, t_new);
+                    parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
                     L.active = false;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1524,6 +1689,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 }
             }
         }
+        push_events<RHS>(Q, W, L.idx, parked);
     }
 }
 
@@ -1536,7 +1702,7 @@ template <int RHS, bool ADAPTIVE>
 __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n_items) return;
+    if (i >= A.n) return;
     double px[3], pk[3], pa[3], pr = 0.0, ph = 0.0;
     pk[0] = A.k0[i * 3 + 0];
     pk[1] = A.k0[i * 3 + 1];
@@ -1618,39 +1784,6 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
         e[4] = pk[1];
         e[5] = pk[2];
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Resolve pass (one thread per ray, almost all exit at once): rays parked with a pending-event code get
-// their crossing step recomputed, the quartic dense output built and the root located by Brent.
-// ------------------------------------------------------------------------------------------
-template <int RHS, bool ADAPTIVE>
-__global__ void __launch_bounds__(64) resolve_kernel(const TraceArgs A)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= A.n_items) return;
-    const uint64_t i = A.worklist ? A.worklist[j] : j;
-    const uint32_t fl = A.flags[i];
-    const uint32_t kind = pending_kind(fl);
-    if (kind == 0u) return;
-    const double *e = A.end + i * 6;
-    const double *w = A.ws + i * (uint64_t)A.ws_stride;
-    double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
-    const double t_new = w[3], h = w[4], h_next = w[5];
-    const double t = t_new - h;  // the step's start, good to an ulp: only brackets the root search
-    Metric met;
-    met.r_s = A.r_s;
-    met.M = 0.5 * A.r_s;
-    met.a = A.spin;
-    met.E = met.L = 0.0;
-    if (RHS == BHG_RHS_KERR_BL_) {
-        met.E = w[6];
-        met.L = w[7];
-    }
-    if (ADAPTIVE)
-        dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, (uint32_t)i, met);
-    else
-        rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, (uint32_t)i, met);
 }
 
 #ifdef BHG_TU_KERR
@@ -1905,15 +2038,14 @@ __global__ void accel_kernel(const double *x, const double *k, double r_s, uint6
 template <int RHS, int EVT>
 static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hipStream_t s, hipEvent_t *ev)
 {
-    const unsigned gp = (unsigned)((a_in.n_items + 255) / 256), gr = (unsigned)((a_in.n_items + 63) / 64);
-    const bool first = a_in.worklist == nullptr;  // resume passes skip the prepare pass
+    const unsigned gp = (unsigned)((a_in.n + 255) / 256);
     // Schwarzschild forms: the trace kernel's waves work out the start records themselves while they fill
     // their ray queues (converged, 64 lanes wide) -- no prepare launch, no 40-byte record round trip per ray.
     // Kerr keeps the prepare pass (Cartesian -> Boyer-Lindquist, E and L: trig-heavy, 200 registers).
     TraceArgs a = a_in;
-    a.inline_prepare = (first && RHS != BHG_RHS_KERR_BL_ && BHG_INLINE_PREPARE) ? 1 : 0;
+    a.inline_prepare = (RHS != BHG_RHS_KERR_BL_ && BHG_INLINE_PREPARE) ? 1 : 0;
     if (ev) (void)hipEventRecord(ev[0], s);
-    if (first && !a.inline_prepare) {
+    if (!a.inline_prepare) {
         if (method == BHG_METHOD_RK4_)
             hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
         else
@@ -1925,11 +2057,6 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
     else
         hipLaunchKernelGGL((trace_dp54_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
     if (ev) (void)hipEventRecord(ev[2], s);
-    if (method == BHG_METHOD_RK4_)
-        hipLaunchKernelGGL((resolve_kernel<RHS, false>), dim3(gr), dim3(64), 0, s, a);
-    else
-        hipLaunchKernelGGL((resolve_kernel<RHS, true>), dim3(gr), dim3(64), 0, s, a);
-    if (ev) (void)hipEventRecord(ev[3], s);
     return hipGetLastError();
 }
 

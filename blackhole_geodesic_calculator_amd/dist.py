@@ -15,27 +15,51 @@ def tile_grid(width: int, height: int, tile: int):
     return (int(width) + tile - 1) // tile, (int(height) + tile - 1) // tile
 
 
-def rank_tiles(width: int, height: int, tile: int, rank: int, world: int) -> np.ndarray:
-    """Tile ids (row-major over the tile grid) owned by `rank`: id % world == rank."""
+def _tile_costs(width, height, tile, tile_cost):
     tx, ty = tile_grid(width, height, tile)
-    return np.arange(rank, tx * ty, world, dtype=np.int64)
+    ids = np.arange(tx * ty, dtype=np.int64)
+    return np.array([tile_cost((x + 0.5) * tile, (y + 0.5) * tile) for y, x in zip(ids // tx, ids % tx)], dtype=np.float64)
+
+
+def tile_owner(width: int, height: int, tile: int, world: int, tile_cost=None) -> np.ndarray:
+    """Owner rank of every tile (row-major over the tile grid).
+
+    Without a cost: tiles are dealt cyclically along each tile row and every row starts one rank further on,
+    owner = (tile_x + tile_y) % world.  (Plain id % world hands out whole tile COLUMNS whenever the tiles per row
+    divide by the world size -- 32, 64, 128 tiles per row against 2, 4, 8 ranks.)
+    With tile_cost(cx, cy) -> float (expected work of the tile centred there): the tiles are sorted by decreasing
+    cost (stable) and dealt round-robin in THAT order, so every rank gets one of each `world` consecutive tiles
+    of the cost ranking -- longest-processing-time-first across ranks.  A thin ring of expensive tiles (the
+    shadow edge) then spreads to within one tile per rank, where any fixed lattice leaves +-10 % at 8 ranks."""
+    tx, ty = tile_grid(width, height, tile)
+    ids = np.arange(tx * ty, dtype=np.int64)
+    if tile_cost is None:
+        return (ids % tx + ids // tx) % int(world)
+    order = np.argsort(-_tile_costs(width, height, tile, tile_cost), kind="stable")
+    own = np.empty(tx * ty, dtype=np.int64)
+    own[order] = np.arange(tx * ty, dtype=np.int64) % int(world)
+    return own
+
+
+def rank_tiles(width: int, height: int, tile: int, rank: int, world: int, tile_cost=None) -> np.ndarray:
+    """Tile ids (row-major over the tile grid) owned by `rank`: ascending, or -- with a cost -- by decreasing cost."""
+    mine = np.nonzero(tile_owner(width, height, tile, world, tile_cost) == int(rank))[0].astype(np.int64)
+    if tile_cost is not None:
+        mine = mine[np.argsort(-_tile_costs(width, height, tile, tile_cost)[mine], kind="stable")]
+    return mine
 
 
 def rank_pixels(width: int, height: int, tile: int, rank: int, world: int, tile_cost=None) -> np.ndarray:
     """Flat pixel indices (y*W + x) owned by `rank`, tile after tile, row-major inside a tile.
 
-    tile_cost(cx, cy) -> float, optional: the rank's tiles are visited in order of DECREASING cost
-    (longest-processing-time-first: the expensive rays near the photon sphere start early and the
-    kernel's tail is made of cheap far-field rays).  Which pixels a rank owns does not change."""
+    tile_cost(cx, cy) -> float, optional: tiles are dealt to the ranks by cost ranking (tile_owner) and each rank
+    visits its tiles in order of DECREASING cost (the expensive rays near the photon sphere start early and the
+    kernel's tail is made of cheap far-field rays).  Every rank -- and the FrameGatherer -- must use the same
+    tile_cost."""
     W, H = int(width), int(height)
     tx, _ = tile_grid(W, H, tile)
     out = []
-    tiles = rank_tiles(W, H, tile, rank, world)
-    if tile_cost is not None:
-        ty_, tx_ = np.divmod(tiles, tx)
-        cost = np.array([tile_cost((x + 0.5) * tile, (y + 0.5) * tile) for x, y in zip(tx_, ty_)])
-        tiles = tiles[np.argsort(-cost, kind="stable")]
-    for t in tiles:
+    for t in rank_tiles(W, H, tile, rank, world, tile_cost):
         ty_, tx_ = divmod(int(t), tx)
         ys = np.arange(ty_ * tile, min((ty_ + 1) * tile, H))
         xs = np.arange(tx_ * tile, min((tx_ + 1) * tile, W))
@@ -43,14 +67,15 @@ def rank_pixels(width: int, height: int, tile: int, rank: int, world: int, tile_
     return np.concatenate(out) if out else np.zeros(0, np.int64)
 
 
-def max_pixels_per_rank(width: int, height: int, tile: int, world: int) -> int:
-    return max(len(rank_pixels(width, height, tile, r, world)) for r in range(world))
+def max_pixels_per_rank(width: int, height: int, tile: int, world: int, tile_cost=None) -> int:
+    return max(len(rank_pixels(width, height, tile, r, world, tile_cost)) for r in range(world))
 
 
-def gather_frame(local, width: int, height: int, tile: int, group=None, dst: int = 0):
+def gather_frame(local, width: int, height: int, tile: int, group=None, dst: int = 0, tile_cost=None):
     """Gather per-pixel results to rank `dst` and scatter them into frame order.
 
-    local: torch tensor [P_local, C] for this rank's pixels in rank_pixels() order.
+    local: torch tensor [P_local, C] for this rank's pixels in rank_pixels(..., tile_cost) order (every rank
+    must pass the same tile_cost it built its shard with).
     Returns a [H, W, C] tensor on rank dst, None elsewhere.  One collective: dist.gather of
     equal-sized (padded) slabs.
     """
@@ -63,9 +88,9 @@ def gather_frame(local, width: int, height: int, tile: int, group=None, dst: int
     C_ = local.shape[1]
     if world == 1:
         out = torch.empty((H * W, C_), dtype=local.dtype, device=local.device)
-        out[torch.from_numpy(rank_pixels(W, H, tile, 0, 1)).to(local.device)] = local
+        out[torch.from_numpy(rank_pixels(W, H, tile, 0, 1, tile_cost)).to(local.device)] = local
         return out.reshape(H, W, C_)
-    pmax = max_pixels_per_rank(W, H, tile, world)
+    pmax = max_pixels_per_rank(W, H, tile, world, tile_cost)
     slab = torch.zeros((pmax, C_), dtype=local.dtype, device=local.device)
     slab[: local.shape[0]] = local
     bufs = [torch.empty_like(slab) for _ in range(world)] if rank == dst else None
@@ -74,7 +99,7 @@ def gather_frame(local, width: int, height: int, tile: int, group=None, dst: int
         return None
     out = torch.empty((H * W, C_), dtype=local.dtype, device=local.device)
     for r in range(world):
-        px = torch.from_numpy(rank_pixels(W, H, tile, r, world)).to(local.device)
+        px = torch.from_numpy(rank_pixels(W, H, tile, r, world, tile_cost)).to(local.device)
         out[px] = bufs[r][: len(px)]
     return out.reshape(H, W, C_)
 
@@ -85,9 +110,12 @@ class FrameGatherer:
     rotation so a slab in flight is never overwritten.  Rank dst scatters the slabs into frame order.
     Works over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests)."""
 
-    def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0, assemble=None):
+    def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0, assemble=None,
+                 tile_cost=None):
         """assemble(slabs [world*pmax, C], perm [H*W] int64, frame [H*W, C]): optional device routine for the
-        root's frame assembly, frame[p] = slabs[perm[p]] (bench.py passes libbhgeo's kernel); default: torch."""
+        root's frame assembly, frame[p] = slabs[perm[p]] (bench.py passes libbhgeo's kernel); default: torch.
+        tile_cost: the SAME function the shards were built with (rank_pixels(..., tile_cost=)): row p of a rank's
+        slab belongs to the p-th pixel of that list, so the gatherer must know the order."""
         import torch
         import torch.distributed as dist
 
@@ -99,15 +127,16 @@ class FrameGatherer:
         self.rank = dist.get_rank(group) if self.dist else 0
         self.W, self.H, self.tile = int(width), int(height), int(tile)
         dtype = dtype or torch.float32
-        self.P = len(rank_pixels(self.W, self.H, tile, self.rank, self.world))
-        self.pmax = max_pixels_per_rank(self.W, self.H, tile, self.world)
+        self.pixels = rank_pixels(self.W, self.H, tile, self.rank, self.world, tile_cost)   # this rank's slab rows
+        self.P = len(self.pixels)
+        self.pmax = max_pixels_per_rank(self.W, self.H, tile, self.world, tile_cost)
         self.slabs = [torch.zeros((self.pmax, channels), dtype=dtype, device=device) for _ in range(2)]
         self.is_dst = self.rank == dst
         self.recv = [None, None]
         self.pix_of = None
         self.frame = None
         if self.is_dst:
-            pix = [rank_pixels(self.W, self.H, tile, r, self.world) for r in range(self.world)]
+            pix = [rank_pixels(self.W, self.H, tile, r, self.world, tile_cost) for r in range(self.world)]
             self.pix_of = [torch.from_numpy(p).to(device) for p in pix]
             if self.world > 1:
                 # the ranks' slabs arrive in ONE block [world * pmax, C]; frame order is a single gather through

@@ -145,9 +145,9 @@ int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int 
 /* Device buffers (all d_* are device addresses on ctx's device; x0_shared is a HOST [3] array or
  * NULL when d_x0 [n][3] is given).  Enqueues on `stream` (a hipStream_t; NULL = HIP's null
  * stream, as everywhere in HIP; bhg_context_stream() gives the context's own stream) and
- * returns without synchronising (exception: with a disk the call loops over resume passes and
- * synchronises the stream).  Two calls on one context must not be in flight at once: they share
- * the context's work counters and workspace. */
+ * returns without synchronising -- with or without a disk or objects: ONE persistent launch finishes
+ * every ray (events are located and rays that carry on are resumed inside the trace kernel).  Two calls
+ * on one context must not be in flight at once: they share the context's work counters and workspace. */
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
@@ -161,7 +161,7 @@ int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_sha
  * of |x(lambda) - c_j| - radius_j on the dense output (Brent, like every other event).  Of all terminal
  * events of a step the earliest wins.  Such rays end with BHG_FLAG_HIT_OBJECT, end = entry point and
  * direction there, object_id = j; all other rays get object_id -1.  object_id may be NULL.  Not
- * available with BHG_RHS_KERR_BL.  Like the disk, these calls loop over resume passes and synchronise.
+ * available with BHG_RHS_KERR_BL.  The device-buffer form only enqueues (one launch), like bhg_trace_device.
  * With n_spheres = 0 they are bhg_trace / bhg_trace_device. */
 int bhg_trace_objects(bhg_context *ctx, const bhg_params *p, const double *spheres, int32_t n_spheres,
                       const double *x0, int x0_is_shared, const double *k0, size_t n, double *end,
@@ -235,18 +235,20 @@ int bhg_synchronize(bhg_context *ctx);
 /* The context's own non-blocking stream (a hipStream_t), used by the host-buffer calls. */
 void *bhg_context_stream(bhg_context *ctx);
 
-/* Per-pass timing of the trace calls.  A trace call runs up to three passes on the caller's stream:
+/* Per-pass timing of the trace calls.  A trace call runs up to two passes on the caller's stream:
  * PREPARE (per-ray setup: f0, initial step -- its own launch for BHG_RHS_KERR_BL only; the Schwarzschild
- * forms do it inside TRACE and report 0 here), TRACE (the integrate loop; the dominant kernel) and
- * RESOLVE (root search for rays that ended on an event).  With profiling enabled the library
- * records HIP events around each pass on that stream; bhg_last_pass_ms() waits for the last call's
- * events and returns {prepare, trace, resolve} in milliseconds. */
+ * forms do it inside TRACE and report 0 here) and TRACE (the integrate loop including the root search for
+ * rays that end on an event; the dominant kernel).  With profiling enabled the library records HIP
+ * events around each pass on that stream; bhg_last_pass_ms() waits for the last call's events and
+ * returns {prepare, trace, 0} in milliseconds (the third slot was a separate root-search pass up to
+ * ABI 1.x builds of round 1; it stays in the signature and reads 0). */
 int bhg_set_profiling(bhg_context *ctx, int enable);
 int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
 
 /* Kernel launch geometry chosen for the last bhg_trace* call (for DESIGN/bench reporting):
  * out[0] = workgroups, out[1] = threads per workgroup, out[2] = resident waves per CU,
- * out[3] = number of trace passes the call took (1 unless disk crossings had to be resumed). */
+ * out[3] = number of trace launches the call took (always 1: rays whose disk / object candidate step
+ *          held no terminal event are resumed inside the same launch). */
 int bhg_last_launch(bhg_context *ctx, int32_t out[4]);
 
 #ifdef __cplusplus

@@ -51,9 +51,7 @@ if rank == 0:
     ids = np.arange(W * H).reshape(H, W)
     assert np.array_equal(img[..., 0], ids)
     assert np.array_equal(img[..., 2], ids // W) and np.array_equal(img[..., 3], ids % W)
-    tx = (W + T - 1) // T
-    tile_id = (ids // W // T) * tx + (ids % W) // T
-    assert np.array_equal(img[..., 1], tile_id % world)
+    assert np.array_equal(img[..., 1], ((ids // W) // T + (ids % W) // T) % world)   # owner = (tile_x + tile_y) % world
     print("GATHER_OK")
 else:
     assert img is None
@@ -97,6 +95,36 @@ dist.destroy_process_group()
 """
 
 
+_WORKER3 = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["BHG_ROOT"])
+from blackhole_geodesic_calculator_amd import dist as bd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H, T = 128, 96, 32
+cost = lambda cx, cy: -abs(np.hypot(cx - W / 2, cy - H / 2) - 30.0)   # a ring of expensive tiles, like the shadow edge
+px = bd.rank_pixels(W, H, T, rank, world, tile_cost=cost)
+assert not np.array_equal(px, bd.rank_pixels(W, H, T, rank, world))    # the cost order really differs
+g = bd.FrameGatherer(W, H, T, channels=4, dtype=torch.float32, device="cpu", tile_cost=cost)
+assert np.array_equal(g.pixels, px)
+for frame in range(3):
+    local = torch.tensor(np.stack([px + 1000 * frame, np.full_like(px, rank), px // W, px % W], 1), dtype=torch.float32)
+    g.submit(frame, local)
+g.drain()
+img1 = bd.gather_frame(torch.tensor(np.stack([px, px], 1), dtype=torch.float64), W, H, T, tile_cost=cost)
+dist.barrier()
+if rank == 0:
+    img = g.image().numpy()
+    ids = np.arange(W * H).reshape(H, W)
+    assert np.array_equal(img[..., 0], ids + 2000)
+    assert np.array_equal(img[..., 2], ids // W) and np.array_equal(img[..., 3], ids % W)
+    assert np.array_equal(img1.numpy()[..., 0], ids)
+    print("COST_ORDER_OK")
+dist.destroy_process_group()
+"""
+
+
 def _run_world2(tmp_path, body, token):
     script = tmp_path / "worker.py"
     script.write_text(body)
@@ -114,6 +142,51 @@ def _run_world2(tmp_path, body, token):
 def test_frame_gatherer_async_double_buffer_world2_gloo(tmp_path):
     """bench.py's frame-end path: asynchronous gather, two slabs in rotation, scatter on rank 0."""
     _run_world2(tmp_path, _WORKER2, "GATHERER_OK")
+
+
+def test_frame_gatherer_with_tile_cost_order_world2_gloo(tmp_path):
+    """Shards built longest-first (rank_pixels(tile_cost=), what bench.py does) land in frame order."""
+    _run_world2(tmp_path, _WORKER3, "COST_ORDER_OK")
+
+
+def test_frame_gatherer_single_process_tile_cost():
+    import torch
+    from blackhole_geodesic_calculator_amd import dist as bd
+    W, H, T = 128, 128, 32
+    cost = lambda cx, cy: -abs(np.hypot(cx - W / 2, cy - H / 2) - 40.0)
+    px = bd.rank_pixels(W, H, T, 0, 1, tile_cost=cost)
+    g = bd.FrameGatherer(W, H, T, channels=2, dtype=torch.float64, tile_cost=cost)
+    g.submit(0, torch.tensor(np.stack([px, 2 * px], 1), dtype=torch.float64))
+    g.drain()
+    assert np.array_equal(g.image().numpy()[..., 0].reshape(-1), np.arange(W * H))
+
+    def fill(out, scatter):
+        out[scatter] = torch.tensor(np.stack([3 * px, px], 1), dtype=torch.float64)
+    g.submit_with(1, fill)
+    g.drain()
+    assert np.array_equal(g.image().numpy()[..., 0].reshape(-1), 3 * np.arange(W * H))
+
+
+def test_tile_dealing_is_skewed_and_balanced():
+    """Without a cost, owner = (tile_x + tile_y) % world: no rank owns whole tile columns, every rank owns 1/world of
+    each tile row.  With bench.py's tile cost the tiles are dealt by cost ranking and the shadow-edge pixels spread
+    evenly (id % world gave +-10 % at 8 ranks, and so does any fixed lattice)."""
+    from blackhole_geodesic_calculator_amd import dist as bd
+    for world, (W, H) in [(2, (2048, 1024)), (4, (2048, 2048)), (8, (4096, 2048))]:
+        own = bd.tile_owner(W, H, 32, world).reshape(H // 32, W // 32)
+        for r in range(world):
+            assert ((own == r).sum(1) == W // 32 // world).all()
+            assert not (own == r).all(0).any()
+        # dealt by cost ranking (bench.py's tile_cost): the shadow-edge ring spreads to within a tile per rank
+        cost = lambda cx, cy: -abs(np.hypot(0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H) - 2.598 / 30.0)
+        own = bd.tile_owner(W, H, 32, world, cost).reshape(H // 32, W // 32)
+        assert np.bincount(own.reshape(-1), minlength=world).tolist() == [own.size // world] * world
+        ys, xs = np.mgrid[0:H:4, 0:W:4]
+        b = np.hypot(0.6 * (xs - W / 2) / W, 0.6 * (ys - H / 2) / H) * 30.0      # impact parameter of the pixel
+        for width in (0.2, 0.4, 1.0):
+            edge = (np.abs(b - 2.598) < width)
+            cnt = np.array([(edge & (own[ys // 32, xs // 32] == r)).sum() for r in range(world)])
+            assert cnt.max() / cnt.mean() < 1.04 and cnt.min() / cnt.mean() > 0.96, (world, width, cnt)
 
 
 def test_frame_gatherer_single_process():
