@@ -519,29 +519,36 @@ __device__ __forceinline__ bool crossed_disk_plane(const double x0[3], const dou
     return ((x0[2] <= 0.0) && (x1[2] >= 0.0)) || ((x0[2] >= 0.0) && (x1[2] <= 0.0));
 }
 
-// A step that crosses the disk plane z = 0 needs the resolve pass only if the crossing can lie in the annulus.
+// sqrt through the rsq seed + Newton (about 1 ulp), 0 at 0: for bounds, where the last bit is free
+__device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
+
+// A step that crosses the disk plane z = 0 needs the event drain only if the crossing can lie in the annulus.
 // The crossing point of the step's dense output lies within delta of the chord's crossing point, where
-// delta = 2 |h| (|v0 - c| + |v1 - c|), c = (x1 - x0) / h the chord velocity: a curve whose velocity stays within
-// eps of c for a time |h| strays at most |h| eps from the chord, and the velocities of an accepted step lie
-// between its end velocities up to the (controlled) step error -- twice the sum of both end deviations is a
-// generous bound (the true excursion is about |h| |v1 - v0| / 8: a factor 16 to 32 of slack).  Outside [R_in - delta, R_out + delta]: not terminal,
-// the ray simply carries on, exactly as the resolve pass would have decided.
+// delta = |h| (|v0 - c| + |v1 - c|), c = (x1 - x0) / h the chord velocity: a curve that starts and ends on the chord and
+// whose velocity stays within eps of c strays at most |h| eps / 2 from it, and the velocities of an accepted step lie
+// between its end velocities up to the (controlled) step error, eps <= max(|v0 - c|, |v1 - c|) -- the sum of both end
+// deviations over |h| is at least twice that bound, and the true excursion is about |h| |v1 - v0| / 8 (a factor 8 to 16
+// of slack).  Outside [R_in - delta, R_out + delta]: not terminal, the ray simply carries on, exactly as the drain
+// would have decided.  Runs in the step loop whenever any lane of the wave crossed the plane: no divisions, no IEEE
+// square roots (rcp / rsq seeds + Newton; the bound does not need the last bit).
 __device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const double x0[3], const double v0[3],
                                                       const double x1[3], const double v1[3], double h)
 {
-    const double s = x0[2] / (x0[2] - x1[2]);  // NaN when the step lies in the plane: falls through to "may hit"
-    const double xl = x0[0] + s * (x1[0] - x0[0]), yl = x0[1] + s * (x1[1] - x0[1]);
-    const double R = sqrt(xl * xl + yl * yl);
-    const double ih = 1.0 / h;
+    const double s = x0[2] * rcp_nr(x0[2] - x1[2]);  // NaN when the step lies in the plane: falls through to "may hit"
+    const double xl = __builtin_fma(s, x1[0] - x0[0], x0[0]), yl = __builtin_fma(s, x1[1] - x0[1], x0[1]);
+    const double R2 = __builtin_fma(xl, xl, yl * yl);
+    const double ih = rcp_nr(h);
     double d0 = 0.0, d1 = 0.0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const double cv = (x1[c] - x0[c]) * ih;
-        d0 += (v0[c] - cv) * (v0[c] - cv);
-        d1 += (v1[c] - cv) * (v1[c] - cv);
+        const double e0 = v0[c] - cv, e1 = v1[c] - cv;
+        d0 = __builtin_fma(e0, e0, d0);
+        d1 = __builtin_fma(e1, e1, d1);
     }
-    const double delta = 2.0 * fabs(h) * (sqrt(d0) + sqrt(d1));
-    return !(R + delta < A.disk_r_in || R - delta > A.disk_r_out);
+    const double delta = fabs(h) * (sqrt_nr(d0) + sqrt_nr(d1)) * (1.0 + 1e-9);
+    const double lo = A.disk_r_in - delta, hi = A.disk_r_out + delta;
+    return !((lo > 0.0 && R2 < lo * lo) || R2 > hi * hi);  // NaN anywhere: may hit
 }
 
 // The same question in Boyer-Lindquist coordinates (x = (r, theta, phi)): the plane is theta* = pi/2 + k pi, the
@@ -557,17 +564,18 @@ __device__ __forceinline__ bool disk_crossing_may_hit_bl(const TraceArgs &A, con
     if (fabs(k1 - k0) != 1.0) return true;
     const double th_star = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
     const double dth = x1[1] - x0[1], dr = x1[0] - x0[0];
-    const double ih = 1.0 / h, idth = 1.0 / dth;
+    const double ih = rcp_nr(h), idth = rcp_nr(dth);
     const double s = (th_star - x0[1]) * idth;
     const double r_lin = __builtin_fma(s, dr, x0[0]);
     const double cr = dr * ih, cth = dth * ih;
-    const double d_r = 2.0 * fabs(h) * (fabs(v0[0] - cr) + fabs(v1[0] - cr));
-    const double d_th = 2.0 * fabs(h) * (fabs(v0[1] - cth) + fabs(v1[1] - cth));
-    const double D = __builtin_fma(fabs(dr), d_th * fabs(idth), d_r);
+    const double d_r = fabs(h) * (fabs(v0[0] - cr) + fabs(v1[0] - cr));
+    const double d_th = fabs(h) * (fabs(v0[1] - cth) + fabs(v1[1] - cth));
+    const double D = __builtin_fma(fabs(dr), d_th * fabs(idth), d_r) * (1.0 + 1e-9);
     const double a2 = A.spin * A.spin;
     const double r_lo = fmax(r_lin - D, 0.0), r_hi = r_lin + D;
-    const double R_lo = sqrt(__builtin_fma(r_lo, r_lo, a2)), R_hi = sqrt(__builtin_fma(r_hi, r_hi, a2));
-    return !(R_hi < A.disk_r_in || R_lo > A.disk_r_out);  // NaN anywhere: may hit
+    // R = sqrt(r^2 + a^2) against the annulus, compared in squares
+    const double R2_lo = __builtin_fma(r_lo, r_lo, a2), R2_hi = __builtin_fma(r_hi, r_hi, a2);
+    return !(R2_hi < A.disk_r_in * A.disk_r_in || R2_lo > A.disk_r_out * A.disk_r_out);  // NaN anywhere: may hit
 }
 
 __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
@@ -597,6 +605,9 @@ struct Wave {
     uint32_t slice, dry;         // current slice, number of slices found dry so far
     bool have_pending;
     unsigned long long pending;  // in-flight work-counter fetch on `slice` (valid in lane 0)
+#ifdef BHG_DIAG
+    unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0;
+#endif
 };
 
 __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
@@ -1371,8 +1382,16 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
         if (W.q_count == 0) {
             // The queue's storage is free: the moment to work off parked events 64 lanes wide -- whenever 64 have
             // piled up, or, at the very end (no batch left, nothing to resume, every lane idle), whatever is left.
-            while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull))
+            while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull)) {
+#ifdef BHG_DIAG
+                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+                W.diag_drained += (unsigned long long)(W.ev_count < 64 ? W.ev_count : 64);
+#endif
                 drain_events<RHS, ADAPTIVE>(A, Q, W, L, lane);
+#ifdef BHG_DIAG
+                W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
+#endif
+            }
             if (W.res_count > 0) {
                 fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
             } else {
@@ -1396,7 +1415,13 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
                     const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
                     first = sblk * A.order_block_len + (q << 6);
                 }
+#ifdef BHG_DIAG
+                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
                 fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
+#ifdef BHG_DIAG
+                W.diag_fill_cyc += __builtin_amdgcn_s_memtime() - c0;
+#endif
                 if (W.q_count == 0) continue;
             }
         }
@@ -1597,6 +1622,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         d[2] = diag_iters;
         d[3] = diag_lanes;
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;
+        d[5] = W.diag_drain_cyc;
+        d[6] = W.diag_drained;
+        d[7] = W.diag_fill_cyc;
     }
 #endif
 }

@@ -6,7 +6,7 @@ cd blackhole_geodesic_calculator_amd/csrc
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-math-errno -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-function"
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c geodesic_kernels.hip -o $T/a.o &
-/opt/rocm/bin/hipcc $F "$@" -c geodesic_kernels_kerr.hip -o $T/b.o &
+/opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c geodesic_kernels_kerr.hip -o $T/b.o &
 /opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c frame_kernels.hip -o $T/c.o &
 /opt/rocm/bin/hipcc $F "$@" -c bhgeo_capi.hip -o $T/d.o &
 wait

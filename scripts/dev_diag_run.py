@@ -1,13 +1,28 @@
+"""Run one workload with a -DBHG_DIAG build and dump the per-wave stamps: dev_diag_run.py frame|disk|orbit <out.bin>"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from blackhole_geodesic_calculator_amd import _ffi
-from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, FrameBatch
+what = sys.argv[1] if len(sys.argv) > 1 else "frame"
+out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/diag.bin"
 ctx = _ffi.Context(0)
-fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
+if what == "disk":
+    cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0)) for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
+    fr = FrameBatch(ctx, cams, 1024, 1024, 1, fov_x=0.9, fov_y=0.9)
+    p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)
+elif what == "orbit":
+    fr = DeviceFrame(ctx, 2048, 2048, 4, fov_x=0.6, fov_y=0.6)
+    fr.set_objects([[8.0, 0.0, 0.0, 1.5]])
+    p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
+elif what == "exit":
+    fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
+    p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
+else:
+    fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
+    p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
 fr.generate_rays()
-p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
-for _ in range(300): fr.trace(p)
+for _ in range(100): fr.trace(p)
 torch.cuda.synchronize()
-os.environ["BHGEO_DIAG_DUMP"] = "gpurun_out/diag.bin"
+os.environ["BHGEO_DIAG_DUMP"] = out
 fr.trace(p); torch.cuda.synchronize()
 fr.trace(p); torch.cuda.synchronize()
