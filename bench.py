@@ -8,9 +8,12 @@ raytracer/RelativisticRenderEngine.py:185-230, seed 42).  Inputs are resident in
 timed region starts; the timed region is trace + shade/sample-mean and, for N > 1, the single gather of
 per-pixel RGBA to rank 0 (asynchronous, overlapping the next frame's trace).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): WEAK scaling -- the frame
-grows to (1024*nx) x (1024*ny), nx*ny = N, over the same window of directions, so every rank still traces
-5,242,880 rays of the same distribution; 32x32-pixel tiles are dealt round-robin to ranks.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the headline figures are WEAK scaling --
+the frame grows to (1024*nx) x (1024*ny), nx*ny = N, over the same window of directions, so every rank still
+traces 5,242,880 rays of the same distribution; 32x32-pixel tiles are dealt to the ranks by cost ranking.  A second
+timed region then shards ONE fixed 1024x1024x5 frame over the N ranks (BASELINE.json's metric read as strong
+scaling) and is reported in the same line as "strong": {...}.  BHGEO_FORCE_COLLECTIVE=1 makes a single-GPU run
+take the N > 1 code path (RCCL process group of one rank, the real asynchronous gather, root-side assembly).
 
 Prints ONE JSON line on rank 0.
 """
@@ -96,8 +99,12 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_collective = os.environ.get("BHGEO_FORCE_COLLECTIVE", "0") == "1"
+    if world > 1 or force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -108,8 +115,7 @@ def main():
     from blackhole_geodesic_calculator_amd.raygen import python_random_stream
 
     ctx = _ffi.Context(local_rank)
-    nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
-    W, H, S = a.width * nx, a.height * ny, a.samples
+    collective = world > 1 or force_collective
     cam = np.array([1e-4, 0.0, 30.0])
     method = "rk4" if a.regime == "rk4" else "dp54"
     # oracle-style keyword set; the same dict configures the CPU baseline
@@ -122,50 +128,9 @@ def main():
     elif a.workload == "orbit":
         okw.update(lambda_end=80.0, r_exit=40.0)
     params = _ffi.make_params(**okw)
-
-    # ---- synthetic input, resident in HBM before the timed region ----------------------------
-    # this rank's tiles of the frame (all samples of a pixel together); jitter stream = the
-    # reference's random.seed(42) MT19937 doubles; rays generated on device once (the engine
-    # re-seeds identically on every render(), so every frame of a static camera traces the same
-    # rays); sky = deterministic synthetic equirect image (no dataset: "data": "synthetic").
-    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
-    # tiles in order of decreasing expected cost: steps per ray peak at the shadow edge (impact
-    # parameter b_c = 2.6 r_s -> radius b_c / |cam| / fov * width pixels around the frame centre)
-    # the frame always spans the same window of directions (0.6 x 0.6 in the pinhole's tangent plane): for a
-    # non-square rank grid (N = 2, 8) fov_y is widened by nx / ny, because y_render carries the aspect
-    # factor H / W (RelativisticRenderEngine.py:197-198); every rank then samples the same distribution of rays
-    fov_x, fov_y = 0.6, 0.6 * nx / ny
-
-    def tile_cost(cx, cy):
-        ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
-        return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
-
-    tcost = tile_cost if (a.lpt and a.workload == "frame") else None
-    pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
-    jitter = python_random_stream(42.0, 2 * S * W * H)
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, FrameBatch, synthetic_sky
     sky = synthetic_sky(2048, 1024)
-    frames = []   # the DeviceFrames one step passes over
-    batch = None
-    if a.workload == "disk":
-        # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination),
-        # traced by ONE library call with per-ray origins (FrameBatch); shaded frame by frame
-        from blackhole_geodesic_calculator_amd.device_frame import FrameBatch
-        cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0))
-                for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
-        batch = FrameBatch(ctx, cams, W, H, S, pixels=pixels, jitter=jitter, fov_x=0.9, fov_y=0.9, sampling_seed=42.0)
-        frames = batch.frames
-        disk_tex = synthetic_sky(1024, 128, seed=3)
-        for f in frames:
-            f.set_disk(DISK[0], DISK[1], disk_tex)
-    else:
-        frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
-                                  pixels=pixels, jitter=jitter))
-    del jitter
-    for f in frames:
-        f.set_sky(sky)
-        f.generate_rays()
-    fr = frames[0]
-    n, P = sum(f.n for f in frames), fr.P
+    ts = torch.cuda.current_stream()
 
     def orbit_scene(i):
         # config 4: a sphere of radius 1.5 on a circular orbit of radius 8 r_s, inclined 20 degrees to the line of
@@ -174,105 +139,176 @@ def main():
         tilt = np.radians(70.0)
         c = 8.0 * np.array([np.cos(ph), np.sin(ph) * np.cos(tilt), np.sin(ph) * np.sin(tilt)])
         return [[c[0], c[1], c[2], 1.5]], [[1.0, 0.85, 0.7]], [[10.0, 10.0, 30.0, 30.0]]
-    ts = torch.cuda.current_stream()
-    k0 = None
 
-    # frame end: per-pixel RGBA (fp32, what Blender's layer.rect holds) handed to the frame owner.
-    # N > 1: ONE gather per frame over RCCL, issued asynchronously so it overlaps the next frame's
-    # trace (dist.FrameGatherer: two slabs in rotation; rank 0 scatters into frame order).
     def assemble(slabs, perm, frame):   # rank 0, N > 1: slabs -> frame order in one kernel
         ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
                                       stream=torch.cuda.current_stream().cuda_stream)
 
-    gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=assemble,
-                                   tile_cost=tcost)   # the gatherer must know the shards' pixel order
-    assert np.array_equal(gatherer.pixels, pixels)
-    kernel_ms = []
+    def measure(nx, ny, ramp):
+        """One timed region over a frame of (width * nx) x (height * ny) pixels sharded over the ranks.
+        Returns the figures of this rank (dt already the maximum over ranks)."""
+        W, H, S = a.width * nx, a.height * ny, a.samples
+        # ---- synthetic input, resident in HBM before the timed region ----------------------------
+        # this rank's tiles of the frame (all samples of a pixel together); jitter stream = the
+        # reference's random.seed(42) MT19937 doubles; rays generated on device once (the engine
+        # re-seeds identically on every render(), so every frame of a static camera traces the same
+        # rays); sky = deterministic synthetic equirect image (no dataset: "data": "synthetic").
+        # The frame always spans the same window of directions (0.6 x 0.6 in the pinhole's tangent plane): for a
+        # non-square rank grid (N = 2, 8) fov_y is widened by nx / ny, because y_render carries the aspect
+        # factor H / W (RelativisticRenderEngine.py:197-198); every rank then samples the same distribution of rays
+        fov_x, fov_y = 0.6, 0.6 * nx / ny
 
-    def step(i, timed):
-        if a.workload == "orbit":
-            fr.set_objects(*orbit_scene(i))
-        tracers = [batch] if batch is not None else frames
-        for f in tracers:
-            if timed:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(ts)
-                f.trace(params)
-                e1.record(ts)
-                kernel_ms.append((e0, e1))
-            else:
-                f.trace(params)
-        for j, f in enumerate(frames):
-            # shade + sample mean written as float RGBA straight into the gather slab (N > 1) or, single rank,
-            # into the frame image in frame order
-            gatherer.submit_with(i * len(frames) + j, f.shade_f32)
+        # tiles in order of decreasing expected cost: steps per ray peak at the shadow edge (impact
+        # parameter b_c = 2.6 r_s -> radius b_c / |cam| / fov * width pixels around the frame centre)
+        def tile_cost(cx, cy):
+            f = 0.9 if a.workload == "disk" else 0.6
+            ax, ay = f * (cx - W / 2) / W, f * (cy - H / 2) / H
+            return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
 
-    def barrier():
-        gatherer.drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        tcost = tile_cost if a.lpt else None
+        pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
+        jitter = python_random_stream(42.0, 2 * S * W * H)
+        frames = []   # the DeviceFrames one step passes over
+        batch = None
+        if a.workload == "disk":
+            # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination),
+            # traced by ONE library call with per-ray origins (FrameBatch); shaded frame by frame
+            cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0))
+                    for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
+            batch = FrameBatch(ctx, cams, W, H, S, pixels=pixels, jitter=jitter, fov_x=0.9, fov_y=0.9, sampling_seed=42.0)
+            frames = batch.frames
+            disk_tex = synthetic_sky(1024, 128, seed=3)
+            for f in frames:
+                f.set_disk(DISK[0], DISK[1], disk_tex)
+        else:
+            frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
+                                      pixels=pixels, jitter=jitter))
+        del jitter
+        for f in frames:
+            f.set_sky(sky)
+            f.generate_rays()
+        fr = frames[0]
+        n = sum(f.n for f in frames)
 
-    if a.ramp_seconds > 0:      # clock ramp (untimed, not counted in W or K)
-        t_ramp = time.perf_counter()
-        while True:
-            for i in range(4):
-                step(i, False)
-            torch.cuda.synchronize()
-            # every rank must run the same number of frames (each one is a collective): rank 0's clock decides
-            go = torch.tensor([1.0 if time.perf_counter() - t_ramp < a.ramp_seconds else 0.0], device="cuda")
+        # frame end: per-pixel RGBA (fp32, what Blender's layer.rect holds) handed to the frame owner.
+        # N > 1: ONE gather per frame over RCCL, issued asynchronously so it overlaps the next frame's
+        # trace (dist.FrameGatherer: two slabs in rotation; rank 0 puts the slabs into frame order).
+        gatherer = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=assemble,
+                                       tile_cost=tcost, collective=collective)   # (the gatherer must know the shards' pixel order)
+        assert np.array_equal(gatherer.pixels, pixels)
+        kernel_ms = []
+
+        def step(i, timed):
+            if a.workload == "orbit":
+                fr.set_objects(*orbit_scene(i))
+            tracers = [batch] if batch is not None else frames
+            for f in tracers:
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(ts)
+                    f.trace(params)
+                    e1.record(ts)
+                    kernel_ms.append((e0, e1))
+                else:
+                    f.trace(params)
+            for j, f in enumerate(frames):
+                # shade + sample mean written as float RGBA straight into the gather slab (N > 1) or, single rank,
+                # into the frame image in frame order
+                gatherer.submit_with(i * len(frames) + j, f.shade_f32)
+
+        def barrier():
+            gatherer.drain()
             if world > 1:
-                dist.broadcast(go, src=0)
-            if float(go.item()) == 0.0:
-                break
-        barrier()
-    for i in range(a.warmup):
-        step(i, False)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    ctx.set_profiling(False)
-    ray_steps = sum(int(f.d_steps.to(torch.int64).sum().item()) for f in frames)
-    # per step: the trace calls of all its frames
-    call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(a.steps, 1) if kernel_ms else float("nan")
-    # the dominant kernel alone: one extra profiled call after the timed region (events on this stream)
-    # (HIP events recorded by the library around prepare | trace | resolve on this same stream);
-    # its share of the whole call (prepare | trace | resolve) is applied to the call time measured inside the timed region
-    ctx.set_profiling(True)
-    tr = []
-    for _ in range(8):
-        (batch or fr).trace(params)
-        tr.append(ctx.last_pass_ms())
-    ctx.set_profiling(False)
-    share = float(np.median([t["trace"] / (t["prepare"] + t["trace"] + t["resolve"]) for t in tr]))
-    k_ms = call_ms * share
-    prep_ms = call_ms * float(np.median([t["prepare"] / (t["prepare"] + t["trace"] + t["resolve"]) for t in tr]))
-    res_ms = call_ms - k_ms - prep_ms
-    multipass = a.workload != "frame"   # disk / objects: the call loops over resume passes; price the whole call
-    if multipass:
-        k_ms, prep_ms, res_ms = call_ms, float("nan"), float("nan")
-    tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tot)
-    rays_all, steps_all = float(tot[0].item()), float(tot[1].item())
+        if ramp > 0:      # clock ramp (untimed, not counted in W or K)
+            t_ramp = time.perf_counter()
+            while True:
+                for i in range(4):
+                    step(i, False)
+                torch.cuda.synchronize()
+                # every rank must run the same number of frames (each one is a collective): rank 0's clock decides
+                go = torch.tensor([1.0 if time.perf_counter() - t_ramp < ramp else 0.0], device="cuda")
+                if world > 1:
+                    dist.broadcast(go, src=0)
+                if float(go.item()) == 0.0:
+                    break
+            barrier()
+        for i in range(a.warmup):
+            step(i, False)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i, True)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+        # the frame really is the frame: rank 0's assembled image against a shade of ITS OWN pixels at their places
+        # (outside the timed region; catches a slab / pixel-order mismatch)
+        if rank == 0 and len(frames) == 1:
+            img = gatherer.image().reshape(-1, 4)
+            own = torch.empty((fr.P, 4), dtype=torch.float32, device="cuda")
+            fr.shade_f32(own)
+            torch.cuda.synchronize()
+            assert torch.equal(img[fr.d_pixels], own), "assembled frame does not hold rank 0's pixels at their places"
+
+        ray_steps = sum(int(f.d_steps.to(torch.int64).sum().item()) for f in frames)
+        # per step: the trace calls of all its frames (HIP events on the stream the library launches on)
+        call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(a.steps, 1) if kernel_ms else float("nan")
+        # the dominant kernel alone: one launch per call finishes every ray (events are located and resumed rays
+        # carry on inside trace_*_kernel); Kerr adds a prepare and a finalize launch.  A few extra profiled calls
+        # after the timed region (HIP events recorded by the library around prepare | trace on this same stream)
+        # give the trace kernel's share of the call, applied to the call time measured inside the timed region
+        ctx.set_profiling(True)
+        tr = []
+        for _ in range(8):
+            (batch or fr).trace(params)
+            tr.append(ctx.last_pass_ms())
+        ctx.set_profiling(False)
+        torch.cuda.synchronize()
+        if a.rhs == "kerr":
+            # the finalize launch follows the library's last event: price it as part of the call, not of the kernel
+            share = float(np.median([t["trace"] for t in tr])) / call_ms if call_ms == call_ms else float("nan")
+            share = min(share, 1.0)
+        else:
+            share = float(np.median([t["trace"] / (t["prepare"] + t["trace"]) for t in tr]))
+        k_ms = call_ms * share
+        tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tot)
+        return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
+                    steps_all=float(tot[1].item()), launch=ctx.last_launch(), fr=fr)
+
+    nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
+    m = measure(nx, ny, a.ramp_seconds)
+    strong = None
+    if world > 1 and a.workload != "orbit":
+        # BASELINE.json's metric read as strong scaling: ONE fixed frame of the single-GPU size over all ranks
+        s_ = measure(1, 1, 0.0)
+        strong = {"value": s_["rays_all"] / (s_["dt"] / a.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": s_["dt"] / a.steps * 1e3,
+                  "ray_steps_per_s": s_["steps_all"] / (s_["dt"] / a.steps), "scaling": "strong",
+                  "workload": f"ONE {s_['W']}x{s_['H']} x{s_['S']} frame sharded over {world} GPUs ({s_['n']} rays on rank 0), same K / W, "
+                              f"barrier + max-over-ranks timing",
+                  "trace_kernel_ms_rank0": s_["k_ms"]}
+        del s_
+    W, H, S, n, ray_steps, dt, call_ms, k_ms = m["W"], m["H"], m["S"], m["n"], m["ray_steps"], m["dt"], m["call_ms"], m["k_ms"]
+    rays_all, steps_all, fr = m["rays_all"], m["steps_all"], m["fr"]
 
     if rank == 0:
         F = FLOP_PER_STEP[(method, a.rhs)]
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(a, method)
         out = {
             "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU"
                       if a.workload == "frame" else
-                      {"disk": "Mrays/s, 1024x1024 Schwarzschild + thin disk, 5 camera inclinations per step",
+                      {"disk": "Mrays/s, 1024x1024 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " + thin disk, 5 camera inclinations per step",
                        "orbit": "Mrays/s, 2048x2048x16 orbiting-sphere animation frame"}[a.workload],
             "value": rays_all / (dt / a.steps) / 1e6,
             "unit": "Mrays/s",
@@ -291,7 +327,7 @@ def main():
                              f"{'Kerr a/M=0.9' if a.rhs == 'kerr' else 'Schwarzschild'} frame per GPU "
                              f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50")
                             if a.workload == "frame" else
-                            {"disk": f"BASELINE.json configs[2]: {a.width}x{a.height} x{S} Schwarzschild + thin disk "
+                            {"disk": f"BASELINE.json configs[2]: {a.width}x{a.height} x{S} {'Kerr a/M=0.9' if a.rhs == 'kerr' else 'Schwarzschild'} + thin disk "
                                      f"{DISK[0]}..{DISK[1]} r_s, camera r=30 at inclinations 85/80/60/30/5 deg (5 frames per "
                                      f"step, one trace call with per-ray origins, shaded per frame), fov 0.9, exit sphere 40, curve_end 80; frame {W}x{H} over {world} GPU(s)",
                              "orbit": f"BASELINE.json configs[3]: {W}x{H} x{S} frame of the orbiting-sphere animation (sphere "
@@ -300,63 +336,98 @@ def main():
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
                 "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
-                "tile": a.tile, "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0" if world > 1 else "in frame order"),
-                "launch": ctx.last_launch(),
+                "tile": a.tile, "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0 + root-side assembly kernel" if collective else "in frame order"),
+                "collective": ("rccl gather, %d rank(s)%s" % (world, " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if collective else "none (single rank)",
+                "launch": m["launch"],
             },
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": f"trace_{method}_kernel<{a.rhs}>" if not multipass else
-                          f"bhg_trace call, all passes (prepare + trace_{method}_kernel<{a.rhs}> + resolve, repeated for resumed rays)",
+                "kernel": f"trace_{method}_kernel<{a.rhs}>: ONE launch per trace call integrates every ray to its end "
+                          f"(step loop + in-kernel event location and resumption)",
                 "achieved": achieved_tf,
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS,
-                "traffic": pmc_traffic(a, method),
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "flop_per_ray_step": F,
                 "ray_steps_per_launch": ray_steps,
                 "kernel_ms": k_ms,
-                "trace_call_ms": call_ms, "prepare_ms": prep_ms, "resolve_ms": res_ms,
+                "trace_call_ms": call_ms,
                 "hbm_algorithmic_GBps": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9,
                 "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
         }
+        if strong is not None:
+            out["strong"] = strong
         if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
-            # the host-buffer entry point (numpy in, numpy out: what the reference's Python caller would use),
-            # H2D + passes + D2H over PCIe -- reported beside `value`, never as `value`
-            k_host = fr.d_k0.cpu().numpy()
-            ctx.trace(k_host[:65536], cam, params)
-            t = time.perf_counter()
-            ctx.trace(k_host, cam, params)
-            th = time.perf_counter() - t
-            out["host_buffer_call"] = {"value": n / th / 1e6, "unit": "Mrays/s", "ms": th * 1e3,
-                                       "what": "bhg_trace on pageable numpy arrays, PCIe-inclusive (H2D k0, D2H end/flags/steps)"}
-            del k_host
+            out["host_buffer_call"] = host_buffer_figures(ctx, fr, cam, params, n)
         if a.cpu_seconds > 0 and world == 1:   # the CPU baseline is an N = 1 figure (rank 0's host cores, nothing else running)
             if a.workload == "orbit":
                 okw["spheres"] = orbit_scene(a.steps - 1)[0]
             out["cpu_baseline"] = cpu_baseline(fr.d_k0.cpu().numpy(), fr.origin, a, okw)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
+    if world > 1 or force_collective:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: RCCL writes a version banner through C stdio, which sits in libc's buffer
+        # (stdout is a pipe under the driver) until it is flushed -- flush it first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+
+
+def host_buffer_figures(ctx, fr, cam, params, n):
+    """The host-buffer entry point (numpy in, numpy out: what the reference's Python caller would use), H2D + trace
+    + D2H over PCIe as a chunked pipeline -- reported beside `value`, never as `value`.  Two figures: the adaptor's
+    default (k0 a plain numpy array, results in the library's page-locked pool: the copy engines write what the
+    caller receives) and everything in plain pageable numpy arrays (results cross a pinned staging ring with
+    multi-threaded host copies)."""
+    k_host = fr.d_k0.cpu().numpy()
+    out = {}
+    for key, pinned in (("value", True), ("pageable_results", False)):
+        ctx.trace(k_host, cam, params, pinned_results=pinned)          # first call: allocations, page-locking
+        best = float("inf")
+        for _ in range(3):
+            t = time.perf_counter()
+            r = ctx.trace(k_host, cam, params, pinned_results=pinned)
+            best = min(best, time.perf_counter() - t)
+            del r
+        out[key] = n / best / 1e6
+        out["ms" if pinned else "pageable_results_ms"] = best * 1e3
+    out["unit"] = "Mrays/s"
+    out["what"] = ("bhg_trace, PCIe-inclusive, best of 3 after one warm-up call: k0 from a pageable numpy array (staged by worker "
+                   "threads), H2D || trace || D2H pipelined over 2^20-ray chunks; value: end/flags/n_steps/n_accepted arrive in "
+                   "page-locked arrays from the library's pool (the Python adaptor's default); pageable_results: into plain numpy arrays")
+    return out
 
 
 def pmc_traffic(a, method):
-    """HBM bytes per launch of the dominant kernel from the latest committed PMC summary
-    (profiles/rNN*_pmc_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
-    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be
-    read inside the timed run, so this is the committed measurement, or None if it does not apply."""
+    """HBM bytes per launch of the dominant kernel from the latest committed PMC summary of THIS workload
+    (profiles/rNN*_pmc_summary[_<workload>].json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside
+    the timed run, so this is the committed measurement, replayed: (bytes, file name), or (None, None) if there is
+    none for this configuration."""
     import glob
-    if not (a.workload == "frame" and a.regime == "adaptive" and a.rhs == "christoffel" and method == "dp54" and a.width == 1024
-            and a.height == 1024 and a.samples == 5):
-        return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not (a.regime == "adaptive" and method == "dp54" and a.rhs in ("christoffel", "kerr")):
+        return None, None
+    dflt = {"frame": (1024, 5), "disk": (1024, 1), "orbit": (2048, 16)}[a.workload]
+    if (a.width, a.height, a.samples) != (dflt[0], dflt[0], dflt[1]):
+        return None, None
+    tag = {"frame": "", "disk": "_disk", "orbit": "_orbit"}[a.workload] + ("_kerr" if a.rhs == "kerr" else "")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))
+                   if os.path.basename(f).split("_pmc_summary")[1] == tag + ".json")
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1])).get("hbm_bytes_per_launch")
+        return json.load(open(files[-1])).get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def effective_cores():

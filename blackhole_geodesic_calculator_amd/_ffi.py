@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -44,7 +44,7 @@ EXPORTS = (
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
     "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
-    "bhg_assemble_frame_f32_device",
+    "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free",
 )
 
 
@@ -197,6 +197,10 @@ def load():
     L.bhg_last_pass_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bhg_acceleration.restype = C.c_int
     L.bhg_acceleration.argtypes = [C.c_void_p, C.POINTER(Params), _dp, _dp, C.c_size_t, _dp]
+    L.bhg_host_alloc.restype = C.c_int
+    L.bhg_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.bhg_host_free.restype = C.c_int
+    L.bhg_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.bhg_synchronize.restype = C.c_int
     L.bhg_synchronize.argtypes = [C.c_void_p]
     L.bhg_context_stream.restype = C.c_void_p
@@ -236,6 +240,64 @@ def _np_dp(a):
     return a.ctypes.data_as(_dp)
 
 
+class _PinnedBlock:
+    """One bhg_host_alloc block.  Page-locking is slow (tens of ms for a few hundred MB), so blocks are pooled:
+    when the last numpy view of a block dies, the block goes back to its pool's free list instead of to the OS."""
+
+    def __init__(self, nbytes, pool):
+        p = C.c_void_p()
+        _check(load().bhg_host_alloc(None, int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes, self.pool = p.value, int(nbytes), pool
+
+    def release(self):
+        if self.ptr:
+            load().bhg_host_free(None, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class PinnedPool:
+    """Page-locked result arrays for the host-buffer calls (Context.trace): numpy arrays over bhg_host_alloc
+    memory, so the device's copy engines write results straight into what the caller gets -- no staging copy."""
+
+    def __init__(self, max_free_bytes=2 << 30):
+        self._free = {}          # nbytes -> [blocks]
+        self._free_bytes = 0
+        self.max_free_bytes = int(max_free_bytes)
+
+    def _give_back(self, blk):
+        if blk.ptr is None:
+            return
+        if self._free_bytes + blk.nbytes > self.max_free_bytes:
+            blk.release()
+            return
+        self._free.setdefault(blk.nbytes, []).append(blk)
+        self._free_bytes += blk.nbytes
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        if n == 0:
+            return np.empty(shape, dtype)
+        size = (n + 4095) & ~4095
+        lst = self._free.get(size)
+        if lst:
+            blk = lst.pop()
+            self._free_bytes -= blk.nbytes
+        else:
+            blk = _PinnedBlock(size, self)
+        buf = (C.c_char * n).from_address(blk.ptr)
+        weakref.finalize(buf, PinnedPool._give_back, self, blk)   # the array's base chain holds `buf`
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def clear(self):
+        for lst in self._free.values():
+            for blk in lst:
+                blk.release()
+        self._free.clear()
+        self._free_bytes = 0
+
+
 class Context:
     """One bhg_context = one device + stream.  Not thread-safe; one call at a time."""
 
@@ -245,9 +307,11 @@ class Context:
         _check(L.bhg_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self.pinned = PinnedPool()
 
     def close(self):
         if getattr(self, "_h", None):
+            self.pinned.clear()
             load().bhg_destroy(self._h)
             self._h = None
 
@@ -290,9 +354,11 @@ class Context:
         _check(load().bhg_synchronize(self._h))
 
     # -- host buffers -------------------------------------------------------------------
-    def trace(self, k0, x0, params: Params, want_accepted=True, spheres=None):
+    def trace(self, k0, x0, params: Params, want_accepted=True, spheres=None, want_steps=True, pinned_results=True):
         """k0[N,3], x0[3] (shared) or [N,3] -> (end[N,6], flags[N] u8, n_steps[N] u32, n_accepted[N] u32);
-        with spheres [[cx, cy, cz, radius], ...] a fifth array object_id[N] i8 is appended."""
+        with spheres [[cx, cy, cz, radius], ...] a fifth array object_id[N] i8 is appended.  want_steps /
+        want_accepted = False: that array is not brought back (None in its place).  The result arrays are
+        page-locked (self.pinned, a pool) unless pinned_results=False."""
         k0 = np.ascontiguousarray(k0, dtype=np.float64)
         if k0.ndim != 2 or k0.shape[1] != 3:
             raise ValueError("k0 must have shape [N, 3]")
@@ -304,22 +370,22 @@ class Context:
                 raise ValueError("x0 must have shape [3] or [N, 3]")
         elif x0.shape != (n, 3):
             raise ValueError("x0 must have shape [3] or [N, 3]")
-        end = np.empty((n, 6), np.float64)
-        flags = np.empty(n, np.uint8)
-        steps = np.empty(n, np.uint32)
-        acc = np.empty(n, np.uint32) if want_accepted else None
+        new = self.pinned.empty if (pinned_results and n >= 65536) else (lambda shape, dt: np.empty(shape, dt))
+        end = new((n, 6), np.float64)
+        flags = new((n,), np.uint8)
+        steps = new((n,), np.uint32) if want_steps else None
+        acc = new((n,), np.uint32) if want_accepted else None
+        p_steps = steps.ctypes.data_as(_u32p) if steps is not None else None
+        p_acc = acc.ctypes.data_as(_u32p) if acc is not None else None
         if spheres is not None:
             sp = _spheres_array(spheres)
-            obj = np.empty(n, np.int8)
+            obj = new((n,), np.int8)
             _check(load().bhg_trace_objects(self._h, C.byref(params), _np_dp(sp), len(sp), _np_dp(x0), 1 if shared else 0,
-                                            _np_dp(k0), n, _np_dp(end), flags.ctypes.data_as(_u8p),
-                                            steps.ctypes.data_as(_u32p),
-                                            acc.ctypes.data_as(_u32p) if acc is not None else None,
+                                            _np_dp(k0), n, _np_dp(end), flags.ctypes.data_as(_u8p), p_steps, p_acc,
                                             obj.ctypes.data_as(C.POINTER(C.c_int8))))
             return end, flags, steps, acc, obj
         _check(load().bhg_trace(self._h, C.byref(params), _np_dp(x0), 1 if shared else 0, _np_dp(k0), n,
-                                _np_dp(end), flags.ctypes.data_as(_u8p), steps.ctypes.data_as(_u32p),
-                                acc.ctypes.data_as(_u32p) if acc is not None else None))
+                                _np_dp(end), flags.ctypes.data_as(_u8p), p_steps, p_acc))
         return end, flags, steps, acc
 
     def trajectory(self, k0, x0, params: Params, n_points):

@@ -6,12 +6,19 @@
 // compute entry point needs a HIP device and fails with BHG_E_NO_DEVICE / BHG_E_HIP otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/bhgeo.h"
 #include "geodesic_kernels.h"
@@ -55,17 +62,116 @@ int fail_hip(hipError_t e, const char *what)
 
 }  // namespace
 
+namespace {
+
+// Worker threads for the host side of the host-buffer entry points: a 100-MB-class memcpy between a caller's
+// pageable array and the pinned staging ring runs at one core's ~10 GB/s single-threaded, several times below what
+// the PCIe link moves; split over a few threads it keeps up.  Created on first use, joined with the context.
+class HostCopyPool {
+public:
+    ~HostCopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    // dst <- src, blocking; the calling thread takes pieces too
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const size_t piece = size_t(2) << 20;
+        if (bytes <= 2 * piece) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        start();
+        size_t n_jobs = 0;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t off = 0; off < bytes; off += piece, n_jobs++)
+                q_.push_back({(char *)dst + off, (const char *)src + off, std::min(piece, bytes - off)});
+            pending_ += n_jobs;
+        }
+        cv_.notify_all();
+        for (;;) {  // help until the queue is empty, then wait for the pieces still being copied
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                if (q_.empty()) {
+                    done_.wait(g, [&] { return pending_ == 0; });
+                    return;
+                }
+                j = q_.front();
+                q_.pop_front();
+            }
+            std::memcpy(j.dst, j.src, j.bytes);
+            finish_one();
+        }
+    }
+
+private:
+    struct Job {
+        char *dst;
+        const char *src;
+        size_t bytes;
+    };
+    void start()
+    {
+        if (!th_.empty()) return;
+        unsigned hw = std::thread::hardware_concurrency();
+        unsigned n = hw > 1 ? std::min(hw - 1, 7u) : 0u;  // + the calling thread
+        for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { run(); });
+    }
+    void finish_one()
+    {
+        std::lock_guard<std::mutex> g(m_);
+        if (--pending_ == 0) done_.notify_all();
+    }
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                j = q_.front();
+                q_.pop_front();
+            }
+            std::memcpy(j.dst, j.src, j.bytes);
+            finish_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<Job> q_;
+    size_t pending_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
+
 struct bhg_context {
     int device = 0;
     hipStream_t stream = nullptr;
     unsigned long long *counter = nullptr;  // work counter (device)
     int num_cus = 0;
     char name[256] = {0};
-    // staging buffers for the host-buffer entry point, grown on demand
+    // device buffers of the host-buffer entry points, grown on demand
     void *d_in = nullptr;
     size_t d_in_bytes = 0;
     void *d_out = nullptr;
     size_t d_out_bytes = 0;
+    // their pipeline: copy streams either side of the compute stream, a two-slot pinned staging ring for callers'
+    // pageable arrays, events per slot, worker threads for the host-side copies
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    void *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    HostCopyPool pool;
     // per-ray workspace of the trace passes (prepare / event / resume records, internal flags)
     void *d_ws = nullptr;
     size_t d_ws_bytes = 0;
@@ -91,6 +197,32 @@ int ensure(void **p, size_t *have, size_t need)
     HIP_TRY(hipMalloc(p, want));
     *have = want;
     return BHG_OK;
+}
+
+int ensure_pinned(void **p, size_t *have, size_t need)
+{
+    if (*have >= need) return BHG_OK;
+    if (*p) {
+        HIP_TRY(hipHostFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    HIP_TRY(hipHostMalloc(p, need, hipHostMallocDefault));
+    *have = need;
+    return BHG_OK;
+}
+
+// Is this host address page-locked memory HIP knows (hipHostMalloc / hipHostRegister, e.g. bhg_host_alloc)?  Then the
+// copy engines reach it directly; a pageable array goes through the staging ring.
+bool is_pinned(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
 }
 
 int validate(const bhg_params *p)
@@ -201,6 +333,15 @@ void bhg_destroy(bhg_context *c)
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->pin_in) (void)hipHostFree(c->pin_in);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->counter) (void)hipFree(c->counter);
     for (int i = 0; i < 3; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -438,6 +579,14 @@ int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_s
     return bhg_trace_objects(c, p, nullptr, 0, x0, x0_is_shared, k0, n, end, flags, n_steps, n_accepted, nullptr);
 }
 
+// The host-buffer call as a pipeline over chunks of rays:
+//   host   : caller's k0 (x0) chunk -> pinned ring          (worker threads; skipped for pinned caller memory)
+//   s_in   : H2D                                            (copy engine)
+//   stream : trace (one launch per chunk)                   (compute)
+//   s_out  : D2H of the arrays the caller asked for         (the other copy engine)
+//   host   : pinned ring -> caller's arrays                 (worker threads; skipped for pinned caller memory)
+// Chunk c+1 is staged and uploaded while chunk c is traced and chunk c-1 comes back.  Results do not depend on the
+// chunking: every ray is its own ODE.
 int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const double *x0,
                       int x0_is_shared, const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
                       uint32_t *n_accepted, int8_t *object_id)
@@ -449,8 +598,20 @@ int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres
     if (rc != BHG_OK) return rc;
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !end) return fail(BHG_E_INVALID, "x0 / k0 / end is NULL");
+    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t in_bytes = n * 3 * sizeof(double) * (x0_is_shared ? 1 : 2);
+    if (!c->s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    // device arrays for the whole call (chunks are sub-ranges of each)
+    const bool per_ray_x0 = !x0_is_shared;
+    const size_t in_bytes = n * 3 * sizeof(double) * (per_ray_x0 ? 2 : 1);
     const size_t off_flags = n * 6 * sizeof(double);
     const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
     const size_t off_acc = off_steps + n * sizeof(uint32_t);
@@ -461,21 +622,107 @@ int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres
     rc = ensure(&c->d_out, &c->d_out_bytes, out_bytes);
     if (rc != BHG_OK) return rc;
     double *d_k0 = (double *)c->d_in;
-    double *d_x0 = x0_is_shared ? nullptr : d_k0 + n * 3;
+    double *d_x0 = per_ray_x0 ? d_k0 + n * 3 : nullptr;
     char *o = (char *)c->d_out;
-    HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    rc = trace_device_impl(c, p, spheres, n_spheres, x0_is_shared ? x0 : nullptr, d_x0, d_k0, n, (double *)o,
-                           (uint8_t *)(o + off_flags), (uint32_t *)(o + off_steps), (uint32_t *)(o + off_acc),
-                           object_id ? (int8_t *)(o + off_obj) : nullptr, c->stream);
+    double *d_end = (double *)o;
+    uint8_t *d_flags = (uint8_t *)(o + off_flags);
+    uint32_t *d_steps = (uint32_t *)(o + off_steps), *d_acc = (uint32_t *)(o + off_acc);
+    int8_t *d_obj = object_id ? (int8_t *)(o + off_obj) : nullptr;
+
+    const size_t chunk = size_t(1) << 20;  // rays per chunk: 24 MB up, 57 MB back
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    const size_t cmax = std::min(chunk, n);
+    const bool pin_k0 = is_pinned(k0), pin_x0 = !per_ray_x0 || is_pinned(x0), pin_end = is_pinned(end);
+    const bool pin_fl = !flags || is_pinned(flags), pin_st = !n_steps || is_pinned(n_steps);
+    const bool pin_ac = !n_accepted || is_pinned(n_accepted), pin_ob = !object_id || is_pinned(object_id);
+    // staging ring slot layouts (each array of a slot at a fixed offset)
+    const size_t si_x0 = cmax * 24, si_slot = cmax * 48;
+    const size_t so_fl = cmax * 48, so_st = so_fl + ((cmax + 7) & ~size_t(7)), so_ac = so_st + cmax * 4, so_ob = so_ac + cmax * 4;
+    const size_t so_slot = (so_ob + cmax + 63) & ~size_t(63);
+    if (!pin_k0 || !pin_x0) {
+        rc = ensure_pinned(&c->pin_in, &c->pin_in_bytes, 2 * si_slot);
+        if (rc != BHG_OK) return rc;
+    }
+    if (!pin_end || !pin_fl || !pin_st || !pin_ac || !pin_ob) {
+        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, 2 * so_slot);
+        if (rc != BHG_OK) return rc;
+    }
+
+    auto copy_out = [&](size_t ch) -> int {  // host side of chunk ch's way back
+        const int slot = (int)(ch & 1);
+        const size_t off = ch * chunk, m = std::min(chunk, n - off);
+        HIP_TRY(hipEventSynchronize(c->ev_out[slot]));
+        const char *ps = (const char *)c->pin_out + (size_t)slot * so_slot;
+        if (!pin_end) c->pool.copy(end + off * 6, ps, m * 48);
+        if (!pin_fl) c->pool.copy(flags + off, ps + so_fl, m);
+        if (!pin_st) c->pool.copy(n_steps + off, ps + so_st, m * 4);
+        if (!pin_ac) c->pool.copy(n_accepted + off, ps + so_ac, m * 4);
+        if (!pin_ob) c->pool.copy(object_id + off, ps + so_ob, m);
+        return BHG_OK;
+    };
+
+    for (size_t ch = 0; ch < n_chunks; ch++) {
+        const int slot = (int)(ch & 1);
+        const size_t off = ch * chunk, m = std::min(chunk, n - off);
+        char *pi = (char *)c->pin_in + (size_t)slot * si_slot;
+        // the slot's previous upload (chunk ch - 2) must have left the staging memory
+        if (ch >= 2 && (!pin_k0 || !pin_x0)) HIP_TRY(hipEventSynchronize(c->ev_in[slot]));
+        const void *src_k0 = k0 + off * 3, *src_x0 = per_ray_x0 ? x0 + off * 3 : nullptr;
+        if (!pin_k0) {
+            c->pool.copy(pi, src_k0, m * 24);
+            src_k0 = pi;
+        }
+        if (per_ray_x0 && !pin_x0) {
+            c->pool.copy(pi + si_x0, src_x0, m * 24);
+            src_x0 = pi + si_x0;
+        }
+        HIP_TRY(hipMemcpyAsync(d_k0 + off * 3, src_k0, m * 24, hipMemcpyHostToDevice, c->s_in));
+        if (per_ray_x0) HIP_TRY(hipMemcpyAsync(d_x0 + off * 3, src_x0, m * 24, hipMemcpyHostToDevice, c->s_in));
+        HIP_TRY(hipEventRecord(c->ev_in[slot], c->s_in));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+        rc = trace_device_impl(c, p, spheres, n_spheres, x0_is_shared ? x0 : nullptr, per_ray_x0 ? d_x0 + off * 3 : nullptr,
+                               d_k0 + off * 3, m, d_end + off * 6, d_flags + off, d_steps + off, d_acc + off,
+                               d_obj ? d_obj + off : nullptr, c->stream);
+        if (rc != BHG_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev_k[slot], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->s_out, c->ev_k[slot], 0));
+        char *po = (char *)c->pin_out + (size_t)slot * so_slot;
+        HIP_TRY(hipMemcpyAsync(pin_end ? (void *)(end + off * 6) : (void *)po, d_end + off * 6, m * 48, hipMemcpyDeviceToHost, c->s_out));
+        if (flags) HIP_TRY(hipMemcpyAsync(pin_fl ? (void *)(flags + off) : (void *)(po + so_fl), d_flags + off, m, hipMemcpyDeviceToHost, c->s_out));
+        if (n_steps)
+            HIP_TRY(hipMemcpyAsync(pin_st ? (void *)(n_steps + off) : (void *)(po + so_st), d_steps + off, m * 4, hipMemcpyDeviceToHost, c->s_out));
+        if (n_accepted)
+            HIP_TRY(hipMemcpyAsync(pin_ac ? (void *)(n_accepted + off) : (void *)(po + so_ac), d_acc + off, m * 4, hipMemcpyDeviceToHost, c->s_out));
+        if (object_id)
+            HIP_TRY(hipMemcpyAsync(pin_ob ? (void *)(object_id + off) : (void *)(po + so_ob), d_obj + off, m, hipMemcpyDeviceToHost, c->s_out));
+        HIP_TRY(hipEventRecord(c->ev_out[slot], c->s_out));
+        // while the GPU works on this chunk: the previous chunk's results go from the ring to the caller's arrays
+        if (ch >= 1) {
+            rc = copy_out(ch - 1);
+            if (rc != BHG_OK) return rc;
+        }
+    }
+    rc = copy_out(n_chunks - 1);
     if (rc != BHG_OK) return rc;
-    if (object_id) HIP_TRY(hipMemcpyAsync(object_id, o + off_obj, n, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(end, o, n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (flags) HIP_TRY(hipMemcpyAsync(flags, o + off_flags, n, hipMemcpyDeviceToHost, c->stream));
-    if (n_steps) HIP_TRY(hipMemcpyAsync(n_steps, o + off_steps, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    if (n_accepted)
-        HIP_TRY(hipMemcpyAsync(n_accepted, o + off_acc, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->s_out));
+    return BHG_OK;
+}
+
+int bhg_host_alloc(bhg_context *c, size_t bytes, void **out)
+{
+    if (!out) return fail(BHG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (bytes == 0) return BHG_OK;
+    if (c) HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return BHG_OK;
+}
+
+int bhg_host_free(bhg_context *c, void *p)
+{
+    (void)c;
+    if (!p) return BHG_OK;
+    HIP_TRY(hipHostFree(p));
     return BHG_OK;
 }
 

@@ -111,11 +111,14 @@ class FrameGatherer:
     Works over RCCL ("nccl") on GPUs and over gloo on CPU tensors (tests)."""
 
     def __init__(self, width, height, tile, channels=4, dtype=None, device="cpu", group=None, dst=0, assemble=None,
-                 tile_cost=None):
+                 tile_cost=None, collective=None):
         """assemble(slabs [world*pmax, C], perm [H*W] int64, frame [H*W, C]): optional device routine for the
         root's frame assembly, frame[p] = slabs[perm[p]] (bench.py passes libbhgeo's kernel); default: torch.
         tile_cost: the SAME function the shards were built with (rank_pixels(..., tile_cost=)): row p of a rank's
-        slab belongs to the p-th pixel of that list, so the gatherer must know the order."""
+        slab belongs to the p-th pixel of that list, so the gatherer must know the order.
+        collective: None = issue the gather when there is more than one rank; True = issue it even in a process
+        group of ONE rank (a 1-rank gather is legal): the whole N > 1 code path -- slabs, the asynchronous
+        collective on the backend's stream, the root-side assembly -- then runs on a single GPU."""
         import torch
         import torch.distributed as dist
 
@@ -126,6 +129,9 @@ class FrameGatherer:
         self.world = dist.get_world_size(group) if self.dist else 1
         self.rank = dist.get_rank(group) if self.dist else 0
         self.W, self.H, self.tile = int(width), int(height), int(tile)
+        self.collective = (self.world > 1) if collective is None else bool(collective)
+        if self.collective and self.dist is None:
+            raise RuntimeError("collective=True needs an initialised torch.distributed process group")
         dtype = dtype or torch.float32
         self.pixels = rank_pixels(self.W, self.H, tile, self.rank, self.world, tile_cost)   # this rank's slab rows
         self.P = len(self.pixels)
@@ -138,7 +144,7 @@ class FrameGatherer:
         if self.is_dst:
             pix = [rank_pixels(self.W, self.H, tile, r, self.world, tile_cost) for r in range(self.world)]
             self.pix_of = [torch.from_numpy(p).to(device) for p in pix]
-            if self.world > 1:
+            if self.collective:
                 # the ranks' slabs arrive in ONE block [world * pmax, C]; frame order is a single gather through
                 # `perm` (perm[pixel] = r * pmax + position of the pixel in rank r's list): one kernel per frame
                 # on the root instead of one scatter per rank
@@ -173,7 +179,7 @@ class FrameGatherer:
         self.finish(b)
         self.last = b
         self.slabs[b][: self.P].copy_(local)
-        if self.world > 1:
+        if self.collective:
             self.pending[b] = self.dist.gather(self.slabs[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
         else:
             self.frame[self.pix_of[0]] = self.slabs[b][: self.P]
@@ -186,7 +192,7 @@ class FrameGatherer:
         b = i & 1
         self.finish(b)
         self.last = b
-        if self.world > 1:
+        if self.collective:
             fill(self.slabs[b][: self.P], None)
             self.pending[b] = self.dist.gather(self.slabs[b], self.recv[b], dst=self.dst, group=self.group, async_op=True)
         else:

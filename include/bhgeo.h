@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 3
+#define BHG_ABI_VERSION 4
 
 /* return codes */
 #define BHG_OK 0
@@ -125,11 +125,20 @@ int bhg_num_cus(bhg_context *ctx);
 
 /* --- the hot path ----------------------------------------------------------------------- */
 /* Host buffers.  Batched replacement of N calc_trajectory calls (:293-294): copies k0 (and x0)
- * to the device, integrates all rays, copies end/flags/n_steps back.  x0_is_shared != 0: x0 is
- * [3]; else [n][3].  flags, n_steps, n_accepted may be NULL. */
+ * to the device, integrates all rays, copies end and whichever of flags / n_steps / n_accepted is not NULL
+ * back.  x0_is_shared != 0: x0 is [3]; else [n][3].  Blocking.  Internally a pipeline over chunks of 2^20 rays
+ * (upload of the next chunk, trace, download of the previous one overlap on three streams); arrays in pageable
+ * memory go through a pinned staging ring with multi-threaded host copies, arrays in page-locked memory
+ * (bhg_host_alloc, hipHostMalloc, hipHostRegister) are read / written by the copy engines directly. */
 int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared,
               const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
               uint32_t *n_accepted);
+
+/* Page-locked host memory for the arrays handed to bhg_trace / bhg_trace_objects: results then arrive by DMA
+ * with no host-side copy.  (numpy's own allocations are pageable; the Python adaptor allocates its result arrays
+ * here and keeps a pool of them, page-locking being slow.)  ctx may be NULL in bhg_host_free. */
+int bhg_host_alloc(bhg_context *ctx, size_t bytes, void **out);
+int bhg_host_free(bhg_context *ctx, void *p);
 
 /* Sampled curves, host buffers: what calc_trajectory returns for nr_points_curve samples
  * (RelativisticRenderEngine.py:293-294, :299-302; the trajectory plots of README.md Fig. 5/6).

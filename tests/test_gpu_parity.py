@@ -616,6 +616,31 @@ def test_device_buffer_entry_point_matches_host_entry_point(ctx, full_frame):
     assert np.array_equal(dend.cpu().numpy(), end[:n])
     assert np.array_equal(dfl.cpu().numpy(), flags[:n])
     assert np.array_equal(dst.cpu().numpy().astype(np.uint32), steps[:n])
+    del dk, dend, dfl, dst
+    # the host-buffer call is a pipeline over 2^20-ray chunks (five here, the last one ragged) with the results
+    # arriving in page-locked arrays; the whole frame in ONE device-resident call must give the same bits ...
+    n = len(k0)
+    dk = torch.from_numpy(k0).cuda()
+    dend = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+    dfl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    dac = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.trace_device(_params(r_s=1.0, lambda_end=50.0), n, dk.data_ptr(), dend.data_ptr(), x0_shared=CAM,
+                     d_flags=dfl.data_ptr(), d_n_steps=dst.data_ptr(), d_n_accepted=dac.data_ptr(),
+                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dend.cpu().numpy(), end) and np.array_equal(dfl.cpu().numpy(), flags)
+    assert np.array_equal(dst.cpu().numpy().astype(np.uint32), steps) and np.array_equal(dac.cpu().numpy().astype(np.uint32), acc)
+    # ... and so must the same call into ordinary (pageable) numpy arrays through the staging ring, with only the
+    # arrays asked for coming back
+    m = 2 * (1 << 20) + 12345
+    e2, f2, s2, a2 = ctx.trace(k0[:m], CAM, _params(r_s=1.0, lambda_end=50.0), want_steps=False, want_accepted=False,
+                               pinned_results=False)
+    assert s2 is None and a2 is None and np.array_equal(e2, end[:m]) and np.array_equal(f2, flags[:m])
+    # per-ray origins take the same road
+    x0 = np.broadcast_to(CAM, (m, 3)).copy()
+    e3, f3, s3, a3 = ctx.trace(k0[:m], x0, _params(r_s=1.0, lambda_end=50.0), pinned_results=False)
+    assert np.array_equal(e3, end[:m]) and np.array_equal(s3, steps[:m]) and np.array_equal(a3, acc[:m])
 
 
 def test_calc_trajectory_adaptor(ctx, oracle):

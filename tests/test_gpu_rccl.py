@@ -1,0 +1,91 @@
+"""RCCL on the one GPU the test box has: a process group of ONE rank over the "nccl" backend (= RCCL on ROCm), so that
+librccl is loaded and the frame-end exchange runs exactly as it does at N > 1 -- FrameGatherer issues its real
+asynchronous dist.gather on RCCL's stream, the two slabs rotate, rank 0 assembles the frame with libbhgeo's gather
+kernel on the compute stream -- and the result must be bit-identical to the frame shaded directly.  The second test
+drives bench.py through the same path (BHGEO_FORCE_COLLECTIVE=1)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["BHG_ROOT"])
+from blackhole_geodesic_calculator_amd import _ffi, dist as bd
+from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
+from blackhole_geodesic_calculator_amd.raygen import python_random_stream
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+W, H, S, T = 192, 128, 3, 32
+cam = np.array([1e-4, 0.0, 30.0])
+sky = synthetic_sky(256, 128)
+jit = python_random_stream(42.0, 2 * S * W * H)
+ctx = _ffi.Context(0)
+params = _ffi.make_params(r_s=1.0, lambda_end=60.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=8.0)
+cost = lambda cx, cy: -abs(np.hypot(0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H) - 2.598 / 30.0)
+pix = bd.rank_pixels(W, H, T, 0, 1, tile_cost=cost)          # the longest-first order bench.py uses
+f = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=cam, pixels=pix, jitter=jit)
+f.set_sky(sky); f.set_disk(3.0, 8.0); f.generate_rays()
+calls = []
+def assemble(slabs, perm, frame):
+    calls.append(1)
+    ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream)
+g = bd.FrameGatherer(W, H, T, channels=4, dtype=torch.float32, device="cuda", assemble=assemble, tile_cost=cost,
+                     collective=True)
+assert g.collective and g.world == 1
+for frame in range(5):                       # five frames: both slabs go round twice, every gather is a real RCCL call
+    f.trace(params)
+    g.submit_with(frame, f.shade_f32)
+    assert g.pending[frame & 1] is not None  # an asynchronous collective is in flight
+g.drain()
+torch.cuda.synchronize()
+assert g.frames_done == 5 and len(calls) == 5
+want = torch.zeros((H * W, 4), dtype=torch.float32, device="cuda")
+f.shade_f32(want, f.d_pixels)
+torch.cuda.synchronize()
+got = g.image().reshape(-1, 4)
+assert torch.equal(got, want), float((got - want).abs().max())
+import ctypes
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps, "RCCL was not loaded"
+print("RCCL_WORLD1_OK")
+dist.destroy_process_group()
+"""
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_frame_gatherer_over_rccl_world1(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, BHG_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "RCCL_WORLD1_OK" in out.stdout
+
+
+def test_bench_takes_the_collective_path_on_one_gpu():
+    env = dict(os.environ, BHGEO_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--ramp-seconds", "0",
+                          "--cpu-seconds", "0", "--width", "256", "--samples", "2"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("{"), out.stdout[-500:]   # the JSON line is the LAST line (after RCCL's banner)
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["collective"].startswith("rccl gather, 1 rank")
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
