@@ -400,6 +400,26 @@ def host_buffer_figures(ctx, fr, cam, params, n):
             del r
         out[key] = n / best / 1e6
         out["ms" if pinned else "pageable_results_ms"] = best * 1e3
+    # the adaptors' resident-ray path (frame.FrameTracer, camera.RelativisticCamera): rays generated on the device once
+    # (bhg_rays_create from the jitter stream), per frame only end_dir + flags come back (bhg_rays_trace)
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.raygen import python_random_stream
+    W, H, S = fr.W, fr.H, fr.S
+    jit = python_random_stream(42.0, 2 * S * W * H)
+    t = time.perf_counter()
+    rs = _ffi.RaySet(ctx, W, H, S, fr.fov_x, fr.fov_y, cam, None, jit, False, None)
+    t_create = time.perf_counter() - t
+    rs.trace(params, want=("end_dir", "flags"))
+    best = float("inf")
+    for _ in range(3):
+        t = time.perf_counter()
+        r = rs.trace(params, want=("end_dir", "flags"))
+        best = min(best, time.perf_counter() - t)
+        del r
+    out["resident_rays"] = {"value": rs.n / best / 1e6, "unit": "Mrays/s", "ms": best * 1e3, "rays_create_ms": t_create * 1e3,
+                            "what": "bhg_rays_trace over the whole frame, best of 3: rays generated on the device once from the "
+                                    "MT19937 jitter stream (rays_create_ms, 16 B/ray up, not in ms), only end_dir + flags (25 B/ray) come back"}
+    rs.close()
     out["unit"] = "Mrays/s"
     out["what"] = ("bhg_trace, PCIe-inclusive, best of 3 after one warm-up call: k0 from a pageable numpy array (staged by worker "
                    "threads), H2D || trace || D2H pipelined over 2^20-ray chunks; value: end/flags/n_steps/n_accepted arrive in "

@@ -44,8 +44,19 @@ EXPORTS = (
     "bhg_acceleration", "bhg_synchronize", "bhg_last_launch", "bhg_context_stream", "bhg_raygen_device",
     "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
-    "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free",
+    "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free", "bhg_rays_create", "bhg_rays_count",
+    "bhg_rays_destroy", "bhg_rays_trace",
 )
+
+
+class Camera(C.Structure):
+    """struct bhg_camera (include/bhgeo.h)."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("samples", C.c_int32), ("reserved", C.c_int32),
+        ("fov_x", C.c_double), ("fov_y", C.c_double),
+        ("rot", C.c_double * 9),
+        ("origin", C.c_double * 3),
+    ]
 
 
 class Scene(C.Structure):
@@ -197,6 +208,16 @@ def load():
     L.bhg_last_pass_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.bhg_acceleration.restype = C.c_int
     L.bhg_acceleration.argtypes = [C.c_void_p, C.POINTER(Params), _dp, _dp, C.c_size_t, _dp]
+    L.bhg_rays_create.restype = C.c_int
+    L.bhg_rays_create.argtypes = [C.c_void_p, C.POINTER(Camera), _dp, C.c_int, C.POINTER(C.c_int64), C.c_size_t,
+                                  C.POINTER(C.c_void_p)]
+    L.bhg_rays_count.restype = C.c_size_t
+    L.bhg_rays_count.argtypes = [C.c_void_p]
+    L.bhg_rays_destroy.restype = None
+    L.bhg_rays_destroy.argtypes = [C.c_void_p]
+    L.bhg_rays_trace.restype = C.c_int
+    L.bhg_rays_trace.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int32, C.c_size_t, C.c_size_t, _dp, _dp, _dp, _u8p,
+                                 _u32p, _u32p, C.POINTER(C.c_int8)]
     L.bhg_host_alloc.restype = C.c_int
     L.bhg_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.bhg_host_free.restype = C.c_int
@@ -296,6 +317,63 @@ class PinnedPool:
                 blk.release()
         self._free.clear()
         self._free_bytes = 0
+
+
+class RaySet:
+    """bhg_rays: the camera rays of one frame, generated on the device and resident there (include/bhgeo.h).
+    Ray s * n_pixels + p is sample s of pixel p."""
+
+    def __init__(self, ctx: "Context", width, height, samples, fov_x, fov_y, origin, rot=None, jitter=None,
+                 jitter_is_compact=False, pixels=None):
+        cam = Camera()
+        cam.width, cam.height, cam.samples = int(width), int(height), int(samples)
+        cam.fov_x, cam.fov_y = float(fov_x), float(fov_y)
+        r = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        cam.rot[:] = [float(v) for v in r.reshape(9)]
+        cam.origin[:] = [float(v) for v in np.asarray(origin, dtype=np.float64).reshape(3)]
+        jit = None if jitter is None else np.ascontiguousarray(jitter, dtype=np.float64).reshape(-1)
+        pix = None if pixels is None else np.ascontiguousarray(pixels, dtype=np.int64).reshape(-1)
+        n_pixels = int(width) * int(height) if pix is None else len(pix)
+        need = 2 * int(samples) * (n_pixels if jitter_is_compact else int(width) * int(height))
+        if jit is not None and len(jit) < need:
+            raise ValueError(f"jitter stream too short: {len(jit)} < {need}")
+        h = C.c_void_p()
+        _check(load().bhg_rays_create(ctx._h, C.byref(cam), None if jit is None else _np_dp(jit), 1 if jitter_is_compact else 0,
+                                      None if pix is None else pix.ctypes.data_as(C.POINTER(C.c_int64)), n_pixels, C.byref(h)))
+        self._h, self.ctx = h, ctx
+        self.n_pixels, self.samples = n_pixels, int(samples)
+        self.n = int(load().bhg_rays_count(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):    # the context frees nothing of ours; but never touch a dead one
+                load().bhg_rays_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trace(self, params: "Params", first=0, n=None, want=("end", "flags", "n_steps", "n_accepted"), spheres=None):
+        """Trace rays [first, first + n); returns a dict of the arrays named in `want` (of: end [n,6], end_loc [n,3],
+        end_dir [n,3], flags, n_steps, n_accepted, object_id), page-locked from the context's pool."""
+        n = self.n - int(first) if n is None else int(n)
+        pool = self.ctx.pinned
+        new = pool.empty if n >= 65536 else (lambda shape, dt: np.empty(shape, dt))
+        spec = {"end": ((n, 6), np.float64), "end_loc": ((n, 3), np.float64), "end_dir": ((n, 3), np.float64),
+                "flags": ((n,), np.uint8), "n_steps": ((n,), np.uint32), "n_accepted": ((n,), np.uint32),
+                "object_id": ((n,), np.int8)}
+        out = {k: new(*spec[k]) for k in want}
+
+        def ptr(k, typ):
+            return out[k].ctypes.data_as(typ) if k in out else None
+        sp = None if spheres is None else _spheres_array(spheres)
+        _check(load().bhg_rays_trace(self._h, C.byref(params), None if sp is None else _np_dp(sp), 0 if sp is None else len(sp),
+                                     int(first), n, ptr("end", _dp), ptr("end_loc", _dp), ptr("end_dir", _dp), ptr("flags", _u8p),
+                                     ptr("n_steps", _u32p), ptr("n_accepted", _u32p), ptr("object_id", C.POINTER(C.c_int8))))
+        return out
 
 
 class Context:

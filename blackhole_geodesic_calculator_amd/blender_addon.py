@@ -11,12 +11,18 @@ batched GPU trace per sample (frame.FrameTracer), shading stays Blender's `Textu
 This module imports `bpy`; it is loaded by Blender (or by the tests' fake-bpy harness), never by
 the package __init__.
 
-Known deviations from the reference, both deliberate:
+Known deviations from the reference, all deliberate:
   * progress: the reference divides the already-fractional progress by res_y again (:166 vs
     :261, so its bar stays near 0); here update_progress receives the fraction itself;
   * the RenderResult is refreshed once per sample instead of once per row (`buf.tolist()` per row
-    is O(H^2 W) Python work, :163); the final image is identical.
+    is O(H^2 W) Python work, :163); the final image is identical;
+  * one scene property more than the reference's twelve: `curved_space_objects` (default 0 = off).  Off, the
+    image is the reference's: its spacetime_ray_cast always reports hit = False (:304-305), so scene meshes
+    never affect a render.  Set to 1, the MESH objects of the scene (except the black-hole marker) are traced as
+    lamp-lit bounding spheres inside the curved region -- the collision test the reference leaves as a stub;
+    at most 8 (the solver's limit), the nearest to the hole, with a warning when more are dropped.
 """
+import warnings
 import os
 
 import bpy
@@ -114,7 +120,9 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         if (self.mark_y_min, self.mark_y_max, self.mark_x_min, self.mark_x_max) != (0, height, 0, width):
             mark = (self.mark_y_min, self.mark_y_max, self.mark_x_min, self.mark_x_max)
         self.lamps = [ob for ob in depsgraph.scene.objects if ob.type == "LIGHT"]  # :175
-        spheres = self.scene_spheres(depsgraph)
+        # objects in the curved region are opt-in (scene.curved_space_objects): off reproduces the reference image
+        want_objects = float(getattr(depsgraph.scene, "curved_space_objects", 0) or 0) != 0.0
+        spheres = self.scene_spheres(depsgraph) if want_objects else np.zeros((0, 4))
         tracer = FrameTracer(
             self.GeoInt, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
             sampling_seed=self.sampling_seed, origin=origin, rotation_euler=rotation, bh_loc=self.bh_loc,
@@ -137,6 +145,8 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
             if radius > 0.0:
                 out.append([loc[0], loc[1], loc[2], radius])
         out.sort(key=lambda s: float(np.linalg.norm(np.array(s[:3]) - self.bh_loc)))
+        if len(out) > 8:
+            warnings.warn(f"{len(out)} mesh objects in the scene: only the 8 nearest to the hole are traced", RuntimeWarning)
         return np.array(out[:8], dtype=np.float64).reshape(-1, 4)
 
     def spacetime_hit_many(self, loc, normal, index, intensity=10):
@@ -175,7 +185,7 @@ class CUSTOM_RENDER_PT_blackhole(RenderButtonsPanel, Panel):
              ("integration_depth", "Integration depth"), ("field_of_view_x", "field_of_view_x"),
              ("field_of_view_y", "field_of_view_y"), ("sampling_seed", "Sampling seed"), ("sky_image", "Sky image"),
              ("mark_x_min", "mark_x_min"), ("mark_x_max", "mark_x_max"), ("mark_y_min", "mark_y_min"),
-             ("mark_y_max", "mark_y_max"))
+             ("mark_y_max", "mark_y_max"), ("curved_space_objects", "Objects in curved space (0/1)"))
 
     def draw(self, context):
         col = self.layout.split().column()
@@ -197,6 +207,11 @@ PROPS = [
     ("mark_y_max", bpy.props.FloatProperty(name="mark_y_max", default=-1.0)),
     ("mark_x_min", bpy.props.FloatProperty(name="mark_x_min", default=-1.0)),
     ("mark_x_max", bpy.props.FloatProperty(name="mark_x_max", default=-1.0)),
+]
+
+# beyond the reference: opt-in switch for objects inside the curved region (module docstring)
+EXTRA_PROPS = [
+    ("curved_space_objects", bpy.props.FloatProperty(name="curved_space_objects", default=0)),
 ]
 
 _EXCLUDED_PANELS = {"VIEWLAYER_PT_filter", "VIEWLAYER_PT_layer_passes"}
@@ -222,7 +237,7 @@ def _extra_panels():
 def register():
     bpy.utils.register_class(RelativisticRenderEngine)
     bpy.utils.register_class(CUSTOM_RENDER_PT_blackhole)
-    for name, prop in PROPS:
+    for name, prop in PROPS + EXTRA_PROPS:
         setattr(bpy.types.Scene, name, prop)
     for panel in get_panels() + [CUSTOM_RENDER_PT_blackhole] + _extra_panels():
         panel.COMPAT_ENGINES.add(RelativisticRenderEngine.bl_idname)
@@ -231,7 +246,7 @@ def register():
 def unregister():
     bpy.utils.unregister_class(RelativisticRenderEngine)
     bpy.utils.unregister_class(CUSTOM_RENDER_PT_blackhole)
-    for name, _ in PROPS:
+    for name, _ in PROPS + EXTRA_PROPS:
         delattr(bpy.types.Scene, name)
     for panel in get_panels() + [CUSTOM_RENDER_PT_blackhole] + _extra_panels():
         panel.COMPAT_ENGINES.discard(RelativisticRenderEngine.bl_idname)

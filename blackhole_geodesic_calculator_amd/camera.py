@@ -64,8 +64,20 @@ class RelativisticCamera:
         else:
             gi = GeodesicIntegratorSchwarzschild(mass=self.M, time_like=False, verbose=False, device=self._device,
                                                  **self._integrator_kw)
-        out = gi.trace(self.pixel_directions(), self.camera_location, max_step=self.max_step,
-                       curve_end=self.curve_end)
+        H, W = self.resolution
+        if hasattr(gi, "ray_set"):
+            # pixel-centre rays generated on the device (jitter None = u 1/2): the directions never cross PCIe
+            rays = gi.ray_set(W, H, 1, self.field_of_view[0], self.field_of_view[1], self.camera_location,
+                              self.camera_rotation_euler, jitter=None)
+            o = gi.trace_rays(rays, max_step=self.max_step, curve_end=self.curve_end,
+                              want=("end", "flags", "n_steps", "n_accepted"))
+            rays.close()
+            out = {"ray_end": o["end"].reshape(H, W, 6), "flags": o["flags"].reshape(H, W),
+                   "ray_blackhole_hit": ((o["flags"] & 1) != 0).astype(np.uint8).reshape(H, W),
+                   "n_steps": o["n_steps"].reshape(H, W), "n_accepted": o["n_accepted"].reshape(H, W)}
+        else:
+            out = gi.trace(self.pixel_directions(), self.camera_location, max_step=self.max_step,
+                           curve_end=self.curve_end)
         self.ray_end = out["ray_end"]
         self.ray_blackhole_hit = out["ray_blackhole_hit"]
         self.results = {"flags": out["flags"], "n_steps": out["n_steps"], "n_accepted": out["n_accepted"]}

@@ -579,14 +579,171 @@ int bhg_trace(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_s
     return bhg_trace_objects(c, p, nullptr, 0, x0, x0_is_shared, k0, n, end, flags, n_steps, n_accepted, nullptr);
 }
 
-// The host-buffer call as a pipeline over chunks of rays:
+}  // extern "C"
+
+struct bhg_rays {
+    bhg_context *ctx = nullptr;
+    double *d_k0 = nullptr;  // [n][3], ray s * n_pixels + p = sample s of pixel p
+    size_t n = 0;
+    double origin[3] = {0, 0, 0};
+};
+
+namespace {
+
+// what a pipelined call reads and writes on the host side
+struct PipeIO {
+    const double *h_k0 = nullptr, *h_x0 = nullptr;  // caller's rays (h_x0: per-ray origins) ...
+    const double *d_k0 = nullptr;                   // ... or rays already resident on the device (no upload)
+    const double *x0_shared = nullptr;              // host [3] when the origin is shared
+    double *end = nullptr, *loc = nullptr, *dir = nullptr;  // end [n][6] and / or its halves [n][3]
+    uint8_t *flags = nullptr;
+    uint32_t *steps = nullptr, *acc = nullptr;
+    int8_t *obj = nullptr;
+};
+
+// The host-buffer calls as a pipeline over chunks of rays:
 //   host   : caller's k0 (x0) chunk -> pinned ring          (worker threads; skipped for pinned caller memory)
-//   s_in   : H2D                                            (copy engine)
-//   stream : trace (one launch per chunk)                   (compute)
+//   s_in   : H2D                                            (copy engine; nothing to do for resident rays)
+//   stream : trace (one launch per chunk), end -> loc / dir (compute)
 //   s_out  : D2H of the arrays the caller asked for         (the other copy engine)
 //   host   : pinned ring -> caller's arrays                 (worker threads; skipped for pinned caller memory)
 // Chunk c+1 is staged and uploaded while chunk c is traced and chunk c-1 comes back.  Results do not depend on the
 // chunking: every ray is its own ODE.
+int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const PipeIO &io, size_t n)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->s_in) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    const bool upload = io.d_k0 == nullptr;
+    const bool per_ray_x0 = io.h_x0 != nullptr;
+    const bool split = io.loc || io.dir;
+    // device arrays for the whole call (chunks are sub-ranges of each)
+    const size_t in_bytes = upload ? n * 3 * sizeof(double) * (per_ray_x0 ? 2 : 1) : 0;
+    const size_t off_flags = n * 6 * sizeof(double);
+    const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
+    const size_t off_acc = off_steps + n * sizeof(uint32_t);
+    const size_t off_obj = off_acc + n * sizeof(uint32_t);
+    const size_t off_loc = (off_obj + n + 7) & ~size_t(7);
+    const size_t off_dir = off_loc + (split ? n * 3 * sizeof(double) : 0);
+    const size_t out_bytes = off_dir + (split ? n * 3 * sizeof(double) : 0);
+    int rc = BHG_OK;
+    if (upload) {
+        rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
+        if (rc != BHG_OK) return rc;
+    }
+    rc = ensure(&c->d_out, &c->d_out_bytes, out_bytes);
+    if (rc != BHG_OK) return rc;
+    double *d_k0u = (double *)c->d_in;
+    const double *d_k0 = upload ? d_k0u : io.d_k0;
+    double *d_x0 = per_ray_x0 ? d_k0u + n * 3 : nullptr;
+    char *o = (char *)c->d_out;
+    double *d_end = (double *)o, *d_loc = (double *)(o + off_loc), *d_dir = (double *)(o + off_dir);
+    uint8_t *d_flags = (uint8_t *)(o + off_flags);
+    uint32_t *d_steps = (uint32_t *)(o + off_steps), *d_acc = (uint32_t *)(o + off_acc);
+    int8_t *d_obj = io.obj ? (int8_t *)(o + off_obj) : nullptr;
+
+    const size_t chunk = size_t(1) << 20;  // rays per chunk: 24 MB up, 57 MB back
+    const size_t n_chunks = (n + chunk - 1) / chunk;
+    const size_t cmax = std::min(chunk, n);
+    const bool pin_k0 = !upload || is_pinned(io.h_k0), pin_x0 = !per_ray_x0 || is_pinned(io.h_x0);
+    struct OutArr {
+        void *host;
+        const char *dev;
+        size_t elem;
+        bool pinned;
+        size_t ring_off;
+    } outs[7] = {{io.end, (const char *)d_end, 48, false, 0},   {io.loc, (const char *)d_loc, 24, false, 0},
+                 {io.dir, (const char *)d_dir, 24, false, 0},   {io.flags, (const char *)d_flags, 1, false, 0},
+                 {io.steps, (const char *)d_steps, 4, false, 0}, {io.acc, (const char *)d_acc, 4, false, 0},
+                 {io.obj, (const char *)d_obj, 1, false, 0}};
+    size_t so_slot = 0;
+    bool stage_out = false;
+    for (auto &a : outs) {
+        if (!a.host) continue;
+        a.pinned = is_pinned(a.host);
+        a.ring_off = so_slot;
+        so_slot += (cmax * a.elem + 63) & ~size_t(63);
+        stage_out = stage_out || !a.pinned;
+    }
+    const size_t si_x0 = cmax * 24, si_slot = cmax * 48;
+    if (!pin_k0 || !pin_x0) {
+        rc = ensure_pinned(&c->pin_in, &c->pin_in_bytes, 2 * si_slot);
+        if (rc != BHG_OK) return rc;
+    }
+    if (stage_out) {
+        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, 2 * so_slot);
+        if (rc != BHG_OK) return rc;
+    }
+
+    auto copy_out = [&](size_t ch) -> int {  // host side of chunk ch's way back
+        const int slot = (int)(ch & 1);
+        const size_t off = ch * chunk, m = std::min(chunk, n - off);
+        HIP_TRY(hipEventSynchronize(c->ev_out[slot]));
+        const char *ps = (const char *)c->pin_out + (size_t)slot * so_slot;
+        for (auto &a : outs)
+            if (a.host && !a.pinned) c->pool.copy((char *)a.host + off * a.elem, ps + a.ring_off, m * a.elem);
+        return BHG_OK;
+    };
+
+    for (size_t ch = 0; ch < n_chunks; ch++) {
+        const int slot = (int)(ch & 1);
+        const size_t off = ch * chunk, m = std::min(chunk, n - off);
+        if (upload) {
+            char *pi = (char *)c->pin_in + (size_t)slot * si_slot;
+            // the slot's previous upload (chunk ch - 2) must have left the staging memory
+            if (ch >= 2 && (!pin_k0 || !pin_x0)) HIP_TRY(hipEventSynchronize(c->ev_in[slot]));
+            const void *src_k0 = io.h_k0 + off * 3, *src_x0 = per_ray_x0 ? io.h_x0 + off * 3 : nullptr;
+            if (!pin_k0) {
+                c->pool.copy(pi, src_k0, m * 24);
+                src_k0 = pi;
+            }
+            if (per_ray_x0 && !pin_x0) {
+                c->pool.copy(pi + si_x0, src_x0, m * 24);
+                src_x0 = pi + si_x0;
+            }
+            HIP_TRY(hipMemcpyAsync(d_k0u + off * 3, src_k0, m * 24, hipMemcpyHostToDevice, c->s_in));
+            if (per_ray_x0) HIP_TRY(hipMemcpyAsync(d_x0 + off * 3, src_x0, m * 24, hipMemcpyHostToDevice, c->s_in));
+            HIP_TRY(hipEventRecord(c->ev_in[slot], c->s_in));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
+        }
+        rc = trace_device_impl(c, p, spheres, n_spheres, io.x0_shared, per_ray_x0 ? d_x0 + off * 3 : nullptr, d_k0 + off * 3, m,
+                               d_end + off * 6, d_flags + off, d_steps + off, d_acc + off, d_obj ? d_obj + off : nullptr,
+                               c->stream);
+        if (rc != BHG_OK) return rc;
+        if (split)
+            HIP_TRY(bhg::launch_split_end(d_end + off * 6, m, io.loc ? d_loc + off * 3 : nullptr, io.dir ? d_dir + off * 3 : nullptr,
+                                          c->stream));
+        HIP_TRY(hipEventRecord(c->ev_k[slot], c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->s_out, c->ev_k[slot], 0));
+        char *po = (char *)c->pin_out + (size_t)slot * so_slot;
+        for (auto &a : outs)
+            if (a.host)
+                HIP_TRY(hipMemcpyAsync(a.pinned ? (void *)((char *)a.host + off * a.elem) : (void *)(po + a.ring_off),
+                                       a.dev + off * a.elem, m * a.elem, hipMemcpyDeviceToHost, c->s_out));
+        HIP_TRY(hipEventRecord(c->ev_out[slot], c->s_out));
+        // while the GPU works on this chunk: the previous chunk's results go from the ring to the caller's arrays
+        if (ch >= 1) {
+            rc = copy_out(ch - 1);
+            if (rc != BHG_OK) return rc;
+        }
+    }
+    rc = copy_out(n_chunks - 1);
+    if (rc != BHG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->s_out));
+    return BHG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const double *x0,
                       int x0_is_shared, const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
                       uint32_t *n_accepted, int8_t *object_id)
@@ -599,113 +756,118 @@ int bhg_trace_objects(bhg_context *c, const bhg_params *p, const double *spheres
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !end) return fail(BHG_E_INVALID, "x0 / k0 / end is NULL");
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    PipeIO io;
+    io.h_k0 = k0;
+    io.h_x0 = x0_is_shared ? nullptr : x0;
+    io.x0_shared = x0_is_shared ? x0 : nullptr;
+    io.end = end;
+    io.flags = flags;
+    io.steps = n_steps;
+    io.acc = n_accepted;
+    io.obj = object_id;
+    return pipeline_impl(c, p, spheres, n_spheres, io, n);
+}
+
+/* ---- rays resident on the device ------------------------------------------------------- */
+int bhg_rays_create(bhg_context *c, const bhg_camera *cam, const double *jitter, int jitter_is_compact, const int64_t *pixels,
+                    size_t n_pixels, bhg_rays **out)
+{
+    if (!out) return fail(BHG_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!c || !cam) return fail(BHG_E_INVALID, "ctx / camera is NULL");
+    if (cam->width <= 0 || cam->height <= 0 || cam->samples <= 0) return fail(BHG_E_INVALID, "width, height, samples must be > 0");
+    const size_t frame_px = (size_t)cam->width * (size_t)cam->height;
+    if (!pixels) n_pixels = frame_px;
+    if (n_pixels == 0) return fail(BHG_E_INVALID, "empty pixel list");
+    if (jitter_is_compact && !jitter) return fail(BHG_E_INVALID, "compact jitter stream is NULL");
+    const size_t n = n_pixels * (size_t)cam->samples;
+    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays");
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->s_in) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
-        }
+    bhg_rays *r = new (std::nothrow) bhg_rays();
+    if (!r) return fail(BHG_E_NOMEM, "host allocation failed");
+    r->ctx = c;
+    r->n = n;
+    std::memcpy(r->origin, cam->origin, sizeof(r->origin));
+    hipError_t e = hipMalloc((void **)&r->d_k0, n * 3 * sizeof(double));
+    if (e != hipSuccess) {
+        delete r;
+        return fail_hip(e, "hipMalloc(rays)");
     }
-    // device arrays for the whole call (chunks are sub-ranges of each)
-    const bool per_ray_x0 = !x0_is_shared;
-    const size_t in_bytes = n * 3 * sizeof(double) * (per_ray_x0 ? 2 : 1);
-    const size_t off_flags = n * 6 * sizeof(double);
-    const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
-    const size_t off_acc = off_steps + n * sizeof(uint32_t);
-    const size_t off_obj = off_acc + n * sizeof(uint32_t);
-    const size_t out_bytes = off_obj + n;
-    rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
-    if (rc != BHG_OK) return rc;
-    rc = ensure(&c->d_out, &c->d_out_bytes, out_bytes);
-    if (rc != BHG_OK) return rc;
-    double *d_k0 = (double *)c->d_in;
-    double *d_x0 = per_ray_x0 ? d_k0 + n * 3 : nullptr;
-    char *o = (char *)c->d_out;
-    double *d_end = (double *)o;
-    uint8_t *d_flags = (uint8_t *)(o + off_flags);
-    uint32_t *d_steps = (uint32_t *)(o + off_steps), *d_acc = (uint32_t *)(o + off_acc);
-    int8_t *d_obj = object_id ? (int8_t *)(o + off_obj) : nullptr;
-
-    const size_t chunk = size_t(1) << 20;  // rays per chunk: 24 MB up, 57 MB back
-    const size_t n_chunks = (n + chunk - 1) / chunk;
-    const size_t cmax = std::min(chunk, n);
-    const bool pin_k0 = is_pinned(k0), pin_x0 = !per_ray_x0 || is_pinned(x0), pin_end = is_pinned(end);
-    const bool pin_fl = !flags || is_pinned(flags), pin_st = !n_steps || is_pinned(n_steps);
-    const bool pin_ac = !n_accepted || is_pinned(n_accepted), pin_ob = !object_id || is_pinned(object_id);
-    // staging ring slot layouts (each array of a slot at a fixed offset)
-    const size_t si_x0 = cmax * 24, si_slot = cmax * 48;
-    const size_t so_fl = cmax * 48, so_st = so_fl + ((cmax + 7) & ~size_t(7)), so_ac = so_st + cmax * 4, so_ob = so_ac + cmax * 4;
-    const size_t so_slot = (so_ob + cmax + 63) & ~size_t(63);
-    if (!pin_k0 || !pin_x0) {
-        rc = ensure_pinned(&c->pin_in, &c->pin_in_bytes, 2 * si_slot);
-        if (rc != BHG_OK) return rc;
+    // the jitter stream and the pixel list are only needed to generate the rays: staged in the call's own buffers
+    const size_t n_jit = jitter ? 2 * (size_t)cam->samples * (jitter_is_compact ? n_pixels : frame_px) : 0;
+    const size_t tmp_bytes = n_jit * sizeof(double) + (pixels ? n_pixels * sizeof(int64_t) : 0);
+    int rc = ensure(&c->d_in, &c->d_in_bytes, tmp_bytes + 64);
+    if (rc != BHG_OK) {
+        (void)hipFree(r->d_k0);
+        delete r;
+        return rc;
     }
-    if (!pin_end || !pin_fl || !pin_st || !pin_ac || !pin_ob) {
-        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, 2 * so_slot);
-        if (rc != BHG_OK) return rc;
+    double *d_jit = (double *)c->d_in;
+    int64_t *d_pix = (int64_t *)((char *)c->d_in + n_jit * sizeof(double));
+    bhg::RaygenArgs a;
+    std::memset(&a, 0, sizeof(a));
+    hipError_t err = hipSuccess;
+    if (jitter) err = hipMemcpyAsync(d_jit, jitter, n_jit * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (err == hipSuccess && pixels) err = hipMemcpyAsync(d_pix, pixels, n_pixels * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+    a.jitter = jitter ? d_jit : nullptr;
+    a.compact = jitter_is_compact ? 1 : 0;
+    a.pixels = pixels ? d_pix : nullptr;
+    a.k0 = r->d_k0;
+    a.n_pixels = n_pixels;
+    a.width = cam->width;
+    a.height = cam->height;
+    a.samples = cam->samples;
+    a.fov_x = cam->fov_x;
+    a.fov_y = cam->fov_y;
+    static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    a.rotate = std::memcmp(cam->rot, eye, sizeof(eye)) != 0;
+    std::memcpy(a.rot, cam->rot, sizeof(a.rot));
+    if (err == hipSuccess) err = bhg::launch_raygen(a, c->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    if (err != hipSuccess) {
+        (void)hipFree(r->d_k0);
+        delete r;
+        return fail_hip(err, "ray generation");
     }
-
-    auto copy_out = [&](size_t ch) -> int {  // host side of chunk ch's way back
-        const int slot = (int)(ch & 1);
-        const size_t off = ch * chunk, m = std::min(chunk, n - off);
-        HIP_TRY(hipEventSynchronize(c->ev_out[slot]));
-        const char *ps = (const char *)c->pin_out + (size_t)slot * so_slot;
-        if (!pin_end) c->pool.copy(end + off * 6, ps, m * 48);
-        if (!pin_fl) c->pool.copy(flags + off, ps + so_fl, m);
-        if (!pin_st) c->pool.copy(n_steps + off, ps + so_st, m * 4);
-        if (!pin_ac) c->pool.copy(n_accepted + off, ps + so_ac, m * 4);
-        if (!pin_ob) c->pool.copy(object_id + off, ps + so_ob, m);
-        return BHG_OK;
-    };
-
-    for (size_t ch = 0; ch < n_chunks; ch++) {
-        const int slot = (int)(ch & 1);
-        const size_t off = ch * chunk, m = std::min(chunk, n - off);
-        char *pi = (char *)c->pin_in + (size_t)slot * si_slot;
-        // the slot's previous upload (chunk ch - 2) must have left the staging memory
-        if (ch >= 2 && (!pin_k0 || !pin_x0)) HIP_TRY(hipEventSynchronize(c->ev_in[slot]));
-        const void *src_k0 = k0 + off * 3, *src_x0 = per_ray_x0 ? x0 + off * 3 : nullptr;
-        if (!pin_k0) {
-            c->pool.copy(pi, src_k0, m * 24);
-            src_k0 = pi;
-        }
-        if (per_ray_x0 && !pin_x0) {
-            c->pool.copy(pi + si_x0, src_x0, m * 24);
-            src_x0 = pi + si_x0;
-        }
-        HIP_TRY(hipMemcpyAsync(d_k0 + off * 3, src_k0, m * 24, hipMemcpyHostToDevice, c->s_in));
-        if (per_ray_x0) HIP_TRY(hipMemcpyAsync(d_x0 + off * 3, src_x0, m * 24, hipMemcpyHostToDevice, c->s_in));
-        HIP_TRY(hipEventRecord(c->ev_in[slot], c->s_in));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
-        rc = trace_device_impl(c, p, spheres, n_spheres, x0_is_shared ? x0 : nullptr, per_ray_x0 ? d_x0 + off * 3 : nullptr,
-                               d_k0 + off * 3, m, d_end + off * 6, d_flags + off, d_steps + off, d_acc + off,
-                               d_obj ? d_obj + off : nullptr, c->stream);
-        if (rc != BHG_OK) return rc;
-        HIP_TRY(hipEventRecord(c->ev_k[slot], c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->s_out, c->ev_k[slot], 0));
-        char *po = (char *)c->pin_out + (size_t)slot * so_slot;
-        HIP_TRY(hipMemcpyAsync(pin_end ? (void *)(end + off * 6) : (void *)po, d_end + off * 6, m * 48, hipMemcpyDeviceToHost, c->s_out));
-        if (flags) HIP_TRY(hipMemcpyAsync(pin_fl ? (void *)(flags + off) : (void *)(po + so_fl), d_flags + off, m, hipMemcpyDeviceToHost, c->s_out));
-        if (n_steps)
-            HIP_TRY(hipMemcpyAsync(pin_st ? (void *)(n_steps + off) : (void *)(po + so_st), d_steps + off, m * 4, hipMemcpyDeviceToHost, c->s_out));
-        if (n_accepted)
-            HIP_TRY(hipMemcpyAsync(pin_ac ? (void *)(n_accepted + off) : (void *)(po + so_ac), d_acc + off, m * 4, hipMemcpyDeviceToHost, c->s_out));
-        if (object_id)
-            HIP_TRY(hipMemcpyAsync(pin_ob ? (void *)(object_id + off) : (void *)(po + so_ob), d_obj + off, m, hipMemcpyDeviceToHost, c->s_out));
-        HIP_TRY(hipEventRecord(c->ev_out[slot], c->s_out));
-        // while the GPU works on this chunk: the previous chunk's results go from the ring to the caller's arrays
-        if (ch >= 1) {
-            rc = copy_out(ch - 1);
-            if (rc != BHG_OK) return rc;
-        }
-    }
-    rc = copy_out(n_chunks - 1);
-    if (rc != BHG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(c->s_out));
+    *out = r;
     return BHG_OK;
+}
+
+size_t bhg_rays_count(const bhg_rays *r) { return r ? r->n : 0; }
+
+void bhg_rays_destroy(bhg_rays *r)
+{
+    if (!r) return;
+    if (r->d_k0) {
+        (void)hipSetDevice(r->ctx->device);
+        (void)hipFree(r->d_k0);
+    }
+    delete r;
+}
+
+int bhg_rays_trace(bhg_rays *r, const bhg_params *p, const double *spheres, int32_t n_spheres, size_t first, size_t n,
+                   double *end, double *end_loc, double *end_dir, uint8_t *flags, uint32_t *n_steps, uint32_t *n_accepted,
+                   int8_t *object_id)
+{
+    if (!r) return fail(BHG_E_INVALID, "rays is NULL");
+    int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    rc = validate_spheres(p, spheres, n_spheres);
+    if (rc != BHG_OK) return rc;
+    if (first > r->n || n > r->n - first) return fail(BHG_E_INVALID, "ray range out of bounds");
+    if (n == 0) return BHG_OK;
+    if (!end && !end_loc && !end_dir && !flags) return fail(BHG_E_INVALID, "no result array given");
+    PipeIO io;
+    io.d_k0 = r->d_k0 + first * 3;
+    io.x0_shared = r->origin;
+    io.end = end;
+    io.loc = end_loc;
+    io.dir = end_dir;
+    io.flags = flags;
+    io.steps = n_steps;
+    io.acc = n_accepted;
+    io.obj = object_id;
+    return pipeline_impl(r->ctx, p, spheres, n_spheres, io, n);
 }
 
 int bhg_host_alloc(bhg_context *c, size_t bytes, void **out)

@@ -30,8 +30,8 @@ __global__ void __launch_bounds__(256) raygen_kernel(const RaygenArgs A)
     const double W = (double)A.width, H = (double)A.height;
     const double aspect = H / W;
     const double dy = aspect / H, dx = 1.0 / W;
-    const uint64_t j = (s * (uint64_t)A.width * (uint64_t)A.height + (uint64_t)pix) * 2;
-    const double u1 = A.jitter[j], u2 = A.jitter[j + 1];
+    const uint64_t j = A.compact ? i * 2 : (s * (uint64_t)A.width * (uint64_t)A.height + (uint64_t)pix) * 2;
+    const double u1 = A.jitter ? A.jitter[j] : 0.5, u2 = A.jitter ? A.jitter[j + 1] : 0.5;
     const double x_render = A.fov_x * (double)(px - (int64_t)(A.width / 2)) / W;
     const double y_render = A.fov_y * (double)(py - (int64_t)(A.height / 2)) / H * aspect;
     double d0 = x_render + dx * (u1 - 0.5);
@@ -217,6 +217,24 @@ __global__ void __launch_bounds__(256) gather_rows4_kernel(const float4 *src, co
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[index[i]];
+}
+
+// end[n][6] -> loc[n][3] and / or dir[n][3]: what spacetime_ray_cast hands back separately (end_loc, end_dir,
+// RelativisticRenderEngine.py:307-308), so that only the arrays a caller reads cross PCIe
+__global__ void __launch_bounds__(256) split_end_kernel(const double *end, uint64_t n, double *loc, double *dir)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 3) return;
+    const uint64_t r = i / 3, c = i - r * 3;
+    if (loc) loc[i] = end[r * 6 + c];
+    if (dir) dir[i] = end[r * 6 + 3 + c];
+}
+
+hipError_t launch_split_end(const double *end, uint64_t n, double *loc, double *dir, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(split_end_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, s, end, n, loc, dir);
+    return hipGetLastError();
 }
 
 hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s)

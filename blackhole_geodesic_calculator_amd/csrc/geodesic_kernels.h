@@ -55,7 +55,10 @@ struct TraceArgs {
 
 // camera-ray generation (frame_kernels.hip)
 struct RaygenArgs {
-    const double *jitter;   // [S*H*W*2] MT19937 doubles, sample-major then row-major pixels, (u1, u2)
+    const double *jitter;   // [S*H*W*2] MT19937 doubles, sample-major then row-major pixels, (u1, u2); nullptr = pixel
+                            // centres (u1 = u2 = 1/2)
+    int32_t compact;        // 1: the stream holds draws for the listed pixels only, [S][n_pixels][2] in list order (a
+                            // mark window: the engine draws inside the window only, RelativisticRenderEngine.py:219)
     const int64_t *pixels;  // [n_pixels] flat pixel ids y*W+x, or nullptr = all pixels in order
     double *k0;             // [S*n_pixels][3], ray i = s*n_pixels + p
     uint64_t n_pixels;
@@ -87,6 +90,7 @@ struct ShadeArgs {
 
 hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s);
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s);
+hipError_t launch_split_end(const double *end, uint64_t n, double *loc, double *dir, hipStream_t s);
 hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s);
 
 // ev: nullptr, or 3 events recorded around prepare | trace on stream s

@@ -85,7 +85,7 @@ class FrameTracer:
     def __init__(self, integrator, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
                  origin=(0.0, 0.0, 0.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0),
                  max_step=np.inf, curve_end=50.0, mark=None, spheres=None, object_hit=None, disk=None,
-                 disk_hit=None):
+                 disk_hit=None, device_rays=True):
         self.integrator = integrator
         self.width, self.height, self.samples = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
@@ -104,12 +104,75 @@ class FrameTracer:
         self.disk = disk
         self.disk_hit = disk_hit
         self.last_counters = None
+        # device_rays: generate the rays on the device and keep them there (integrator.ray_set) when the integrator can,
+        # instead of generating them on the host and uploading them for every sample; only end_dir + flags (and
+        # end_loc / object ids when a disk or objects are set) come back.  Bit-identical rays for an unrotated
+        # camera (tests), within an ulp before normalisation otherwise.
+        self.device_rays = bool(device_rays)
+        self._rays = None
+        self._rays_key = None
 
     # the jitter stream depends only on (seed, window, S): cache it across frames (:189 re-seeds
     # identically on every render())
     def directions(self):
         return camera_directions(self.width, self.height, self.samples, self.fov_x, self.fov_y,
                                  self.sampling_seed, self.rotation_euler, self.mark)
+
+    def _window(self):
+        W, H = self.width, self.height
+        y_min, y_max, x_min, x_max = self.mark if self.mark is not None else (0, H, 0, W)
+        rows = [y for y in range(H) if y_min <= y <= y_max]
+        cols = np.array([x for x in range(W) if x_min <= x <= x_max], dtype=np.int64)
+        return rows, cols
+
+    def _resident_rays(self, rows, cols):
+        """The frame's ray set on the device, rebuilt only when the camera, the window or the seed change (the
+        engine re-seeds identically on every render(), :189: a static camera traces the same rays every frame)."""
+        key = (self.width, self.height, self.samples, self.fov_x, self.fov_y, self.sampling_seed, self.rotation_euler,
+               tuple(self.origin - self.bh_loc), self.mark)
+        if self._rays is None or self._rays_key != key:
+            P = len(rows) * len(cols)
+            stream = python_random_stream(self.sampling_seed, 2 * self.samples * P)   # draws inside the window only (:219)
+            full = self.mark is None
+            pix = None if full else (np.asarray(rows, dtype=np.int64)[:, None] * self.width + cols[None, :]).reshape(-1)
+            if self._rays is not None:
+                self._rays.close()
+            self._rays = self.integrator.ray_set(self.width, self.height, self.samples, self.fov_x, self.fov_y,
+                                                 self.origin - self.bh_loc, self.rotation_euler, jitter=stream,
+                                                 jitter_is_compact=not full, pixels=pix)
+            self._rays_key = key
+        return self._rays
+
+    def _cast_sample_resident(self, rays, s, shape):
+        """Sample s of the resident ray set through the solver: the same six values spacetime_ray_cast_batch returns."""
+        P = shape[0] * shape[1]
+        want = ["end_dir", "flags"]
+        sp = None
+        if self.spheres is not None and len(self.spheres):
+            sp = np.array(self.spheres, dtype=np.float64).reshape(-1, 4)
+            sp[:, 0:3] -= self.bh_loc
+            want += ["end_loc", "object_id"]
+        elif self.disk is not None:
+            want += ["end_loc"]
+        kw = {} if self.disk is None else {"disk": (float(self.disk[0]), float(self.disk[1]))}
+        out = self.integrator.trace_rays(rays, first=s * P, n=P, max_step=self.max_step, curve_end=self.curve_end,
+                                         spheres=sp, want=tuple(want), **kw)
+        flags = out["flags"].reshape(shape)
+        end_dir = out["end_dir"].reshape(shape + (3,))
+        end_loc = out["end_loc"].reshape(shape + (3,)) if "end_loc" in out else np.zeros(shape + (3,))
+        hit_bh = (flags & 1) != 0
+        if sp is None:
+            hit = np.zeros(shape, dtype=bool)
+            index = np.full(shape, -1, dtype=np.int8)
+            normal = np.zeros(shape + (3,))
+        else:
+            index = out["object_id"].reshape(shape)
+            hit = index >= 0
+            c = sp[np.maximum(index, 0)]
+            normal = np.where(hit[..., None], (end_loc - c[..., 0:3]) / c[..., 3:4], 0.0)
+        if self.disk is not None:
+            index = np.where(flags == 128, np.int8(-2), index).astype(np.int8)   # BHG_FLAG_HIT_DISK
+        return hit, hit_bh, end_dir, end_loc, normal, index
 
     def ray_trace(self, buf, background_hit):
         """Generator with the reference's protocol: mutates buf[H, W, 4] in place, yields the
@@ -121,17 +184,24 @@ class FrameTracer:
         rows = [y for y in range(H) if y_min <= y <= y_max]
         cols = np.array([x for x in range(W) if x_min <= x <= x_max], dtype=np.int64)
         sbuf = np.zeros((H, W, 4))
-        dirs = self.directions()  # [S, H, W, 3], NaN outside the window
+        resident = self.device_rays and hasattr(self.integrator, "ray_set") and bool(rows) and len(cols) > 0
+        if resident:
+            rset = self._resident_rays(rows, cols)
+        else:
+            dirs = self.directions()  # [S, H, W, 3], NaN outside the window
         steps = 0
         rays = 0
         colour = np.zeros((len(rows), len(cols), 3))
         for s in range(S):
             if rows and len(cols):
-                d = dirs[s][np.ix_(rows, cols)]  # [R, C, 3]
-                hit, hit_bh, end_dir, end_loc, normal, index = spacetime_ray_cast_batch(
-                    self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end,
-                    spheres=self.spheres, return_objects=True, disk=self.disk)
-                colour = np.zeros(d.shape)
+                if resident:
+                    hit, hit_bh, end_dir, end_loc, normal, index = self._cast_sample_resident(rset, s, (len(rows), len(cols)))
+                else:
+                    d = dirs[s][np.ix_(rows, cols)]  # [R, C, 3]
+                    hit, hit_bh, end_dir, end_loc, normal, index = spacetime_ray_cast_batch(
+                        self.integrator, self.origin, d, self.bh_loc, self.max_step, self.curve_end,
+                        spheres=self.spheres, return_objects=True, disk=self.disk)
+                colour = np.zeros(hit_bh.shape + (3,))
                 on_disk = index == -2
                 esc = ~hit_bh & ~hit & ~on_disk   # :239-246: hit -> spacetime_hit, hit_bh -> black, else background
                 if on_disk.any():

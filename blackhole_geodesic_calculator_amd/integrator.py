@@ -97,6 +97,22 @@ class GeodesicIntegratorSchwarzschild:
         return out
 
     # ------------------------------------------------------------------------------------
+    def ray_set(self, width, height, samples, fov_x, fov_y, origin, rotation_euler=(0.0, 0.0, 0.0), jitter=None,
+                jitter_is_compact=False, pixels=None) -> _ffi.RaySet:
+        """The camera rays of a frame generated on the device and kept there (bhg_rays_create): the engine's
+        pinhole + jitter formula (RelativisticRenderEngine.py:224-230) evaluated by libbhgeo's ray-generation
+        kernel from the MT19937 stream; jitter=None gives pixel centres.  origin is BH-centred."""
+        from .raygen import euler_xyz_matrix
+        return _ffi.RaySet(self._ctx, width, height, samples, fov_x, fov_y, origin, euler_xyz_matrix(rotation_euler), jitter,
+                           jitter_is_compact, pixels)
+
+    def trace_rays(self, rays: _ffi.RaySet, first=0, n=None, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None,
+                   spheres=None, want=("end_dir", "flags")):
+        """Trace rays [first, first + n) of a resident ray set; only the arrays named in `want` come back
+        (end, end_loc, end_dir, flags, n_steps, n_accepted, object_id)."""
+        return rays.trace(self.params(max_step, curve_end, r_exit, disk), first, n, want, spheres)
+
+    # ------------------------------------------------------------------------------------
     def calc_trajectory(self, k0_xyz, x0_xyz, max_step=np.inf, curve_end=50, nr_points_curve=50,
                         verbose=False, **_ignored):
         """Per-ray drop-in for the call at RelativisticRenderEngine.py:293-294.

@@ -134,6 +134,36 @@ int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is
               const double *k0, size_t n, double *end, uint8_t *flags, uint32_t *n_steps,
               uint32_t *n_accepted);
 
+/* Rays resident on the device: the engine's camera rays (RelativisticRenderEngine.py:185-230 -- pinhole + MT19937
+ * jitter, rotate, normalise; loop order sample -> row -> column) are generated ON the device from the jitter stream
+ * and stay there, so the directions (24 B/ray) never cross PCIe, and a frame loop whose camera does not move (the
+ * engine re-seeds identically on every render(), :189) traces the same ray set again and again.  This is the path
+ * the frame driver and the pre-traced camera of the Python adaptor use (frame.py, camera.py).
+ *   jitter: HOST array of random.random() draws, (u1, u2) per ray, or NULL = pixel centres (u = 1/2: the Cam
+ *           edition's camera, CamEdition.py:225-228).  jitter_is_compact = 0: the full-frame stream
+ *           [samples][height][width][2]; 1: draws for the listed pixels only, [samples][n_pixels][2] in list order
+ *           (a mark window: the engine only draws inside it, :219).
+ *   pixels: HOST array of flat pixel ids y * width + x, or NULL = every pixel in row-major order.
+ * Ray s * n_pixels + p is sample s of pixel p.  The rays belong to ctx and must be destroyed before it. */
+typedef struct bhg_camera {
+    int32_t width, height, samples, reserved;
+    double fov_x, fov_y;  /* property values fov_x / fov_y of the engine (:504-505) */
+    double rot[9];        /* row-major rotation matrix of the camera's Euler angles (:183); identity = unrotated */
+    double origin[3];     /* camera position minus the hole's (:278) */
+} bhg_camera;
+typedef struct bhg_rays bhg_rays;
+int bhg_rays_create(bhg_context *ctx, const bhg_camera *cam, const double *jitter, int jitter_is_compact,
+                    const int64_t *pixels, size_t n_pixels, bhg_rays **out);
+size_t bhg_rays_count(const bhg_rays *rays);
+void bhg_rays_destroy(bhg_rays *rays);
+/* Trace rays [first, first + n) of the set and bring back only what is asked for (HOST arrays, any may be NULL):
+ * end [n][6], or its halves end_loc [n][3] / end_dir [n][3] -- spacetime_ray_cast's return values (:307-308) --
+ * flags, n_steps, n_accepted, object_id.  Same pipeline, same kernels and bit-for-bit the same results as bhg_trace on
+ * the same directions.  Blocking. */
+int bhg_rays_trace(bhg_rays *rays, const bhg_params *p, const double *spheres, int32_t n_spheres, size_t first, size_t n,
+                   double *end, double *end_loc, double *end_dir, uint8_t *flags, uint32_t *n_steps,
+                   uint32_t *n_accepted, int8_t *object_id);
+
 /* Page-locked host memory for the arrays handed to bhg_trace / bhg_trace_objects: results then arrive by DMA
  * with no host-side copy.  (numpy's own allocations are pageable; the Python adaptor allocates its result arrays
  * here and keeps a pool of them, page-locking being slow.)  ctx may be NULL in bhg_host_free. */

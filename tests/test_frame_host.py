@@ -150,6 +150,11 @@ def test_addon_plugin_surface_with_fake_bpy(monkeypatch):
     marker = types.SimpleNamespace(type="MESH", location=(0.0, 0.0, 0.0), dimensions=(1.0, 1.0, 1.0))
     depsgraph.scene.objects[:] = [ball, lamp, marker, types.SimpleNamespace(type="CAMERA", location=(0, 0, 30), dimensions=(1, 1, 1))]
     depsgraph.scene.blackhole_obj = marker
+    # ... but only when asked to: by default scene meshes leave the image alone, as in the reference (hit = False, :304-305)
+    eng1 = addon.RelativisticRenderEngine()
+    eng1.render(depsgraph)
+    assert np.array_equal(np.array(eng1.result.layers[0].passes["Combined"].rect), rect)
+    depsgraph.scene.curved_space_objects = 1.0
     eng2 = addon.RelativisticRenderEngine()
     eng2.render(depsgraph)
     sph = eng2.scene_spheres(depsgraph)
@@ -157,8 +162,13 @@ def test_addon_plugin_surface_with_fake_bpy(monkeypatch):
     rect2 = np.array(eng2.result.layers[0].passes["Combined"].rect)
     changed = np.abs(rect2 - rect).max(1) > 0
     assert 0 < changed.sum() < len(rect) // 2
+    many = [types.SimpleNamespace(type="MESH", location=(2.0 + j, 0.0, 9.0), dimensions=(1.0, 1.0, 1.0)) for j in range(10)]
+    depsgraph.scene.objects[:] = many
+    with pytest.warns(RuntimeWarning, match="only the 8 nearest"):
+        assert eng2.scene_spheres(depsgraph).shape == (8, 4)
     depsgraph.scene.objects[:] = []
     depsgraph.scene.blackhole_obj = None
+    depsgraph.scene.curved_space_objects = 0.0
     assert (eng.mark_y_min, eng.mark_y_max, eng.mark_x_min, eng.mark_x_max) == (0, 8, 0, 12)
     # shading goes through Blender's texture evaluate with the reference's (u, v)
     col = eng.background_hit(np.array([0.0, 1.0, 0.0]))

@@ -1,0 +1,179 @@
+"""GPU tests of the host-side mirrors of the reference's interface on the resident-ray path: the camera rays are
+generated on the device (bhg_rays_create) and only what the caller reads comes back (bhg_rays_trace) -- frame driver,
+pre-traced camera, and the Blender add-on end to end through the fake-bpy harness with the REAL integrator
+(raytracer/RelativisticRenderEngine.py:50-168: render -> render_scene -> ray_trace -> layer.rect), against an image
+built from the oracle.  Plus Kerr physics checked on what the device returns."""
+import importlib
+
+import numpy as np
+import pytest
+
+import fake_bpy
+from conftest import CAM
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(**kw):
+    from blackhole_geodesic_calculator_amd import _ffi
+    return _ffi.make_params(**kw)
+
+
+def test_resident_rays_equal_host_generated_rays_bit_for_bit(ctx):
+    """Unrotated camera: device ray generation reproduces the host restatement of :224-230 exactly, so tracing the
+    resident set gives the same bits as uploading camera_directions() -- full frame, a mark window (compact jitter
+    stream: the engine only draws inside the window, :219) and pixel centres."""
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild, camera_directions
+    from blackhole_geodesic_calculator_amd.camera import RelativisticCamera
+    from blackhole_geodesic_calculator_amd.raygen import python_random_stream
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=ctx)
+    W, H, S = 96, 80, 3
+    d = camera_directions(W, H, S, 0.6, 0.6, 42.0)
+    ref = ctx.trace(d.reshape(-1, 3), CAM, _params(r_s=1.0, lambda_end=50.0))
+    rs = gi.ray_set(W, H, S, 0.6, 0.6, CAM, jitter=python_random_stream(42.0, 2 * S * W * H))
+    assert rs.n == S * W * H
+    o = gi.trace_rays(rs, want=("end", "end_loc", "end_dir", "flags", "n_steps", "n_accepted"))
+    assert np.array_equal(o["end"], ref[0]) and np.array_equal(o["flags"], ref[1])
+    assert np.array_equal(o["n_steps"], ref[2]) and np.array_equal(o["n_accepted"], ref[3])
+    assert np.array_equal(o["end_loc"], ref[0][:, 0:3]) and np.array_equal(o["end_dir"], ref[0][:, 3:6])
+    # a sub-range (one sample) with only direction + flags coming back
+    P = W * H
+    o1 = gi.trace_rays(rs, first=P, n=P)
+    assert set(o1) == {"end_dir", "flags"} and np.array_equal(o1["end_dir"], ref[0][P:2 * P, 3:6])
+    rs.close()
+    # mark window
+    mark = (10, 49, 20, 70)
+    dm = camera_directions(W, H, S, 0.6, 0.6, 42.0, mark=mark)
+    rows, cols = np.arange(10, 50), np.arange(20, 71)
+    dw = dm[:, rows][:, :, cols]
+    refw = ctx.trace(dw.reshape(-1, 3), CAM, _params(r_s=1.0, lambda_end=50.0))
+    pix = (rows[:, None] * W + cols[None, :]).reshape(-1)
+    rsw = gi.ray_set(W, H, S, 0.6, 0.6, CAM, jitter=python_random_stream(42.0, 2 * S * len(pix)), jitter_is_compact=True, pixels=pix)
+    ow = gi.trace_rays(rsw, want=("end", "flags"))
+    assert np.array_equal(ow["end"], refw[0]) and np.array_equal(ow["flags"], refw[1])
+    rsw.close()
+    # pixel centres: the pre-traced camera
+    cam = RelativisticCamera(resolution=[H, W], field_of_view=[0.6, 0.6], camera_location=CAM, integrator=gi)
+    cam.run()
+    refc = ctx.trace(cam.pixel_directions().reshape(-1, 3), CAM, _params(r_s=1.0, lambda_end=50.0))
+    assert np.array_equal(cam.ray_end.reshape(-1, 6), refc[0]) and np.array_equal(cam.results["flags"].reshape(-1), refc[1])
+    with pytest.raises(Exception):
+        gi.trace_rays(gi.ray_set(8, 8, 1, 0.6, 0.6, CAM), first=60, n=10)      # range beyond the set
+
+
+def test_frame_tracer_resident_path_equals_upload_path(ctx):
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    from blackhole_geodesic_calculator_amd.frame import FrameTracer, equirect_uv
+
+    def sky(d):
+        u, v = equirect_uv(d)
+        return np.stack([0.5 + 0.5 * np.sin(np.pi * u), 0.5 + 0.5 * v, 0.25 + 0.25 * np.cos(2 * np.pi * u)], -1)
+
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=ctx)
+    bh = np.array([1.0, -2.0, 0.5])
+    sph = [[1.0 + 3.0, -2.0 + 2.0, 0.5 + 9.0, 1.5]]
+    hits = []
+
+    def object_hit(loc, normal, index):
+        hits.append(len(index))
+        return np.stack([0.2 + 0.0 * index, 0.4 + 0.0 * index, 0.9 + 0.0 * index], -1)
+
+    for kw, exact in ((dict(), True), (dict(mark=(4, 30, 8, 50)), True), (dict(disk=(3.0, 8.0)), True),
+                      (dict(spheres=sph, object_hit=object_hit, disk=(3.0, 8.0)), True),
+                      (dict(rotation_euler=(0.02, -0.01, 0.3)), False)):
+        bufs = []
+        for resident in (True, False):
+            ft = FrameTracer(gi, 64, 48, 2, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM + bh, bh_loc=bh, curve_end=60.0,
+                             device_rays=resident, **kw)
+            buf = np.ones((48, 64, 4))
+            prog = list(ft.ray_trace(buf, sky))
+            assert len(prog) > 0
+            bufs.append(buf)
+            if resident:   # a second frame reuses the resident set (static camera) and gives the same image
+                assert ft._rays is not None
+                rs = ft._rays
+                buf2 = np.ones((48, 64, 4))
+                list(ft.ray_trace(buf2, sky))
+                assert ft._rays is rs and np.array_equal(buf2, buf)
+        if exact:
+            assert np.array_equal(bufs[0], bufs[1]), kw
+        else:   # rotated camera: the device applies the rotation in a different operation order than numpy's matmul
+            assert np.abs(bufs[0] - bufs[1]).max() < 1e-9
+    assert hits and min(hits) > 0
+
+
+def test_addon_render_on_the_gpu_matches_oracle_image(ctx, oracle):
+    """config 1 geometry through the plugin surface: 64 x 64 x 1, camera (1e-4, 0, 30), fov 0.6, mass 0.5."""
+    bpy, depsgraph = fake_bpy.install(width=64, height=64, samples=1)
+    addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+    addon.register()
+    eng = addon.RelativisticRenderEngine()
+    eng.render(depsgraph)                       # builds its own GeodesicIntegratorSchwarzschild (:134) on the GPU
+    assert eng.ended == 1 and len(eng.progress) == 64
+    rect = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(64, 64, 4)
+    assert eng.GeoInt.context.last_launch()["workgroups"] > 0      # the HIP kernel ran
+    # the same image from the oracle: rays by the reference's formula, black for horizon rays, Blender's texture
+    # lookup (the fake's analytic sky) for the rest, one sample
+    from blackhole_geodesic_calculator_amd import camera_directions
+    from blackhole_geodesic_calculator_amd.frame import equirect_uv
+    d = camera_directions(64, 64, 1, 0.6, 0.6, 42.0).reshape(-1, 3)
+    o = oracle.trace(d, CAM, r_s=1.0, lambda_end=50.0)
+    u, v = equirect_uv(o["end"][:, 3:6])
+    tex = fake_bpy.FakeTexture("t", "IMAGE")
+    col = np.array([tex.evaluate((float(a), float(b), 0)).xyz for a, b in zip(u, v)])
+    col[(o["flags"] & 1) != 0] = 0.0
+    want = col.reshape(64, 64, 3)
+    assert (o["flags"] & 1).sum() > 50
+    assert np.abs(rect[..., 0:3] - want).max() < 1e-7 and np.all(rect[..., 3] == 1.0)
+    addon.unregister()
+
+
+def test_kerr_constants_of_motion_on_device_trajectories(ctx, oracle):
+    """E, L_z, Carter's Q and the null norm along curves the DEVICE integrated (bhg_trajectory samples), recomputed
+    from each sample's Cartesian state through the metric itself -- independent of the generated right-hand side."""
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorKerr
+    from oracle import scipy_reference as sr
+    M, a = 0.5, 0.45
+    gi = GeodesicIntegratorKerr(mass=M, a=a / M, rtol=1e-10, atol=1e-12, context=ctx)
+    cam = np.array([0.0, -25.0, 12.0])
+    rng = np.random.default_rng(12)
+    k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(24, 3)) * 0.1
+    k /= np.linalg.norm(k, axis=1)[:, None]
+
+    def carter(q, u, E, L):
+        Sig = q[0] ** 2 + a * a * np.cos(q[1]) ** 2
+        return (Sig * u[1]) ** 2 + np.cos(q[1]) ** 2 * (L * L / np.sin(q[1]) ** 2 - a * a * E * E)
+
+    escaped = 0
+    for i in range(len(k)):
+        k_xyz, x_xyz, res = gi.calc_trajectory(k[i], cam, curve_end=60.0, nr_points_curve=25)
+        if res["hit_blackhole"]:
+            continue
+        escaped += 1
+        q0, u0 = sr.cart_to_bl(cam, k[i], a)
+        E0, L0, _ = sr.kerr_constants(q0, u0, M, a)
+        Q0 = carter(q0, u0, E0, L0)
+        for j in range(1, x_xyz.shape[1]):
+            q, u = sr.cart_to_bl(x_xyz[:, j], k_xyz[:, j], a)
+            E, L, kt = sr.kerr_constants(q, u, M, a)          # null condition re-solved at the sample
+            assert abs(E - E0) < 1e-7 and abs(L - L0) < 1e-6 and abs(carter(q, u, E, L) - Q0) < 1e-5
+            gtt, gtp, grr, gthth, gpp = sr.kerr_metric(q[0], q[1], M, a)
+            norm = gtt * kt * kt + 2 * gtp * kt * u[2] + grr * u[0] ** 2 + gthth * u[1] ** 2 + gpp * u[2] ** 2
+            assert abs(norm) < 1e-9
+    assert escaped > 8
+
+
+def test_kerr_kernel_at_vanishing_spin_equals_schwarzschild_kernel(ctx):
+    """The Boyer-Lindquist kernel with a -> 0 against the (Cartesian, reduced-form) Schwarzschild kernel."""
+    rng = np.random.default_rng(13)
+    cam = np.array([3.0, -20.0, 14.0])
+    k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(3000, 3)) * 0.15
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    kw = dict(r_s=1.0, lambda_end=50.0, rtol=1e-11, atol=1e-13)
+    ea, fa, _, _ = ctx.trace(k, cam, _params(rhs_form=2, spin=1e-12, **kw))
+    eb, fb, _, _ = ctx.trace(k, cam, _params(rhs_form=1, **kw))
+    esc = (fa == 4) & (fb == 4)
+    assert esc.sum() > 2000 and (fa & 1).sum() > 30
+    # horizon flags: the BL event sits at r_plus (1 + 1e-3), a hair outside r_s -- the same rays are captured
+    assert np.array_equal(fa & 1, fb & 1)
+    assert np.abs(ea - eb)[esc].max() < 1e-6
