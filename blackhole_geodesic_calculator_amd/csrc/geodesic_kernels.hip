@@ -455,25 +455,41 @@ __device__ __forceinline__ double pow_0p2(double x)
 // than 64 + 63 + 64 = 191 rays: neither list can overflow its 192 slots.
 constexpr int EVQ_CAP = 192;
 
+// One queued ray: 12 doubles + 3 counters, laid out so that a lane moves it with seven 16-byte LDS accesses
+// (ds_read_b128 / ds_write_b128) instead of twenty-three 8- and 4-byte ones -- the pop runs in almost every iteration
+// of the step loop (some lane of the wave finishes a ray in nearly each one).
+template <int RHS>
+struct alignas(16) QEntry {
+    double2 d[6];   // {x0, x1} {x2, k0} {k1, k2} {a0, a1} {a2, |h| to try first} {r, lambda} at the start point
+    uint4 i;        // ray index, attempted steps, accepted steps, (drain: lane state bits)
+    double2 el[(RHS == BHG_RHS_KERR_BL_) ? 1 : 0];  // Kerr: the ray's Killing constants E, L
+};
+
 template <int RHS>
 struct WaveLds {
-    static constexpr int NK = (RHS == BHG_RHS_KERR_BL_) ? 64 : 1;
     // prepared rays (filled converged -- start records worked out in place or read from the prepare / resume
     // records -- and drained lane by lane); while the event drain runs, the lanes' own rays are kept here
-    double qx[3][64];
-    double qk[3][64];
-    double qa[3][64];  // FSAL acceleration at the start point
-    double qh[64];     // |h| to try first (initial step, common.py:68-134; or the controller's next step)
-    double qr[64];     // r at the start point
-    double qt[64];     // lambda at the start point (0 unless the ray is resumed)
-    double qE[NK], qL[NK];  // Kerr: the ray's Killing constants
-    uint32_t qidx[64];
-    uint32_t qnatt[64], qnacc[64];
+    QEntry<RHS> q[64];
     uint32_t ev_idx[EVQ_CAP];   // rays whose last accepted step (may have) crossed an event surface
     uint32_t res_idx[EVQ_CAP];  // rays whose parked step held no terminal event after all: they carry on
     uint8_t ev_kind[EVQ_CAP];   // EV_* bits of the parked step
-    uint8_t qflag[64];          // lane state kept across the event drain: bit 0 active, bit 1 rejected
 };
+
+template <int RHS>
+__device__ __forceinline__ void q_put(WaveLds<RHS> &Q, uint32_t s, const double x[3], const double k[3], const double a[3],
+                                      double h, double r, double t, double E, double Lz, uint32_t idx, uint32_t natt,
+                                      uint32_t nacc, uint32_t bits = 0u)
+{
+    QEntry<RHS> &e = Q.q[s];
+    e.d[0] = make_double2(x[0], x[1]);
+    e.d[1] = make_double2(x[2], k[0]);
+    e.d[2] = make_double2(k[1], k[2]);
+    e.d[3] = make_double2(a[0], a[1]);
+    e.d[4] = make_double2(a[2], h);
+    e.d[5] = make_double2(r, t);
+    e.i = make_uint4(idx, natt, nacc, bits);
+    if (RHS == BHG_RHS_KERR_BL_) e.el[0] = make_double2(E, Lz);
+}
 
 // Kinds of event a parked step may hold (bits of WaveLds::ev_kind; they never reach flags[]).
 constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
@@ -598,6 +614,35 @@ struct Lane {
     bool active, rejected;
 };
 
+template <int RHS>
+__device__ __forceinline__ uint32_t q_get(const WaveLds<RHS> &Q, uint32_t s, Lane &L)
+{
+    const QEntry<RHS> &e = Q.q[s];
+    const double2 d0 = e.d[0], d1 = e.d[1], d2 = e.d[2], d3 = e.d[3], d4 = e.d[4], d5 = e.d[5];
+    const uint4 i = e.i;
+    L.x[0] = d0.x;
+    L.x[1] = d0.y;
+    L.x[2] = d1.x;
+    L.v[0] = d1.y;
+    L.v[1] = d2.x;
+    L.v[2] = d2.y;
+    L.a1[0] = d3.x;
+    L.a1[1] = d3.y;
+    L.a1[2] = d4.x;
+    L.h_abs = d4.y;
+    L.r_cur = d5.x;
+    L.t = d5.y;
+    L.idx = i.x;
+    L.n_att = i.y;
+    L.n_acc = i.z;
+    if (RHS == BHG_RHS_KERR_BL_) {
+        const double2 el = e.el[0];
+        L.E = el.x;
+        L.Lz = el.y;
+    }
+    return i.w;
+}
+
 struct Wave {
     int q_head, q_count;
     int ev_count, res_count;     // entries of the parked-event list and of the resume list
@@ -606,7 +651,7 @@ struct Wave {
     bool have_pending;
     unsigned long long pending;  // in-flight work-counter fetch on `slice` (valid in lane 0)
 #ifdef BHG_DIAG
-    unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0;
+    unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0, diag_refill_cyc = 0;
 #endif
 };
 
@@ -796,22 +841,7 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, 
     const uint64_t vmask = __ballot(valid);
     if (valid) {
         const uint32_t s = lane_rank(vmask);
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            Q.qx[c][s] = px[c];
-            Q.qk[c][s] = pk[c];
-            Q.qa[c][s] = pa[c];
-        }
-        Q.qh[s] = ph;
-        Q.qr[s] = pr;
-        Q.qt[s] = 0.0;
-        if (RHS == BHG_RHS_KERR_BL_) {
-            Q.qE[s] = pE;
-            Q.qL[s] = pL;
-        }
-        Q.qidx[s] = (uint32_t)i;
-        Q.qnatt[s] = 0;
-        Q.qnacc[s] = 0;
+        q_put<RHS>(Q, s, px, pk, pa, ph, pr, 0.0, pE, pL, (uint32_t)i, 0u, 0u);
     }
     wave_lds_sync();
     W.q_head = 0;
@@ -853,24 +883,7 @@ __device__ __forceinline__ void fill_resumed(const TraceArgs &A, WaveLds<RHS> &Q
         nacc = A.n_accepted[i];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (see fill_batch)
-    if ((int)lane < take) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            Q.qx[c][lane] = px[c];
-            Q.qk[c][lane] = pk[c];
-            Q.qa[c][lane] = pa[c];
-        }
-        Q.qh[lane] = ph;
-        Q.qr[lane] = pr;
-        Q.qt[lane] = pt;
-        if (RHS == BHG_RHS_KERR_BL_) {
-            Q.qE[lane] = pE;
-            Q.qL[lane] = pL;
-        }
-        Q.qidx[lane] = i;
-        Q.qnatt[lane] = natt;
-        Q.qnacc[lane] = nacc;
-    }
+    if ((int)lane < take) q_put<RHS>(Q, lane, px, pk, pa, ph, pr, pt, pE, pL, i, natt, nacc);
     wave_lds_sync();
     W.res_count = base;
     W.q_head = 0;
@@ -1299,23 +1312,8 @@ __device__ __forceinline__ void push_events(WaveLds<RHS> &Q, Wave &W, uint32_t i
 template <int RHS, bool ADAPTIVE>
 __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        Q.qx[c][lane] = L.x[c];
-        Q.qk[c][lane] = L.v[c];
-        Q.qa[c][lane] = L.a1[c];
-    }
-    Q.qh[lane] = L.h_abs;
-    Q.qr[lane] = L.r_cur;
-    Q.qt[lane] = L.t;
-    if (RHS == BHG_RHS_KERR_BL_) {
-        Q.qE[lane] = L.E;
-        Q.qL[lane] = L.Lz;
-    }
-    Q.qidx[lane] = L.idx;
-    Q.qnatt[lane] = L.n_att;
-    Q.qnacc[lane] = L.n_acc;
-    Q.qflag[lane] = (uint8_t)((L.active ? 1u : 0u) | (L.rejected ? 2u : 0u));
+    q_put<RHS>(Q, lane, L.x, L.v, L.a1, L.h_abs, L.r_cur, L.t, L.E, L.Lz, L.idx, L.n_att, L.n_acc,
+               (L.active ? 1u : 0u) | (L.rejected ? 2u : 0u));
     wave_lds_sync();
 
     const int take = W.ev_count < 64 ? W.ev_count : 64;
@@ -1350,23 +1348,7 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
     W.res_count += __builtin_popcountll(rm);
     wave_lds_sync();
 
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        L.x[c] = Q.qx[c][lane];
-        L.v[c] = Q.qk[c][lane];
-        L.a1[c] = Q.qa[c][lane];
-    }
-    L.h_abs = Q.qh[lane];
-    L.r_cur = Q.qr[lane];
-    L.t = Q.qt[lane];
-    if (RHS == BHG_RHS_KERR_BL_) {
-        L.E = Q.qE[lane];
-        L.Lz = Q.qL[lane];
-    }
-    L.idx = Q.qidx[lane];
-    L.n_att = Q.qnatt[lane];
-    L.n_acc = Q.qnacc[lane];
-    const uint32_t fl = Q.qflag[lane];
+    const uint32_t fl = q_get<RHS>(Q, lane, L);
     L.active = (fl & 1u) != 0u;
     L.rejected = (fl & 2u) != 0u;
     wave_lds_sync();
@@ -1430,23 +1412,7 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
         if (!L.active) {
             const int rk = (int)lane_rank(idle);
             if (rk < take) {
-                const int s = W.q_head + rk;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    L.x[c] = Q.qx[c][s];
-                    L.v[c] = Q.qk[c][s];
-                    L.a1[c] = Q.qa[c][s];
-                }
-                L.h_abs = Q.qh[s];
-                L.r_cur = Q.qr[s];
-                L.idx = Q.qidx[s];
-                L.t = Q.qt[s];
-                if (RHS == BHG_RHS_KERR_BL_) {
-                    L.E = Q.qE[s];
-                    L.Lz = Q.qL[s];
-                }
-                L.n_att = Q.qnatt[s];
-                L.n_acc = Q.qnacc[s];
+                (void)q_get<RHS>(Q, (uint32_t)(W.q_head + rk), L);
                 L.rejected = false;
                 L.active = true;
             }
@@ -1512,7 +1478,13 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
+#ifdef BHG_DIAG
+            const unsigned long long rc0 = __builtin_amdgcn_s_memtime();
+#endif
             idle = refill<RHS, true>(A, Q, W, L, lane, idle);
+#ifdef BHG_DIAG
+            W.diag_refill_cyc += __builtin_amdgcn_s_memtime() - rc0;
+#endif
             if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
         }
 #ifdef BHG_DIAG
@@ -1624,7 +1596,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;
         d[5] = W.diag_drain_cyc;
         d[6] = W.diag_drained;
-        d[7] = W.diag_fill_cyc;
+        d[7] = W.diag_fill_cyc | (W.diag_refill_cyc << 32);  // fill cycles < 2^32; refill() total in the high half
     }
 #endif
 }

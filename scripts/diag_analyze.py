@@ -11,8 +11,13 @@ print("lifetime us: mean %.1f" % life.mean(), "iters/wave mean %.1f min %d max %
 print("lane utilisation %.4f" % (ln.sum() / (64.0 * it.sum())), "total lane-steps", ln.sum())
 print("shader clock GHz: mean %.3f" % np.mean(d[:, 4].astype(np.float64) / ((t1 - t0) * 10.0) / 1e3 * 1e3 / 1e3))
 print("us per iteration: %.3f" % (life.sum() / it.sum()))
+refill = (d[:, 7] >> np.uint64(32)).astype(np.float64)
+d = d.copy(); d[:, 7] &= np.uint64(0xFFFFFFFF)
 cyc = d[:, 4].astype(np.float64)
 print("share of wave cycles: event drain %.4f  batch fill (setup) %.4f" % (d[:, 5].sum() / cyc.sum(), d[:, 7].sum() / cyc.sum()))
 if d[:, 6].sum():
     print("events drained %d, cycles per drained event-wave (64 events) %.0f, per iteration %.0f" % (
         d[:, 6].sum(), d[:, 5].sum() / (d[:, 6].sum() / 64.0), (cyc.sum() - d[:, 5].sum() - d[:, 7].sum()) / it.sum()))
+if refill.sum():
+    other = refill.sum() - d[:, 5].sum() - d[:, 7].sum()
+    print("refill() calls without drain / batch fill (LDS pops, work fetch): %.4f of wave cycles = %.0f cycles per iteration" % (other / cyc.sum(), other / it.sum()))
