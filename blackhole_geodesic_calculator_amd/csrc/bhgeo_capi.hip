@@ -152,6 +152,31 @@ private:
     bool stop_ = false;
 };
 
+// Entry points make the context's device current for their own HIP calls and put the caller's current device back on
+// the way out: a host that created a context on device k while working on device j keeps working on j.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) {
+            (void)hipGetLastError();
+            prev = -1;
+        }
+        if (prev != dev) err = hipSetDevice(dev);
+        else prev = -1;  // nothing to restore
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ENTER_DEVICE(dev)         \
+    DeviceGuard _device_guard(dev); \
+    if (_device_guard.err != hipSuccess) return fail_hip(_device_guard.err, "hipSetDevice")
+
 }  // namespace
 
 struct bhg_context {
@@ -298,7 +323,7 @@ int bhg_create(int device, bhg_context **out)
     int n = bhg_device_count();
     if (n <= 0) return fail(BHG_E_NO_DEVICE, "no HIP device visible (libbhgeo has no CPU fallback)");
     if (device < 0 || device >= n) return fail(BHG_E_NO_DEVICE, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    ENTER_DEVICE(device);
     bhg_context *c = new (std::nothrow) bhg_context();
     if (!c) return fail(BHG_E_NOMEM, "host allocation failed");
     c->device = device;
@@ -328,7 +353,7 @@ int bhg_create(int device, bhg_context **out)
 void bhg_destroy(bhg_context *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -361,7 +386,7 @@ int bhg_num_cus(bhg_context *c) { return c ? c->num_cus : fail(BHG_E_INVALID, "c
 int bhg_synchronize(bhg_context *c)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BHG_OK;
 }
@@ -369,7 +394,7 @@ int bhg_synchronize(bhg_context *c)
 int bhg_set_profiling(bhg_context *c, int enable)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     if (enable && !c->ev[0])
         for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     c->profiling = enable != 0;
@@ -381,7 +406,7 @@ int bhg_last_pass_ms(bhg_context *c, float out_ms[3])
 {
     if (!c || !out_ms) return fail(BHG_E_INVALID, "bad argument");
     if (!c->ev_valid) return fail(BHG_E_INVALID, "no profiled trace call yet (bhg_set_profiling)");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     HIP_TRY(hipEventSynchronize(c->ev[2]));
     for (int i = 0; i < 2; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
     out_ms[2] = 0.0f;  // events are resolved inside the trace kernel: there is no separate pass any more
@@ -428,7 +453,7 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     if (!d_k0 || !d_end) return fail(BHG_E_INVALID, "k0 / end is NULL");
     if (!x0_shared && !d_x0) return fail(BHG_E_INVALID, "neither x0_shared nor d_x0 given");
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
 
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
@@ -611,7 +636,7 @@ struct PipeIO {
 // chunking: every ray is its own ODE.
 int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const PipeIO &io, size_t n)
 {
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     if (!c->s_in) {
         HIP_TRY(hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
@@ -782,7 +807,7 @@ int bhg_rays_create(bhg_context *c, const bhg_camera *cam, const double *jitter,
     if (jitter_is_compact && !jitter) return fail(BHG_E_INVALID, "compact jitter stream is NULL");
     const size_t n = n_pixels * (size_t)cam->samples;
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     bhg_rays *r = new (std::nothrow) bhg_rays();
     if (!r) return fail(BHG_E_NOMEM, "host allocation failed");
     r->ctx = c;
@@ -839,7 +864,7 @@ void bhg_rays_destroy(bhg_rays *r)
 {
     if (!r) return;
     if (r->d_k0) {
-        (void)hipSetDevice(r->ctx->device);
+        DeviceGuard guard(r->ctx->device);
         (void)hipFree(r->d_k0);
     }
     delete r;
@@ -875,7 +900,7 @@ int bhg_host_alloc(bhg_context *c, size_t bytes, void **out)
     if (!out) return fail(BHG_E_INVALID, "out is NULL");
     *out = nullptr;
     if (bytes == 0) return BHG_OK;
-    if (c) HIP_TRY(hipSetDevice(c->device));
+    DeviceGuard _device_guard(c ? c->device : 0);
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return BHG_OK;
 }
@@ -898,7 +923,7 @@ int bhg_raygen_device(bhg_context *c, int32_t width, int32_t height, int32_t sam
     if (!d_jitter || !d_k0) return fail(BHG_E_INVALID, "jitter / k0 is NULL");
     if (!d_pixels && n_pixels != (size_t)width * (size_t)height)
         return fail(BHG_E_INVALID, "n_pixels must be width*height when no pixel list is given");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     bhg::RaygenArgs a;
     std::memset(&a, 0, sizeof(a));
     a.jitter = d_jitter;
@@ -927,7 +952,7 @@ int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags
     if (samples <= 0 || sky_w <= 0 || sky_h <= 0) return fail(BHG_E_INVALID, "samples, sky_w, sky_h must be > 0");
     if (n_pixels == 0) return BHG_OK;
     if (!d_end || !d_flags || !d_sky || !d_rgba) return fail(BHG_E_INVALID, "NULL device pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     bhg::ShadeArgs a;
     std::memset(&a, 0, sizeof(a));
     a.end = d_end;
@@ -990,7 +1015,7 @@ int shade_scene_impl(bhg_context *c, const double *d_end, const uint8_t *d_flags
         if (!(sc->spheres[j][3] > 0.0)) return fail(BHG_E_INVALID, "sphere radii must be > 0");
     if (n_pixels == 0) return BHG_OK;
     if (!d_end || !d_flags || !sc->d_sky) return fail(BHG_E_INVALID, "NULL device pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     bhg::ShadeArgs a;
     std::memset(&a, 0, sizeof(a));
     a.end = d_end;
@@ -1032,7 +1057,7 @@ int bhg_assemble_frame_f32_device(bhg_context *c, const float *d_slabs, const in
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     if (n_pixels == 0) return BHG_OK;
     if (!d_slabs || !d_index || !d_frame) return fail(BHG_E_INVALID, "NULL device pointer");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     HIP_TRY(bhg::launch_gather_rows4(d_slabs, d_index, n_pixels, d_frame, (hipStream_t)stream));
     return BHG_OK;
 }
@@ -1049,7 +1074,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !traj || !n_valid) return fail(BHG_E_INVALID, "x0 / k0 / traj / n_valid is NULL");
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     const size_t in_bytes = n * 3 * sizeof(double) * (x0_is_shared ? 1 : 2);
     const size_t sz_traj = n * 6 * (size_t)n_points * sizeof(double);
     const size_t off_end = sz_traj, off_nv = off_end + n * 6 * sizeof(double), off_steps = off_nv + n * sizeof(uint32_t);
@@ -1117,7 +1142,7 @@ int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const
     if (rc != BHG_OK) return rc;
     if (n == 0) return BHG_OK;
     if (!x || !k || !acc) return fail(BHG_E_INVALID, "x / k / acc is NULL");
-    HIP_TRY(hipSetDevice(c->device));
+    ENTER_DEVICE(c->device);
     rc = ensure(&c->d_in, &c->d_in_bytes, n * 6 * sizeof(double));
     if (rc != BHG_OK) return rc;
     rc = ensure(&c->d_out, &c->d_out_bytes, n * 3 * sizeof(double));

@@ -194,8 +194,13 @@ struct Metric {
 // Kerr in Boyer-Lindquist coordinates: x = (r, theta, phi), k = d/dlambda of those.  The body is
 // sin and cos of one angle together: Cody-Waite reduction by pi/2 in three parts (exact with FMA for the
 // |th| < ~1e5 a polar angle can reach), then the classic degree-13 / degree-14 minimax kernels on
-// [-pi/4, pi/4] (the coefficients every libm carries), quadrant fix-up by selects.  About 1 ulp; ~35
-// instructions for both values, against two separate library calls with their large-argument paths.
+// [-pi/4, pi/4], quadrant fix-up by selects.  About 1 ulp; ~35 instructions for both values, against two
+// separate library calls with their large-argument paths.
+//
+// Attribution: the polynomial coefficients S1..S6 / C1..C6 below are those of FreeBSD msun / fdlibm's k_sin.c and
+// k_cos.c: "Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.  Developed at SunPro, a Sun
+// Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this software is freely granted,
+// provided that this notice is preserved."
 __device__ __forceinline__ void sincos_pi4(double x, double &s, double &c)
 {
     const double kf = __builtin_rint(x * 0.63661977236758134308);  // 2/pi
@@ -369,7 +374,14 @@ __device__ __forceinline__ double dense_g(const Dense &d, double t, double R, bo
 }
 
 // Brent's method on g(t) = r(t) - R over [ta, tb], xtol = rtol = 4 eps (ivp.py:51-76).
-// Rare and divergent: runs once per ray that ends on the horizon or on the exit sphere.
+//
+// Attribution: this function follows SciPy's brentq step for step (scipy/optimize/Zeros/brentq.c, "Written by
+// Charles Harris charles.harris@sdl.usu.edu", part of SciPy, Copyright (c) 2001-2002 Enthought, Inc.,
+// 2003- SciPy Developers, BSD 3-Clause License), including its variable names, so that the located root -- and with
+// it every event state this library returns -- is the iterate scipy.integrate.solve_ivp itself would return.
+// Redistribution of that algorithm's expression here is under the BSD 3-Clause terms; SciPy's licence text:
+// https://github.com/scipy/scipy/blob/main/LICENSE.txt
+// Runs converged in the event drain, once per parked step and candidate event.
 template <class F>
 __device__ __forceinline__ double brent_root(const F &g, double xa, double xb)
 {

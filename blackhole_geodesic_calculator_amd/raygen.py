@@ -42,6 +42,25 @@ def euler_xyz_matrix(euler) -> np.ndarray:
     return rz @ ry @ rx
 
 
+def _directions(width, height, samples, px, py, u, fov_x, fov_y, rotation_euler):
+    """The formula of :224-230 for pixels (px, py) with jitter u[S, ..., 2]: the one place it is written down."""
+    W, H = int(width), int(height)
+    aspect = H / W
+    dy = aspect / H
+    dx = 1 / W
+    x_render = fov_x * (px - int(W / 2)) / W
+    y_render = fov_y * (py - int(H / 2)) / H * aspect
+    d = np.empty(u.shape[:-1] + (3,), dtype=np.float64)
+    d[..., 0] = x_render + dx * (u[..., 0] - 0.5)
+    d[..., 1] = y_render + dy * (u[..., 1] - 0.5)
+    d[..., 2] = -1.0
+    rot = euler_xyz_matrix(rotation_euler)
+    if not np.array_equal(rot, np.eye(3)):
+        d = d @ rot.T
+    nrm = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
+    return d / nrm[..., None]
+
+
 def camera_directions(width, height, samples, fov_x=1.0, fov_y=1.0, seed=42.0,
                       rotation_euler=(0.0, 0.0, 0.0), mark=None, stream=None) -> np.ndarray:
     """Unit ray directions [S, H, W, 3] (float64); NaN for pixels outside the mark window.
@@ -51,30 +70,16 @@ def camera_directions(width, height, samples, fov_x=1.0, fov_y=1.0, seed=42.0,
     same seed on every render(), :189, so every frame of a static camera draws the same rays).
     """
     W, H, S = int(width), int(height), int(samples)
-    aspect = H / W
-    dy = aspect / H
-    dx = 1 / W
     y_min, y_max, x_min, x_max = mark if mark is not None else (0, H, 0, W)
     ys = np.arange(H)
     xs = np.arange(W)
     row_in = (ys >= y_min) & (ys <= y_max)
     col_in = (xs >= x_min) & (xs <= x_max)
-    n_draw_px = int(row_in.sum()) * int(col_in.sum())
+    R, Cn = int(row_in.sum()), int(col_in.sum())
     if stream is None:
-        stream = python_random_stream(seed, 2 * S * n_draw_px)
-    u = np.asarray(stream, dtype=np.float64)[: 2 * S * n_draw_px].reshape(S, int(row_in.sum()), int(col_in.sum()), 2)
-
-    x_render = fov_x * (xs[col_in] - int(W / 2)) / W
-    y_render = fov_y * (ys[row_in] - int(H / 2)) / H * aspect
-    d = np.empty((S, int(row_in.sum()), int(col_in.sum()), 3), dtype=np.float64)
-    d[..., 0] = x_render[None, None, :] + dx * (u[..., 0] - 0.5)
-    d[..., 1] = y_render[None, :, None] + dy * (u[..., 1] - 0.5)
-    d[..., 2] = -1.0
-    rot = euler_xyz_matrix(rotation_euler)
-    if not np.array_equal(rot, np.eye(3)):
-        d = d @ rot.T
-    nrm = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
-    d = d / nrm[..., None]
+        stream = python_random_stream(seed, 2 * S * R * Cn)
+    u = np.asarray(stream, dtype=np.float64)[: 2 * S * R * Cn].reshape(S, R, Cn, 2)
+    d = _directions(W, H, S, xs[col_in][None, None, :], ys[row_in][None, :, None], u, fov_x, fov_y, rotation_euler)
     if mark is None:
         return d
     out = np.full((S, H, W, 3), np.nan)
@@ -88,21 +93,8 @@ def camera_directions_for_pixels(width, height, samples, pixels, fov_x=1.0, fov_
     stream: what one GPU's tile shard needs.  Bit-identical to camera_directions()[s, y, x]."""
     W, H, S = int(width), int(height), int(samples)
     pixels = np.asarray(pixels, dtype=np.int64)
-    aspect = H / W
-    dy = aspect / H
-    dx = 1 / W
     if stream is None:
         stream = python_random_stream(seed, 2 * S * W * H)
     u = np.asarray(stream, dtype=np.float64)[: 2 * S * W * H].reshape(S, H * W, 2)[:, pixels, :]
     py, px = np.divmod(pixels, W)
-    x_render = fov_x * (px - int(W / 2)) / W
-    y_render = fov_y * (py - int(H / 2)) / H * aspect
-    d = np.empty((S, len(pixels), 3), dtype=np.float64)
-    d[..., 0] = x_render[None, :] + dx * (u[..., 0] - 0.5)
-    d[..., 1] = y_render[None, :] + dy * (u[..., 1] - 0.5)
-    d[..., 2] = -1.0
-    rot = euler_xyz_matrix(rotation_euler)
-    if not np.array_equal(rot, np.eye(3)):
-        d = d @ rot.T
-    nrm = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
-    return d / nrm[..., None]
+    return _directions(W, H, S, px[None, :], py[None, :], u, fov_x, fov_y, rotation_euler)

@@ -117,7 +117,9 @@ void bhg_default_params(bhg_params *p); /* engine defaults: r_s=1 (mass 0.5), la
                                            max_step=inf, rtol=1e-3, atol=1e-6, DP54, Christoffel
                                            (RelativisticRenderEngine.py:506-508; scipy rk.py:85-87) */
 
-/* --- context ---------------------------------------------------------------------------- */
+/* --- context ----------------------------------------------------------------------------
+ * Every entry point makes the context's device current for its own HIP calls and restores the calling
+ * thread's current device before it returns. */
 int bhg_create(int device, bhg_context **out); /* replaces the per-frame solver construction (:134) */
 void bhg_destroy(bhg_context *ctx);
 int bhg_device_name(bhg_context *ctx, char *buf, size_t buflen);

@@ -369,7 +369,11 @@ static double ev_eval(const evfun_t *e, double t)
     return radius(e->rc, y) - e->R;
 }
 
-/* Brent's method as scipy.optimize.brentq runs it (xtol = rtol = 4 eps, ivp.py:74-75) */
+/* Brent's method as scipy.optimize.brentq runs it (xtol = rtol = 4 eps, ivp.py:74-75).
+ * Attribution: a restatement of SciPy's scipy/optimize/Zeros/brentq.c ("Written by Charles Harris
+ * charles.harris@sdl.usu.edu"; SciPy, Copyright (c) 2001-2002 Enthought, Inc., 2003- SciPy Developers, BSD 3-Clause
+ * License, https://github.com/scipy/scipy/blob/main/LICENSE.txt), kept step for step -- variable names included --
+ * because the checker has to return the very iterate solve_ivp returns. */
 static double brentq(const evfun_t *e, double xa, double xb)
 {
     const double xtol = 4 * DBL_EPSILON, rtol = 4 * DBL_EPSILON;
