@@ -200,6 +200,12 @@ class FrameBatch:
             f.generate_rays()
 
     def trace(self, params: _ffi.Params):
+        # work-order hint: the rays are (cameras x samples) equal blocks of P rays, each block's pixels in the same
+        # (usually longest-first) order: lets the library start the expensive regions of ALL frames first
+        nb = len(self.frames) * self.frames[0].S
+        if params.order_blocks == 0 and nb > 1:
+            params = _copy_params(params)
+            params.order_blocks = nb
         self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), d_x0=self.d_x0.data_ptr(),
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
                               d_n_accepted=self.d_acc.data_ptr(),
