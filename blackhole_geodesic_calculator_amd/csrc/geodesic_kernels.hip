@@ -1453,8 +1453,15 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
 #ifndef BHG_KERR_WAVES_PER_SIMD
 #define BHG_KERR_WAVES_PER_SIMD 2
 #endif
+// Variants with optional events (exit sphere, disk, objects) run the event drain for (nearly) every ray: at 4 waves per
+// SIMD (128 VGPRs) the drain spills ~60 doubles per lane and drain to scratch and the launch moves 4 GB through the L2
+// fabric (config 3); at 3 waves (168 VGPRs) it does not -- measured +3.5 % (config 3), +2.2 % (config 4) -- while
+// the event-free variant loses 0.8 % at 3.
+#ifndef BHG_DP54_EVT_WAVES_PER_SIMD
+#define BHG_DP54_EVT_WAVES_PER_SIMD 3
+#endif
 template <int RHS, int EVT>
-__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A)
+__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : (EVT ? BHG_DP54_EVT_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD))) trace_dp54_kernel(const TraceArgs A)
 {
     __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
