@@ -1047,7 +1047,7 @@ __device__ __forceinline__ double dp54_factor(double errsq)
 // R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424); an object sphere when the curve enters
 // it (the reference's collision stub, RelativisticRenderEngine.py:304-305).
 // g_r(t, R) = r(t) - R, g_z(t) = z(t), pos(t, x) / eval(t, x, v) = interpolated state.  Returns true if the ray ended.
-template <class GR, class GZ, class POS, class EV>
+template <int EVT, class GR, class GZ, class POS, class EV>
 __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind, uint32_t idx, double t, double t_new,
                                               const double x0[3], const double x1[3], const GR &g_r, const GZ &g_z,
                                               const POS &pos, const EV &eval, bool bl)
@@ -1062,14 +1062,15 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
             fl = BHG_FLAG_HIT_HORIZON_;
         }
     }
-    if (kind & EV_EXIT) {
+    // (event kinds the kernel variant was not compiled for cannot be set: the tests fold away)
+    if ((EVT & EVT_EXIT) && (kind & EV_EXIT)) {
         const double r = brent_root([&](double tt) { return g_r(tt, A.r_exit); }, t, t_new);
         if (r < best) {
             best = r;
             fl = BHG_FLAG_EXITED_SPHERE_;
         }
     }
-    if (kind & EV_DISK) {
+    if ((EVT & EVT_DISK) && (kind & EV_DISK)) {
         const double r = brent_root([&](double tt) { return g_z(tt); }, t, t_new);
         double xe[3];
         pos(r, xe);
@@ -1080,7 +1081,7 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
             fl = BHG_FLAG_HIT_DISK_;
         }
     }
-    if (kind & EV_OBJ) {
+    if ((EVT & EVT_OBJ) && (kind & EV_OBJ)) {
         for (int j = 0; j < A.n_spheres; j++) {
             const double *sp = A.spheres[j];
             double bb, cc;
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ bool finish_or_resume(const TraceArgs &A, uint32_t id
 
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
-template <int RHS>
+template <int RHS, int EVT>
 __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                    const double a1[3], double t, double t_new, double h,
                                                    double h_next, uint32_t kind, uint32_t idx, const Metric &m)
@@ -1163,7 +1164,7 @@ __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const dou
             d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
         }
     }
-    const bool ended = settle_events(
+    const bool ended = settle_events<EVT>(
         A, kind, idx, t, t_new, x, xn, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
             if (RHS != BHG_RHS_KERR_BL_) return dense_z(d, tt);
@@ -1177,6 +1178,7 @@ __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const dou
             dense_dir(d, tt, ve);
         },
         RHS == BHG_RHS_KERR_BL_);
+    if (!(EVT & (EVT_DISK | EVT_OBJ))) return false;  // horizon / exit crossings always end the ray: nothing to resume
     return ended ? false : finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
 }
 
@@ -1241,7 +1243,7 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
     return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) - R;
 }
 
-template <int RHS>
+template <int RHS, int EVT>
 __device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
                                                   const double a1[3], double t, double t_new, double h,
                                                   double h_next, uint32_t kind, uint32_t idx, const Metric &m)
@@ -1257,7 +1259,7 @@ __device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const doub
         d.v0[c] = v[c];
         d.a0[c] = a1[c];
     }
-    const bool ended = settle_events(
+    const bool ended = settle_events<EVT>(
         A, kind, idx, t, t_new, x, d.x1, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
             double xx[3], vv[3];
@@ -1269,6 +1271,7 @@ __device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const doub
             hermite_eval(d, tt, xe, vv);
         },
         [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); }, RHS == BHG_RHS_KERR_BL_);
+    if (!(EVT & (EVT_DISK | EVT_OBJ))) return false;
     return ended ? false : finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
 }
 
@@ -1321,7 +1324,7 @@ __device__ __forceinline__ void push_events(WaveLds<RHS> &Q, Wave &W, uint32_t i
 // lanes' own rays wait in the queue's storage meanwhile, so the drain has the whole register budget and the
 // root search always runs (nearly) 64 lanes wide -- never one lane wide inside the step loop.
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool ADAPTIVE>
+template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     q_put<RHS>(Q, lane, L.x, L.v, L.a1, L.h_abs, L.r_cur, L.t, L.E, L.Lz, L.idx, L.n_att, L.n_acc,
@@ -1350,9 +1353,9 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
             met.L = w[7];
         }
         if (ADAPTIVE)
-            resumed = dp54_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+            resumed = dp54_resolve_event<RHS, EVT>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
         else
-            resumed = rk4_resolve_event<RHS>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+            resumed = rk4_resolve_event<RHS, EVT>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
     }
     const uint64_t rm = __ballot(resumed);
     if (resumed) Q.res_idx[(uint32_t)W.res_count + lane_rank(rm)] = i;
@@ -1368,7 +1371,7 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
 
 // Give idle lanes new rays.  Returns the idle mask afterwards (all ones: the wave is done -- nothing in flight,
 // queued, parked or waiting to resume, and no batch left to claim).
-template <int RHS, bool ADAPTIVE>
+template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane,
                                            uint64_t idle)
 {
@@ -1381,7 +1384,7 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
                 const unsigned long long c0 = __builtin_amdgcn_s_memtime();
                 W.diag_drained += (unsigned long long)(W.ev_count < 64 ? W.ev_count : 64);
 #endif
-                drain_events<RHS, ADAPTIVE>(A, Q, W, L, lane);
+                drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
 #ifdef BHG_DIAG
                 W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
 #endif
@@ -1447,21 +1450,20 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
 // ------------------------------------------------------------------------------------------
 // Adaptive Dormand-Prince 5(4), scipy RK45 controller semantics, persistent lane-refill wave.
 // ------------------------------------------------------------------------------------------
+// Waves per SIMD of the DP5(4) kernels.  Schwarzschild forms: 3 (168 VGPRs).  The step loop alone fits 4 waves
+// (~120 VGPRs), but the event drain inlined next to it does not: at the 128-VGPR cap it spills ~60 doubles per lane and
+// drain to scratch, which shows up as HBM traffic (config 2: 646 MB per launch against 425 MB algorithmic; config 3:
+// 4.0 GB) and, for the variants that drain (nearly) every ray, as time (config 3 +3.5 %, config 4 +2.2 % at 3 waves);
+// the event-free frame measures the same at 3 and at 4 waves (1.429 vs 1.423 ms) with 498 MB of traffic.  2 waves
+// measured 8 % slower.  Kerr: 2 (its right-hand side alone needs ~200 VGPRs).
 #ifndef BHG_DP54_WAVES_PER_SIMD
-#define BHG_DP54_WAVES_PER_SIMD 4
+#define BHG_DP54_WAVES_PER_SIMD 3
 #endif
 #ifndef BHG_KERR_WAVES_PER_SIMD
 #define BHG_KERR_WAVES_PER_SIMD 2
 #endif
-// Variants with optional events (exit sphere, disk, objects) run the event drain for (nearly) every ray: at 4 waves per
-// SIMD (128 VGPRs) the drain spills ~60 doubles per lane and drain to scratch and the launch moves 4 GB through the L2
-// fabric (config 3); at 3 waves (168 VGPRs) it does not -- measured +3.5 % (config 3), +2.2 % (config 4) -- while
-// the event-free variant loses 0.8 % at 3.
-#ifndef BHG_DP54_EVT_WAVES_PER_SIMD
-#define BHG_DP54_EVT_WAVES_PER_SIMD 3
-#endif
 template <int RHS, int EVT>
-__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : (EVT ? BHG_DP54_EVT_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD))) trace_dp54_kernel(const TraceArgs A)
+__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A)
 {
     __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
@@ -1500,7 +1502,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 #ifdef BHG_DIAG
             const unsigned long long rc0 = __builtin_amdgcn_s_memtime();
 #endif
-            idle = refill<RHS, true>(A, Q, W, L, lane, idle);
+            idle = refill<RHS, true, EVT>(A, Q, W, L, lane, idle);
 #ifdef BHG_DIAG
             W.diag_refill_cyc += __builtin_amdgcn_s_memtime() - rc0;
 #endif
@@ -1654,7 +1656,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     for (;;) {
         uint64_t idle = __ballot(!L.active);
         if (idle) {
-            idle = refill<RHS, false>(A, Q, W, L, lane, idle);
+            idle = refill<RHS, false, EVT>(A, Q, W, L, lane, idle);
             if (idle == ~0ull) break;
         }
         uint32_t parked = 0;
