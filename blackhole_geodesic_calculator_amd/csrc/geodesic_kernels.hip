@@ -17,16 +17,17 @@
 //     filled 64 rays at a time by ALL lanes together (coalesced k0 loads, the scipy initial-step
 //     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
 //     always runs converged and the integrate loop always runs (nearly) full;
-//   * passes of one call, all on one stream: TRACE (persistent lane-refill waves, the hot loop, ~120 VGPRs =
-//     4 waves per SIMD; for the Schwarzschild forms the waves also work out each batch's start records --
-//     f0, r0, scipy's initial step -- while they fill their queue) -> RESOLVE (rays whose last step crossed
-//     or may have crossed an event surface: recompute that step, quartic dense output, Brent roots, earliest
-//     terminal root wins; a step that holds none after all hands its ray to another TRACE + RESOLVE pass over
-//     a worklist).  Kerr runs a PREPARE pass first (Cartesian -> Boyer-Lindquist, E, L) and a finalize pass
-//     last.  Keeping the root search out of the hot kernel halves its register footprint (248 -> ~120 VGPRs);
-//   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord touches an
-//     object sphere, parks the step's start state in its own output slots and refills at once, so the root
-//     search never runs one lane wide;
+//   * ONE launch per trace call takes every ray to its end (~120 VGPRs in the step loop; the kernels run at 3 waves per
+//     SIMD so that the event drain next to it does not spill).  For the Schwarzschild forms the waves also work out
+//     each batch's start records -- f0, r0, scipy's initial step -- while they fill their queue; Kerr runs a PREPARE
+//     pass first (Cartesian -> Boyer-Lindquist, E, L) and a finalize pass last;
+//   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord touches an object
+//     sphere, parks the step's start state in its own output slots, puts its ray on the wave's parked-event list and
+//     refills at once, so the root search never runs one lane wide.  When the ray queue is empty and 64 steps are
+//     parked the wave DRAINS them converged: recompute the step (bit-identical stages), quartic dense output, Brent
+//     roots, earliest terminal root wins; a step that holds no terminal event after all puts its ray on the wave's
+//     resume list, from which the queue is refilled before any new batch is claimed.  Park and resume records are
+//     written and read back by the same wavefront: no second pass, no host round trip;
 //   * work is handed out in 64-ray batches from eight sliced device counters (a wave starts on the slice of its
 //     XCD and steals from the others), each batch claimed just before the queue runs out;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
