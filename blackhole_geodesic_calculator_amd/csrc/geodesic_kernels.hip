@@ -29,7 +29,7 @@
 //     resume list, from which the queue is refilled before any new batch is claimed.  Park and resume records are
 //     written and read back by the same wavefront: no second pass, no host round trip;
 //   * work is handed out in 64-ray batches from eight sliced device counters (a wave starts on the slice of its
-//     XCD and steals from the others), each batch claimed just before the queue runs out;
+//     XCD and steals from the others), each batch claimed when the queue has run out;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
 //     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
 //     element-wise ODE, not a contraction.
@@ -313,7 +313,7 @@ __device__ __forceinline__ double ulp_of(double t)
 
 // Cross-lane hand-off through LDS inside ONE wavefront: DS operations of a wave execute in
 // program order, so only the compiler needs fencing.  (A workgroup-scope __syncthreads() would
-// also drain vmcnt and stall on the in-flight result stores and the prefetched work counter.)
+// also drain vmcnt and stall on the in-flight result stores.)
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -624,7 +624,9 @@ struct Lane {
     double t, h_abs, r_cur;
     double E, Lz;  // Kerr only
     uint32_t idx, n_att, n_acc;
-    bool active, rejected;
+    // 0 / 1, as full words: a bool is kept as a byte and compared through SDWA against a zero held in a VGPR for the
+    // life of the kernel -- a register the allocator then spills around the event drain and reloads in the loop
+    uint32_t active, rejected;
 };
 
 template <int RHS>
@@ -661,8 +663,6 @@ struct Wave {
     int ev_count, res_count;     // entries of the parked-event list and of the resume list
     bool exhausted;
     uint32_t slice, dry;         // current slice, number of slices found dry so far
-    bool have_pending;
-    unsigned long long pending;  // in-flight work-counter fetch on `slice` (valid in lane 0)
 #ifdef BHG_DIAG
     unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0, diag_refill_cyc = 0;
 #endif
@@ -1329,7 +1329,7 @@ template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     q_put<RHS>(Q, lane, L.x, L.v, L.a1, L.h_abs, L.r_cur, L.t, L.E, L.Lz, L.idx, L.n_att, L.n_acc,
-               (L.active ? 1u : 0u) | (L.rejected ? 2u : 0u));
+               L.active | (L.rejected << 1));
     wave_lds_sync();
 
     const int take = W.ev_count < 64 ? W.ev_count : 64;
@@ -1365,8 +1365,8 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
     wave_lds_sync();
 
     const uint32_t fl = q_get<RHS>(Q, lane, L);
-    L.active = (fl & 1u) != 0u;
-    L.rejected = (fl & 2u) != 0u;
+    L.active = fl & 1u;
+    L.rejected = (fl >> 1) & 1u;
     wave_lds_sync();
 }
 
@@ -1394,9 +1394,10 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
                 fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
             } else {
                 if (W.exhausted) break;
-                if (!W.have_pending) W.pending = issue_fetch(A, lane, W.slice);
-                W.have_pending = false;
-                const uint64_t base = take_fetch(W.pending, W.slice);
+                // (No prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries,
+                // and the s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's
+                // result stores -- measured: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
+                const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
                 if (base >= A.n) {
                     // this slice is dry: steal from the next one
                     W.slice = (W.slice + 1) % NSLICE;
@@ -1429,8 +1430,8 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
             const int rk = (int)lane_rank(idle);
             if (rk < take) {
                 (void)q_get<RHS>(Q, (uint32_t)(W.q_head + rk), L);
-                L.rejected = false;
-                L.active = true;
+                L.rejected = 0u;
+                L.active = 1u;
             }
         }
         wave_lds_sync();
@@ -1438,12 +1439,6 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
         W.q_count -= take;
         idle = __ballot(!L.active);
         if (!idle) break;
-    }
-    // claim the next batch just before it is needed: the fetch is in flight while the last few
-    // queued rays are handed out, and no wave sits on unstarted batches at the end of the kernel
-    if (!W.have_pending && !W.exhausted && W.q_count <= 8 && W.res_count == 0) {
-        W.pending = issue_fetch(A, lane, W.slice);
-        W.have_pending = true;
     }
     return idle;
 }
@@ -1482,7 +1477,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     L.t = L.h_abs = L.r_cur = 0.0;
     L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
-    L.active = L.rejected = false;
+    L.active = L.rejected = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
     W.ev_count = W.res_count = 0;
@@ -1494,8 +1489,6 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 #endif
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
-    W.have_pending = false;
-    W.pending = 0;
 
     for (;;) {
         uint64_t idle = __ballot(!L.active);
@@ -1534,7 +1527,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             if (term == 0 && L.t == t_bound) term = BHG_FLAG_REACHED_END_;  // base.py:189-194
             if (term) {
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
-                L.active = false;
+                L.active = 0u;
             } else {
                 double t_new = L.t + L.h_abs;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
@@ -1568,7 +1561,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
                     if (L.rejected) fac = fmin(1.0, fac);
                     L.h_abs *= fac;
-                    L.rejected = false;
+                    L.rejected = 0u;
                     L.n_acc++;
 
                     // events between step ends (ivp.py:109-126): horizon any direction, exit outward
@@ -1586,10 +1579,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                         // x, v, a1, t still hold the step's start: the event drain recomputes it
                         park_event(A, L, h, t_new);
                         parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
-                        L.active = false;
+                        L.active = 0u;
                     } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
                         store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
-                        L.active = false;
+                        L.active = 0u;
                     } else {
                         L.t = t_new;
                         L.r_cur = r_new;
@@ -1602,7 +1595,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     }
                 } else {
                     L.h_abs *= fmax(0.2, fac);
-                    L.rejected = true;
+                    L.rejected = 1u;
                 }
             }
         }
@@ -1644,15 +1637,13 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     L.t = L.h_abs = L.r_cur = 0.0;
     L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
-    L.active = L.rejected = false;
+    L.active = L.rejected = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
     W.ev_count = W.res_count = 0;
     W.exhausted = false;
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
-    W.have_pending = false;
-    W.pending = 0;
 
     for (;;) {
         uint64_t idle = __ballot(!L.active);
@@ -1669,7 +1660,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 term = BHG_FLAG_MAX_STEPS_;
             if (term) {
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_att);
-                L.active = false;
+                L.active = 0u;
             } else {
                 double t_new = L.t + hf;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
@@ -1695,10 +1686,10 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                     L.h_abs = hf;
                     park_event(A, L, h, t_new);
                     parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
-                    L.active = false;
+                    L.active = 0u;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
-                    L.active = false;
+                    L.active = 0u;
                 } else {
                     L.t = t_new;
                     L.r_cur = r_new;
