@@ -1370,60 +1370,72 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
     wave_lds_sync();
 }
 
-// Give idle lanes new rays.  Returns the idle mask afterwards (all ones: the wave is done -- nothing in flight,
-// queued, parked or waiting to resume, and no batch left to claim).
+// The ray queue is empty: work off parked events, then put rays into the queue -- resumed ones first, else a new batch.
+// Leaves the queue empty only if there is nothing to hand out right now (no batch left, nothing to resume; parked
+// events may still wait for the last active lanes).  The rare part of refill(), kept apart from the pop so that the
+// lanes' state is only touched here by the drain's save / restore (the step loop's common path then carries no
+// register copies for it).
+template <int RHS, bool ADAPTIVE, int EVT>
+__device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, uint64_t idle)
+{
+    for (;;) {
+        // The queue's storage is free: the moment to work off parked events 64 lanes wide -- whenever 64 have
+        // piled up, or, at the very end (no batch left, nothing to resume, every lane idle), whatever is left.
+        while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull)) {
+#ifdef BHG_DIAG
+            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+            W.diag_drained += (unsigned long long)(W.ev_count < 64 ? W.ev_count : 64);
+#endif
+            drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
+#ifdef BHG_DIAG
+            W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
+#endif
+        }
+        if (W.res_count > 0) {
+            fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
+            return;
+        }
+        if (W.exhausted) return;
+        // (No prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries,
+        // and the s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's
+        // result stores -- measured: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
+        const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
+        if (base >= A.n) {
+            // this slice is dry: steal from the next one
+            W.slice = (W.slice + 1) % NSLICE;
+            if (++W.dry == NSLICE) W.exhausted = true;
+            continue;
+        }
+        uint64_t first = base;
+        if (A.order_blocks > 1) {
+            // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
+            // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
+            // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
+            // the caller's pixels sorted longest-first the long rays then all start early, instead of once
+            // per block through the whole launch.  A pure permutation of the batch order.
+            const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
+            first = sblk * A.order_block_len + (q << 6);
+        }
+#ifdef BHG_DIAG
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
+        fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
+#ifdef BHG_DIAG
+        W.diag_fill_cyc += __builtin_amdgcn_s_memtime() - c0;
+#endif
+        if (W.q_count > 0) return;
+    }
+}
+
+// Give idle lanes new rays: at most one replenishment of the queue and one pop per call (lanes the queue could not
+// serve are served by the next iteration's call).  Returns the idle mask afterwards (all ones: the wave is done --
+// nothing in flight, queued, parked or waiting to resume, and no batch left to claim).
 template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane,
                                            uint64_t idle)
 {
-    for (;;) {
-        if (W.q_count == 0) {
-            // The queue's storage is free: the moment to work off parked events 64 lanes wide -- whenever 64 have
-            // piled up, or, at the very end (no batch left, nothing to resume, every lane idle), whatever is left.
-            while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull)) {
-#ifdef BHG_DIAG
-                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-                W.diag_drained += (unsigned long long)(W.ev_count < 64 ? W.ev_count : 64);
-#endif
-                drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
-#ifdef BHG_DIAG
-                W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
-#endif
-            }
-            if (W.res_count > 0) {
-                fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
-            } else {
-                if (W.exhausted) break;
-                // (No prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries,
-                // and the s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's
-                // result stores -- measured: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
-                const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
-                if (base >= A.n) {
-                    // this slice is dry: steal from the next one
-                    W.slice = (W.slice + 1) % NSLICE;
-                    if (++W.dry == NSLICE) W.exhausted = true;
-                    continue;
-                }
-                uint64_t first = base;
-                if (A.order_blocks > 1) {
-                    // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
-                    // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
-                    // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
-                    // the caller's pixels sorted longest-first the long rays then all start early, instead of once
-                    // per block through the whole launch.  A pure permutation of the batch order.
-                    const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
-                    first = sblk * A.order_block_len + (q << 6);
-                }
-#ifdef BHG_DIAG
-                const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
-                fill_batch<RHS, ADAPTIVE>(A, Q, W, lane, first);
-#ifdef BHG_DIAG
-                W.diag_fill_cyc += __builtin_amdgcn_s_memtime() - c0;
-#endif
-                if (W.q_count == 0) continue;
-            }
-        }
+    if (W.q_count == 0) replenish<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane, idle);
+    if (W.q_count > 0) {
         const int n_idle = __builtin_popcountll(idle);
         const int take = n_idle < W.q_count ? n_idle : W.q_count;
         if (!L.active) {
@@ -1438,7 +1450,6 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
         W.q_head += take;
         W.q_count -= take;
         idle = __ballot(!L.active);
-        if (!idle) break;
     }
     return idle;
 }
