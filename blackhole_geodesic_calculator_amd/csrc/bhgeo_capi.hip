@@ -459,16 +459,13 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
     //   ws      [n][8] doubles  per-ray records (Kerr prepare records; parked steps and resume records of the trace kernel)
     //   flags   [n] bytes       when the caller does not want flags
-    //   n_steps / n_accepted [n] u32 when not wanted but a ray can be resumed (its counts then travel with its record)
+    //   n_steps / n_accepted [n] u32 when the caller does not want them (the kernels never test these pointers)
     const bool has_exit = p->r_exit > 0.0;
-    // "can_resume": a disk-plane crossing outside the annulus and a chord through an object sphere that the curve
-    // itself misses both send the ray back into the step loop
-    const bool can_resume = p->disk_r_out > 0.0 || n_spheres > 0;
     const size_t sz_ws = n * 8 * sizeof(double);
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
-    const size_t sz_steps = (can_resume && !d_n_steps) ? sz_u32 : 0;
-    const size_t sz_acc = (can_resume && !d_n_accepted) ? sz_u32 : 0;
+    const size_t sz_steps = !d_n_steps ? sz_u32 : 0;
+    const size_t sz_acc = !d_n_accepted ? sz_u32 : 0;
     rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + 64);
     if (rc != BHG_OK) return rc;
     char *wsb = (char *)c->d_ws;
@@ -483,8 +480,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.end = d_end;
     a.ws = (double *)c->d_ws;
     a.flags = d_flags ? d_flags : w_flags;
-    a.n_steps = d_n_steps ? d_n_steps : (can_resume ? w_steps : nullptr);
-    a.n_accepted = d_n_accepted ? d_n_accepted : (can_resume ? w_acc : nullptr);
+    a.n_steps = d_n_steps ? d_n_steps : w_steps;
+    a.n_accepted = d_n_accepted ? d_n_accepted : w_acc;
     a.counter = c->counter;
     a.n = n;
     if (!d_x0) {

@@ -29,8 +29,8 @@ struct TraceArgs {
     const double *x0;            // [n][3] or nullptr -> x0s
     double *end;                 // [n][6]
     uint8_t *flags;              // [n] (never null inside the kernels: the C-ABI layer substitutes a workspace); only ever holds final values
-    uint32_t *n_steps;           // [n] or nullptr (never null when a ray can be resumed: disk or object spheres)
-    uint32_t *n_accepted;        // [n] or nullptr (ditto)
+    uint32_t *n_steps;           // [n] (never null inside the kernels, like flags)
+    uint32_t *n_accepted;        // [n] (ditto)
     unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
     double *ws;                  // [n][ws_stride] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
                                  // (park / resume records are written and read back by ONE wavefront of the trace kernel)
