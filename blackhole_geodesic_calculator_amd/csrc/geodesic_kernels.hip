@@ -1593,10 +1593,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                         park_event(A, L, h, t_new);
                         parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
                         L.active = 0u;
-                    } else if (t_new - t_bound >= 0.0) {  // base.py:203-204
-                        store_result(A, L.idx, xn, vn, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
-                        L.active = 0u;
                     } else {
+                        // take the step (ONE place where the lane's state is overwritten: the compiler otherwise
+                        // emits the twelve register copies once per way out of this block)
                         L.t = t_new;
                         L.r_cur = r_new;
 #pragma unroll
@@ -1604,6 +1603,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                             L.x[c] = xn[c];
                             L.v[c] = vn[c];
                             L.a1[c] = a7[c];
+                        }
+                        if (t_new - t_bound >= 0.0) {  // base.py:203-204
+                            store_result(A, L.idx, L.x, L.v, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
+                            L.active = 0u;
                         }
                     }
                 } else {
