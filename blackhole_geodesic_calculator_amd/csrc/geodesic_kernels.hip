@@ -672,8 +672,9 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
                                              const double v[3], uint32_t flags, uint32_t n_att,
                                              uint32_t n_acc)
 {
-    bool bad = !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(v[0]) &&
-                 isfinite(v[1]) && isfinite(v[2]));
+    // any NaN or infinity among the six makes their sum non-finite (inf - inf is NaN): five additions and one class test
+    // instead of six class tests and their combination (the state is O(1e2) at most, the sum cannot overflow)
+    const bool bad = !isfinite(((x[0] + x[1]) + (x[2] + v[0])) + (v[1] + v[2]));
     if (bad) flags |= BHG_FLAG_NAN_;
     double *e = A.end + (size_t)idx * 6;
     // 48 contiguous bytes per lane: three 16-byte stores
@@ -1526,18 +1527,14 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             uint32_t term = 0;
             // 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound]: skip the exact value (rk.py:119)
             // unless the step is already that small
-            const double min_step = (L.h_abs > A.min_step_cap) ? 0.0 : 10.0 * ulp_of(L.t);
-            if (!L.rejected) {
-                if (L.h_abs > max_step)
-                    L.h_abs = max_step;
-                else if (L.h_abs < min_step)
-                    L.h_abs = min_step;
-            }
-            if (L.h_abs < min_step)
-                term = BHG_FLAG_STEP_TOO_SMALL_;
-            else if (L.n_att >= A.max_steps)
-                term = BHG_FLAG_MAX_STEPS_;
-            if (term == 0 && L.t == t_bound) term = BHG_FLAG_REACHED_END_;  // base.py:189-194
+            // (written as selects: as nested ifs this prologue is eight divergent branches per iteration)
+            const double ten_ulp = 10.0 * ulp_of(L.t);
+            const double min_step = (L.h_abs > A.min_step_cap) ? 0.0 : ten_ulp;
+            const double h_clamped = (L.h_abs > max_step) ? max_step : ((L.h_abs < min_step) ? min_step : L.h_abs);
+            L.h_abs = L.rejected ? L.h_abs : h_clamped;
+            term = (L.h_abs < min_step) ? (uint32_t)BHG_FLAG_STEP_TOO_SMALL_
+                                        : ((L.n_att >= A.max_steps) ? (uint32_t)BHG_FLAG_MAX_STEPS_ : 0u);
+            term = (term == 0u && L.t == t_bound) ? (uint32_t)BHG_FLAG_REACHED_END_ : term;  // base.py:189-194
             if (term) {
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
                 L.active = 0u;
