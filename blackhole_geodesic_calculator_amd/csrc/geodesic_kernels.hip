@@ -165,6 +165,9 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return __builtin_fma(t, p, y);                    // cubic: residual ~e^3
 }
 
+// sqrt through the rsq seed + Newton (about 1 ulp), 0 at 0: for bounds and event functions
+__device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
+
 // x^(-1/10) for x in [1e-11, 1e7]: fp32 exp2/log2 seed (~1e-7) + one cubic Newton step.
 __device__ __forceinline__ double pow_m0p1(double x)
 {
@@ -331,12 +334,12 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 struct Dense {
     double x0[3], v0[3];
     double qx[4][3], qv[4][3];
-    double t0, h;
+    double t0, h, ih;  // ih = 1 / h (Newton reciprocal): theta = (t - t0) * ih, within an ulp of the quotient
 };
 
 __device__ __forceinline__ void dense_pos(const Dense &d, double t, double x[3])
 {
-    double th = (t - d.t0) / d.h;
+    double th = (t - d.t0) * d.ih;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double s = __builtin_fma(d.qx[3][i], th, d.qx[2][i]);
@@ -348,7 +351,7 @@ __device__ __forceinline__ void dense_pos(const Dense &d, double t, double x[3])
 
 __device__ __forceinline__ void dense_dir(const Dense &d, double t, double v[3])
 {
-    double th = (t - d.t0) / d.h;
+    double th = (t - d.t0) * d.ih;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double s = __builtin_fma(d.qv[3][i], th, d.qv[2][i]);
@@ -371,7 +374,7 @@ __device__ __forceinline__ double dense_g(const Dense &d, double t, double R, bo
     double x[3];
     dense_pos(d, t, x);
     if (bl) return x[0] - R;
-    return sqrt(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]))) - R;
+    return sqrt_nr(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0]))) - R;
 }
 
 // Brent's method on g(t) = r(t) - R over [ta, tb], xtol = rtol = 4 eps (ivp.py:51-76).
@@ -410,12 +413,15 @@ __device__ __forceinline__ double brent_root(const F &g, double xa, double xb)
         if (fcur == 0.0 || fabs(sbis) < delta) return xcur;
         if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
             double stry;
+            // (the quotients as Newton reciprocals, v_rcp_f64 + one cubic step: within an ulp or two of the IEEE
+            // divisions brentq.c performs -- same iterates up to rounding, a third of the instructions; a zero
+            // denominator gives inf / NaN like the division and falls through to bisection below)
             if (xpre == xblk) {
-                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+                stry = -fcur * (xcur - xpre) * rcp_nr(fcur - fpre);
             } else {
-                double dpre = (fpre - fcur) / (xpre - xcur);
-                double dblk = (fblk - fcur) / (xblk - xcur);
-                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+                double dpre = (fpre - fcur) * rcp_nr(xpre - xcur);
+                double dblk = (fblk - fcur) * rcp_nr(xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) * rcp_nr(dblk * dpre * (fblk - fpre));
             }
             double lim = fmin(fabs(spre), 3.0 * fabs(sbis) - delta);
             if (2.0 * fabs(stry) < lim) {
@@ -547,9 +553,6 @@ __device__ __forceinline__ bool crossed_disk_plane(const double x0[3], const dou
     }
     return ((x0[2] <= 0.0) && (x1[2] >= 0.0)) || ((x0[2] >= 0.0) && (x1[2] <= 0.0));
 }
-
-// sqrt through the rsq seed + Newton (about 1 ulp), 0 at 0: for bounds, where the last bit is free
-__device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
 
 // A step that crosses the disk plane z = 0 needs the event drain only if the crossing can lie in the annulus.
 // The crossing point of the step's dense output lies within delta of the chord's crossing point, where
@@ -1095,7 +1098,7 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
                 double xe[3];
                 pos(tt, xe);
                 const double dx = xe[0] - sp[0], dy = xe[1] - sp[1], dz = xe[2] - sp[2];
-                return sqrt(dx * dx + dy * dy + dz * dz) - sp[3];
+                return sqrt_nr(dx * dx + dy * dy + dz * dz) - sp[3];
             };
             double hi = t_new;
             if (!inside) {
@@ -1154,6 +1157,7 @@ __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const dou
     Dense d;
     d.t0 = t;
     d.h = h;
+    d.ih = rcp_nr(h);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         d.x0[c] = x[c];
@@ -1930,6 +1934,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         Dense d;
         d.t0 = t;
         d.h = h;
+        d.ih = rcp_nr(h);
         for (int c = 0; c < 3; c++) {
             d.x0[c] = x[c];
             d.v0[c] = v[c];
