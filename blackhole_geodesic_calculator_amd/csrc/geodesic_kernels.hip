@@ -1145,6 +1145,36 @@ __device__ __forceinline__ bool finish_or_resume(const TraceArgs &A, uint32_t id
     return true;
 }
 
+// The quartic dense output of one accepted DP5(4) step from its stage accelerations (rk.py:393-404, :552-574 in
+// Nystrom form).  One definition for the event drain and the sampled-trajectory kernel: both return the same bits.
+__device__ __forceinline__ void build_dense(Dense &d, double t, double h, const double x[3], const double v[3],
+                                            const double a1[3], const double a2[3], const double a3[3], const double a4[3],
+                                            const double a5[3], const double a6[3], const double a7[3])
+{
+    d.t0 = t;
+    d.h = h;
+    d.ih = rcp_nr(h);
+    const double *aj[8] = {nullptr, a1, a2, a3, a4, a5, a6, a7};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        d.x0[c] = x[c];
+        d.v0[c] = v[c];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            // sum_j P[j][m] a_j and sum_j P~[j][m] a_j as FMA chains; coefficients that are zero (known at compile
+            // time: the whole m = 0 column of P~, P[2][.], P~[7][.]) are skipped
+            double qv = 0.0, qx = 0.0;
+#pragma unroll
+            for (int j = 1; j <= 7; j++) {
+                if (TB.p[j][m] != 0.0) qv = __builtin_fma(TB.p[j][m], aj[j][c], qv);
+                if (TB.pt[j][m] != 0.0) qx = __builtin_fma(TB.pt[j][m], aj[j][c], qx);
+            }
+            d.qv[m][c] = qv;
+            d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
+        }
+    }
+}
+
 // Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
 // Runs converged on the lanes of the event drain: the step is recomputed from its start state.
 template <int RHS, int EVT>
@@ -1155,23 +1185,7 @@ __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const dou
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
     dp54_stages<RHS>(x, v, a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
     Dense d;
-    d.t0 = t;
-    d.h = h;
-    d.ih = rcp_nr(h);
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        d.x0[c] = x[c];
-        d.v0[c] = v[c];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] + TB.p[5][m] * a5[c] +
-                        TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
-            double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] + TB.pt[4][m] * a4[c] +
-                        TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
-            d.qv[m][c] = qv;
-            d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
-        }
-    }
+    build_dense(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
     const bool ended = settle_events<EVT>(
         A, kind, idx, t, t_new, x, xn, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
         [&](double tt) {
@@ -1932,21 +1946,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         n_acc++;
         // dense output of the accepted step
         Dense d;
-        d.t0 = t;
-        d.h = h;
-        d.ih = rcp_nr(h);
-        for (int c = 0; c < 3; c++) {
-            d.x0[c] = x[c];
-            d.v0[c] = v[c];
-            for (int m = 0; m < 4; m++) {
-                double qv = TB.p[1][m] * a1[c] + TB.p[3][m] * a3[c] + TB.p[4][m] * a4[c] + TB.p[5][m] * a5[c] +
-                            TB.p[6][m] * a6[c] + TB.p[7][m] * a7[c];
-                double qx = TB.pt[1][m] * a1[c] + TB.pt[2][m] * a2[c] + TB.pt[3][m] * a3[c] + TB.pt[4][m] * a4[c] +
-                            TB.pt[5][m] * a5[c] + TB.pt[6][m] * a6[c];
-                d.qv[m][c] = qv;
-                d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
-            }
-        }
+        build_dense(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
         const bool bl = RHS == BHG_RHS_KERR_BL_;
         const bool ev_h = ((r_cur - A.r_hor <= 0.0) && (r_new - A.r_hor >= 0.0)) ||
                           ((r_cur - A.r_hor >= 0.0) && (r_new - A.r_hor <= 0.0));
