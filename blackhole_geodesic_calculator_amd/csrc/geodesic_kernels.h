@@ -24,32 +24,41 @@ constexpr int BHG_RHS_REDUCED_ = 1;
 constexpr int BHG_RHS_KERR_BL_ = 2;
 
 // Kernel arguments (passed by value -> SGPRs).  All pointers are device addresses.
+// Fields the step loop reads come first, in order of use, the ones only the queue fill and the event drain read
+// behind them (the kernarg segment is fetched in 16-dword chunks and, short of SGPRs, the compiler spills and reloads
+// scalars through VGPR lanes; the order was measured neutral on every configuration -- it is kept for the reader).
 struct TraceArgs {
-    const double *k0;            // [n][3]
-    const double *x0;            // [n][3] or nullptr -> x0s
+    // ---- chunk 0 (16 dwords): every iteration of the step loop
     double *end;                 // [n][6]
     uint8_t *flags;              // [n] (never null inside the kernels: the C-ABI layer substitutes a workspace); only ever holds final values
     uint32_t *n_steps;           // [n] (never null inside the kernels, like flags)
     uint32_t *n_accepted;        // [n] (ditto)
-    unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
+    double rtol, atol, lambda_end, max_step;
+    // ---- chunk 1: the step loop's event tests and controller limits
+    double r_hor;                // horizon event radius: r_s, or r_plus (1 + margin) for Kerr
+    double r_s;
+    double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
+    double r_exit, disk_r_in, disk_r_out;
+    double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
+    double h_fixed;
+    // ---- chunk 2: parking (in the step loop's event branch), then the rare paths
     double *ws;                  // [n][ws_stride] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
                                  // (park / resume records are written and read back by ONE wavefront of the trace kernel)
+    uint32_t max_steps;
+    int32_t ws_stride;           // doubles per ray record in ws: 6, or 8 for Kerr ({E, L} appended)
+    int32_t n_spheres;           // object spheres inside the curved region (Schwarzschild forms only)
+    int32_t from_records;        // rays start from the records the prepare pass wrote (Kerr)
+    const double *k0;            // [n][3]
+    const double *x0;            // [n][3] or nullptr -> x0s
+    unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
     uint64_t n;                  // rays in the call
     double x0s[3];
-    double r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, disk_r_in, disk_r_out;
-    double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
-    double r_hor;                // horizon event radius: r_s, or r_plus (1 + margin) for Kerr
-    int32_t ws_stride;           // doubles per ray record in ws: 6, or 8 for Kerr ({E, L} appended)
-    int32_t from_records;        // rays start from the records the prepare pass wrote (Kerr)
     int32_t inline_prepare;      // set by the launcher: no prepare launch, the trace waves work the start records out (Schwarzschild forms)
     int32_t order_blocks;        // work-order hint: n = order_blocks * order_block_len, batches are
     uint64_t order_block_len;    // handed out chunk-major over the blocks; 0/1 = plain order
-    uint32_t max_steps;
-    double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
-    uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged
-    unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
     int8_t *object_id;           // [n] or nullptr: sphere index of rays that end with BHG_FLAG_HIT_OBJECT, else -1
-    int32_t n_spheres;           // object spheres inside the curved region (Schwarzschild forms only)
+    unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
+    uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged
     double spheres[BHG_MAX_SPHERES_][4];  // {cx, cy, cz, radius}, BH-centred
 };
 
