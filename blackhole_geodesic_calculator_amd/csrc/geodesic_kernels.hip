@@ -1546,8 +1546,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             // 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound]: skip the exact value (rk.py:119)
             // unless the step is already that small
             // (written as selects: as nested ifs this prologue is eight divergent branches per iteration)
-            const double ten_ulp = 10.0 * ulp_of(L.t);
-            const double min_step = (L.h_abs > A.min_step_cap) ? 0.0 : ten_ulp;
+            // (the exact 10 ulp(t) only when some lane's step is already that small: practically never)
+            const bool tiny = !(L.h_abs > A.min_step_cap);
+            double min_step = 0.0;
+            if (__ballot(tiny)) min_step = tiny ? 10.0 * ulp_of(L.t) : 0.0;
             const double h_clamped = (L.h_abs > max_step) ? max_step : ((L.h_abs < min_step) ? min_step : L.h_abs);
             L.h_abs = L.rejected ? L.h_abs : h_clamped;
             term = (L.h_abs < min_step) ? (uint32_t)BHG_FLAG_STEP_TOO_SMALL_
