@@ -361,6 +361,7 @@ def main():
         if strong is not None:
             out["strong"] = strong
         if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
+            out["pipelined"] = pipelined_figure(ctx, fr, params, a, local_rank)
             out["host_buffer_call"] = host_buffer_figures(ctx, fr, cam, params, n)
         if a.cpu_seconds > 0 and world == 1:   # the CPU baseline is an N = 1 figure (rank 0's host cores, nothing else running)
             if a.workload == "orbit":
@@ -380,6 +381,43 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def pipelined_figure(ctx, fr, params, a, device):
+    """Consecutive frames of an animation are independent: two frames in flight on two streams (two library
+    contexts, each with its own work counters and workspace) let the next frame's waves start while the previous
+    launch drains its last batches.  Reported beside `value`, never as `value`: the per-kernel durations the roofline
+    figure rests on overlap here and mean something else."""
+    import torch
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    ctx2 = _ffi.Context(device)
+    n = fr.n
+    buf = (fr.d_k0, torch.empty((n, 6), dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"),
+           torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"))
+    fr2 = DeviceFrame(ctx2, fr.W, fr.H, fr.S, fov_x=fr.fov_x, fov_y=fr.fov_y, origin=fr.origin, pixels=fr.d_pixels.cpu().numpy(),
+                      jitter=np.zeros(2), buffers=buf)          # same rays (shared d_k0), its own result buffers
+    fr2.d_sky, fr2.sky_wh = fr.d_sky, fr.sky_wh
+    frames = (fr, fr2)
+    streams = (torch.cuda.Stream(), torch.cuda.Stream())
+    imgs = [torch.zeros((fr.W * fr.H, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+
+    def run(k):
+        for i in range(k):
+            with torch.cuda.stream(streams[i & 1]):
+                frames[i & 1].trace(params)
+                frames[i & 1].shade_f32(imgs[i & 1], fr.d_pixels)
+    torch.cuda.synchronize()
+    run(a.warmup)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    same = bool(torch.equal(imgs[0], imgs[1]))
+    ctx2.close()
+    return {"value": n / (dt / a.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": dt / a.steps * 1e3, "frames_identical": same,
+            "what": f"{a.steps} frames alternating between two streams / library contexts (trace + shade each), no synchronisation in between"}
 
 
 def host_buffer_figures(ctx, fr, cam, params, n):
