@@ -566,21 +566,24 @@ __device__ __forceinline__ bool crossed_disk_plane(const double x0[3], const dou
 __device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const double x0[3], const double v0[3],
                                                       const double x1[3], const double v1[3], double h)
 {
-    const double s = x0[2] * rcp_nr(x0[2] - x1[2]);  // NaN when the step lies in the plane: falls through to "may hit"
-    const double xl = __builtin_fma(s, x1[0] - x0[0], x0[0]), yl = __builtin_fma(s, x1[1] - x0[1], x0[1]);
-    const double R2 = __builtin_fma(xl, xl, yl * yl);
-    const double ih = rcp_nr(h);
-    double d0 = 0.0, d1 = 0.0;
+    // Everything scaled so that no quotient is needed: with D = z0 - z1 the chord's crossing point is P / D,
+    // P = z0 (x1, y1) - z1 (x0, y0), and |h| |v - c| = |h v - (x1 - x0)| for the chord velocity c = (x1 - x0) / h.
+    const double D = x0[2] - x1[2];
+    const double Px = __builtin_fma(x0[2], x1[0], -(x1[2] * x0[0])), Py = __builtin_fma(x0[2], x1[1], -(x1[2] * x0[1]));
+    const double P2 = __builtin_fma(Px, Px, Py * Py), D2 = D * D;
+    double n0 = 0.0, n1 = 0.0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double cv = (x1[c] - x0[c]) * ih;
-        const double e0 = v0[c] - cv, e1 = v1[c] - cv;
-        d0 = __builtin_fma(e0, e0, d0);
-        d1 = __builtin_fma(e1, e1, d1);
+        const double dx = x1[c] - x0[c];
+        const double e0 = __builtin_fma(h, v0[c], -dx), e1 = __builtin_fma(h, v1[c], -dx);
+        n0 = __builtin_fma(e0, e0, n0);
+        n1 = __builtin_fma(e1, e1, n1);
     }
-    const double delta = fabs(h) * (sqrt_nr(d0) + sqrt_nr(d1)) * (1.0 + 1e-9);
+    const double delta = (sqrt_nr(n0) + sqrt_nr(n1)) * (1.0 + 1e-9);
     const double lo = A.disk_r_in - delta, hi = A.disk_r_out + delta;
-    return !((lo > 0.0 && R2 < lo * lo) || R2 > hi * hi);  // NaN anywhere: may hit
+    // R = |P| / |D| against [lo, hi], compared as squares times D^2; a step lying in the plane (D = 0, P = 0) and NaN
+    // anywhere fall through to "may hit"
+    return !((lo > 0.0 && P2 < lo * lo * D2) || P2 > hi * hi * D2);
 }
 
 // The same question in Boyer-Lindquist coordinates (x = (r, theta, phi)): the plane is theta* = pi/2 + k pi, the
