@@ -1498,13 +1498,21 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 {
     __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
-    const double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
-    const double max_step = A.max_step;
+    double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
+    double max_step = A.max_step;
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
     met.a = A.spin;
     met.E = met.L = 0.0;
+    if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
+        // Kerr frames without optional events: the scalars every step reads, kept in VGPRs.  They are wave-uniform and the compiler would hold them in
+        // SGPRs, of which the Kerr kernel is short (67 spilled): it parks them in VGPR lanes and fetches them back with
+        // v_readlane at every use, ~130 times per iteration.  Config 5 +2 to +3 %; the Schwarzschild kernels and the Kerr
+        // variants with a disk have no VGPRs to spare for this (config 3 -11 %, Kerr + disk -4 % with it).
+        asm volatile("" : "+v"(r_s), "+v"(rtol), "+v"(atol), "+v"(t_bound), "+v"(max_step));
+        asm volatile("" : "+v"(met.r_s), "+v"(met.M), "+v"(met.a));
+    }
 
     Lane L;
 #pragma unroll
