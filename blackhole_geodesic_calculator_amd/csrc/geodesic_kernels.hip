@@ -1494,10 +1494,11 @@ __device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, 
 #define BHG_KERR_WAVES_PER_SIMD 2
 #endif
 template <int RHS, int EVT>
-__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A)
+__global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A0)
 {
     __shared__ WaveLds<RHS> Q;
     const uint32_t lane = threadIdx.x;
+    TraceArgs A = A0;  // (a copy the Kerr variant below can move fields of into VGPRs; free for the others)
     double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     double max_step = A.max_step;
     Metric met;
@@ -1512,6 +1513,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         // variants with a disk have no VGPRs to spare for this (config 3 -11 %, Kerr + disk -4 % with it).
         asm volatile("" : "+v"(r_s), "+v"(rtol), "+v"(atol), "+v"(t_bound), "+v"(max_step));
         asm volatile("" : "+v"(met.r_s), "+v"(met.M), "+v"(met.a));
+        // ... and the four result pointers (the spilled unit is the whole 16-dword kernarg chunk they sit in: every
+        // result store fetched all sixteen lanes back)
+        asm volatile("" : "+v"(A.end), "+v"(A.flags), "+v"(A.n_steps), "+v"(A.n_accepted));
     }
 
     Lane L;
