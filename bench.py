@@ -304,7 +304,7 @@ def main():
         F = FLOP_PER_STEP[(method, a.rhs)]
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
-        traffic, traffic_source = pmc_traffic(a, method)
+        traffic, traffic_source, valu_insts = pmc_traffic(a, method)
         out = {
             "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU"
                       if a.workload == "frame" else
@@ -350,6 +350,9 @@ def main():
                 "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                # wave-level VALU instructions the whole launch issues (SQ_INSTS_VALU, same replayed summary) per 64
+                # attempted ray-steps: step loop + setup + pop + events; the instruction-stream ceiling is F*64 / (2*64*this)
+                "valu_insts_per_64_ray_steps": None if not valu_insts else valu_insts * 64.0 / ray_steps,
                 "flop_per_ray_step": F,
                 "ray_steps_per_launch": ray_steps,
                 "kernel_ms": k_ms,
@@ -470,22 +473,24 @@ def pmc_traffic(a, method):
     (profiles/rNN*_pmc_summary[_<workload>].json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read inside
     the timed run, so this is the committed measurement, replayed: (bytes, file name), or (None, None) if there is
-    none for this configuration."""
+    none for this configuration.  Third value: wave-level VALU instructions per launch (SQ_INSTS_VALU pass of the same
+    script), or None."""
     import glob
     if not (a.regime == "adaptive" and method == "dp54" and a.rhs in ("christoffel", "kerr")):
-        return None, None
+        return None, None, None
     dflt = {"frame": (1024, 5), "disk": (1024, 1), "orbit": (2048, 16)}[a.workload]
     if (a.width, a.height, a.samples) != (dflt[0], dflt[0], dflt[1]):
-        return None, None
+        return None, None, None
     tag = {"frame": "", "disk": "_disk", "orbit": "_orbit"}[a.workload] + ("_kerr" if a.rhs == "kerr" else "")
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))
                    if os.path.basename(f).split("_pmc_summary")[1] == tag + ".json")
     if not files:
-        return None, None
+        return None, None, None
     try:
-        return json.load(open(files[-1])).get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(files[-1])
+        s = json.load(open(files[-1]))
+        return s.get("hbm_bytes_per_launch"), "profiles/" + os.path.basename(files[-1]), s.get("valu_insts_per_launch")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def effective_cores():

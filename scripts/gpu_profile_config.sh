@@ -16,7 +16,7 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tm
 for f in $(find /tmp/pf_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_pmc_fetch.csv; grep "trace_" $f >> $O/prof_${name}_pmc_fetch.csv; done
 for f in $(find /tmp/pw_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_pmc_write.csv; grep "trace_" $f >> $O/prof_${name}_pmc_write.csv; done
 python3 $R/scripts/summarize_pmc.py $O/prof_${name}_pmc_fetch.csv $O/prof_${name}_pmc_write.csv $O/prof_${name}_pmc_summary.json trace_ > /dev/null
-for ctr in VALUBusy VALUUtilization; do
+for ctr in VALUBusy VALUUtilization SQ_INSTS_VALU; do
   rm -rf /tmp/dv_$name
   timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/dv_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --cpu-seconds 0 "$@" >> $O/prof_${name}_rocprof.log 2>&1
   for f in $(find /tmp/dv_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_$ctr.csv; grep "trace_" $f >> $O/prof_${name}_$ctr.csv; done
@@ -31,6 +31,15 @@ for r in csv.DictReader(open(f"{O}/prof_{name}_kernel_stats.csv")):
         print("   %-60s calls %5s avg %10.1f us  %5.1f %%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 s = json.load(open(f"{O}/prof_{name}_pmc_summary.json"))
 print("   HBM bytes per trace launch %.1f MB (fetch x2 %.1f + write %.1f)" % (s.get("hbm_bytes_per_launch", 0) / 1e6, (s["fetch_bytes_corrected"] or 0) / 1e6, (s["write_bytes"] or 0) / 1e6))
+try:   # wave-level VALU instructions per trace launch -> into the PMC summary (bench.py reports it per 64 ray-steps)
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f"{O}/prof_{name}_SQ_INSTS_VALU.csv")) if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    s["valu_insts_per_launch"] = sum(v) / len(v)
+    s["valu_insts_launches"] = len(v)
+    json.dump(s, open(f"{O}/prof_{name}_pmc_summary.json", "w"), indent=1)
+    rs = b["roofline"]["ray_steps_per_launch"]
+    print("   SQ_INSTS_VALU %.4g per launch = %.1f per 64 ray-steps" % (s["valu_insts_per_launch"], s["valu_insts_per_launch"] * 64 / rs))
+except Exception as e:
+    print("   SQ_INSTS_VALU failed", e)
 for ctr in ("VALUBusy", "VALUUtilization"):
     try:
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f"{O}/prof_{name}_{ctr}.csv")) if r["Counter_Name"] == ctr]
