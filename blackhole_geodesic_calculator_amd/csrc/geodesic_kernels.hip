@@ -165,6 +165,18 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return __builtin_fma(t, p, y);                    // cubic: residual ~e^3
 }
 
+// Three reciprocals from ONE v_rcp_f64 (product inversion; the operands' product must stay inside fp64's range, which
+// Delta * Sigma * sin(theta) of the Kerr right-hand side does).  A zero or NaN operand poisons all three.
+__device__ __forceinline__ void rcp3_nr(double x0, double x1, double x2, double &o0, double &o1, double &o2)
+{
+    const double p01 = x0 * x1;
+    double inv = rcp_nr(p01 * x2);   // 1/(x0 x1 x2)
+    o2 = inv * p01;
+    inv *= x2;                       // 1/(x0 x1)
+    o1 = inv * x0;
+    o0 = inv * x1;
+}
+
 // sqrt through the rsq seed + Newton (about 1 ulp), 0 at 0: for bounds and event functions
 __device__ __forceinline__ double sqrt_nr(double x) { return x > 0.0 ? x * rsqrt_nr(x) : 0.0; }
 
@@ -246,10 +258,14 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
         // of the library, which spells every FMA out and is built with -ffp-contract=off
 #pragma clang fp contract(on)
 #define KERR_RCP(x) rcp_nr(x)
+#define KERR_RCP3(o0, x0, o1, x1, o2, x2) \
+    double o0, o1, o2;                    \
+    rcp3_nr(x0, x1, x2, o0, o1, o2)
 #define KERR_SIN(x) sin_th
 #define KERR_COS(x) cos_th
 #include "kerr_rhs.inc"
 #undef KERR_RCP
+#undef KERR_RCP3
 #undef KERR_SIN
 #undef KERR_COS
     }

@@ -144,10 +144,12 @@ static void acc_kerr_bl(const rayctx *rc, const double q[3], const double u[3], 
     const double E = rc->E, L = rc->L, M = rc->M, a = rc->a;
     double ar, ath, aph, ktv;
 #define KERR_RCP(x) (1.0 / (x))
+#define KERR_RCP3(o0, x0, o1, x1, o2, x2) const double o0 = 1.0 / (x0), o1 = 1.0 / (x1), o2 = 1.0 / (x2)
 #define KERR_SIN(x) sin(x)
 #define KERR_COS(x) cos(x)
 #include "kerr_rhs.inc"
 #undef KERR_RCP
+#undef KERR_RCP3
 #undef KERR_SIN
 #undef KERR_COS
     (void)ktv;

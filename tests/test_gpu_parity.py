@@ -52,12 +52,16 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, **kw):
         assert np.array_equal(obj, o["object_id"])
     else:
         end, flags, steps, acc = ctx.trace(k0, x0, _params(**kw))
-    assert np.array_equal(flags, o["flags"])
     if allow_flips:
-        bad = (steps != o["n_attempted"]) | (acc != o["n_accepted"])
+        # (fixed steps through the coordinate singularity: whether such a ray is seen crossing the horizon radius
+        # before its state turns NaN is rounding noise too -- both sides must still call it horizon and/or NaN)
+        fbad = flags != o["flags"]
+        assert np.all((flags[fbad] & ~np.uint8(1 | 64)) == 0) and np.all((o["flags"][fbad] & ~np.uint8(1 | 64)) == 0)
+        bad = fbad | (steps != o["n_attempted"]) | (acc != o["n_accepted"])
         assert bad.mean() <= (0.005 if allow_flips is True else allow_flips) and np.all((flags[bad] & (1 | 64)) != 0)
         assert np.abs(steps.astype(int) - o["n_attempted"].astype(int)).max(initial=0) <= 3
     else:
+        assert np.array_equal(flags, o["flags"])
         assert np.array_equal(steps, o["n_attempted"])
         assert np.array_equal(acc, o["n_accepted"])
     d = np.abs(end - o["end"]).max(1) if len(end) else np.zeros(0)
