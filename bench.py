@@ -29,10 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic flop per attempted ray-step: 6 RHS x 44 + 390 bookkeeping
-# Kerr (config 5): the generated Boyer-Lindquist RHS has 127 operations after CSE (tools/gen_kerr_rhs.py;
-# 134 until the (t, phi) determinant went in in closed form), sin/cos counted as one each -> 6 x 127 + 390 and 4 x 127 + 78
-FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468, ("dp54", "kerr"): 1152,
-                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130, ("rk4", "kerr"): 586}
+# Kerr (config 5): the generated Boyer-Lindquist RHS is 90 operations (tools/gen_kerr_rhs.py: the structured
+# omega / chi form; the sympy-CSE'd contraction it is checked against has 127), sin / cos / each reciprocal counted as one
+# -> 6 x 90 + 390 and 4 x 90 + 78
+FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468, ("dp54", "kerr"): 930,
+                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130, ("rk4", "kerr"): 438}
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
