@@ -305,7 +305,6 @@ __device__ __forceinline__ void accel(const double x[3], const double k[3], cons
         double u = r_s * rinv;         // r_s/r
         double nk2 = xk * xk * w;      // (n.k)^2
         double f = 1.0 - u;
-        double fp = r_s * w;
         double q = rcp_nr(f);          // 1/f
         double h = u * q;              // r_s/(r - r_s)
         // f' (k^t)^2 + h' (n.k)^2 with (k^t)^2 = (|k|^2 + h (n.k)^2)/f and h' = -f' / f^2, both terms
@@ -316,7 +315,7 @@ __device__ __forceinline__ void accel(const double x[3], const double k[3], cons
         // (three multiplications fewer per evaluation than forming g and 1/2 f g; the 1/f singularity stays in h and q)
         double T = __builtin_fma(h, nk2, kk);
         double Y = __builtin_fma(0.5, __builtin_fma(-q, nk2, T), kk - nk2);
-        c = (-fp * rinv) * Y;
+        c = (-u * w) * Y;              // f' / r = r_s / r^3 = (r_s / r) (1 / r^2)
     }
     a[0] = c * x[0];
     a[1] = c * x[1];
