@@ -369,3 +369,14 @@ def test_kerr_rhs_against_hamiltonian_form(oracle):
         assert abs(sol.y[0, -1] - q1[0]) < 2e-6 and abs(sol.y[1, -1] - q1[1]) < 2e-6 and abs(dphi) < 2e-6
         checked += 1
     assert checked >= 8
+
+
+def test_kerr_snippet_is_the_generators_output_and_matches_the_contraction():
+    """tools/gen_kerr_rhs.py --check: re-derives the Kerr Christoffel contraction with sympy, checks the structured
+    omega / chi statements against it in exact rational arithmetic, and requires both committed copies of
+    kerr_rhs.inc (oracle's and the kernel's) to be byte-for-byte what it emits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_kerr_rhs.py"), "--check"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
