@@ -236,10 +236,13 @@ __device__ __forceinline__ void sincos_pi4(double x, double &s, double &c)
     pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
     pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    const int q = (int)kf;
-    const double ss = (q & 1) ? cr : sr, cs = (q & 1) ? sr : cr;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cs : cs;
+    // quadrant fix-up: odd quadrants swap the two, bit 1 of q (of q + 1) flips the sign of the sine (cosine) -- the
+    // flips as integer operations on the sign bit (three instructions each; as selects they are four or five)
+    const uint32_t q = (uint32_t)(int)kf;
+    const double ss = (q & 1u) ? cr : sr, cs = (q & 1u) ? sr : cr;
+    const uint32_t fs = (q << 30) & 0x80000000u, fc = ((q + 1u) << 30) & 0x80000000u;
+    s = __hiloint2double((int)((uint32_t)__double2hiint(ss) ^ fs), __double2loint(ss));
+    c = __hiloint2double((int)((uint32_t)__double2hiint(cs) ^ fc), __double2loint(cs));
 }
 
 // generated by tools/gen_kerr_rhs.py from the sympy-derived Christoffel symbols (the reference's
