@@ -58,26 +58,75 @@ __global__ void __launch_bounds__(256) raygen_kernel(const RaygenArgs A)
 // build's own and is restated in numpy in device_frame.py for the parity test.)
 __device__ __forceinline__ void sky_lookup(const float *sky, int TW, int TH, double u, double v, double rgb[3])
 {
-    double fx = (u + 1.0) * 0.5 * (double)TW - 0.5;
+    const double TWd = (double)TW;
+    double fx = (u + 1.0) * 0.5 * TWd - 0.5;
     double fy = (v + 1.0) * 0.5 * (double)TH - 0.5;
     double x0f = floor(fx), y0f = floor(fy);
     double ax = fx - x0f, ay = fy - y0f;
-    long x0 = (long)x0f, y0 = (long)y0f;
-    long x1 = x0 + 1, y1 = y0 + 1;
-    x0 %= TW;
-    if (x0 < 0) x0 += TW;
-    x1 %= TW;
-    if (x1 < 0) x1 += TW;
-    y0 = y0 < 0 ? 0 : (y0 > TH - 1 ? TH - 1 : y0);
-    y1 = y1 < 0 ? 0 : (y1 > TH - 1 ? TH - 1 : y1);
-    const float4 t00 = reinterpret_cast<const float4 *>(sky)[y0 * TW + x0];
-    const float4 t01 = reinterpret_cast<const float4 *>(sky)[y0 * TW + x1];
-    const float4 t10 = reinterpret_cast<const float4 *>(sky)[y1 * TW + x0];
-    const float4 t11 = reinterpret_cast<const float4 *>(sky)[y1 * TW + x1];
+    // column x0f mod TW (u wraps) in floating point -- the columns are small integers held exactly, the quotient's
+    // rounding can only be off by one period, which the two selects put right; a 64-bit integer remainder is a
+    // hundred-instruction sequence on this machine
+    double xw = __builtin_fma(-TWd, floor(x0f * (1.0 / TWd)), x0f);
+    xw = xw < 0.0 ? xw + TWd : (xw >= TWd ? xw - TWd : xw);
+    const int x0 = (int)xw;
+    const int x1 = (x0 + 1 == TW) ? 0 : x0 + 1;
+    const double THm = (double)(TH - 1);
+    const int y0 = (int)fmin(fmax(y0f, 0.0), THm), y1 = (int)fmin(fmax(y0f + 1.0, 0.0), THm);
+    const float4 t00 = reinterpret_cast<const float4 *>(sky)[(long)y0 * TW + x0];
+    const float4 t01 = reinterpret_cast<const float4 *>(sky)[(long)y0 * TW + x1];
+    const float4 t10 = reinterpret_cast<const float4 *>(sky)[(long)y1 * TW + x0];
+    const float4 t11 = reinterpret_cast<const float4 *>(sky)[(long)y1 * TW + x1];
     const double w00 = (1.0 - ax) * (1.0 - ay), w01 = ax * (1.0 - ay), w10 = (1.0 - ax) * ay, w11 = ax * ay;
     rgb[0] = w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x;
     rgb[1] = w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y;
     rgb[2] = w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z;
+}
+
+// 1/x: v_rcp_f64 + one cubic Newton step (about an ulp), as in the trace kernels
+__device__ __forceinline__ double rcp_newton(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    double t = __builtin_fma(e, e, e);
+    return __builtin_fma(y, t, y);
+}
+
+// atan2(y, x) for finite arguments, about an ulp, without libm's special-case ladder (the sky lookup calls it twice
+// per ray and was most of the shade kernel's instructions): octant reduction to q = min/max in [0, 1], then the
+// classic argument reduction at 7/16 and 11/16 -- t = q, (2q - 1)/(2 + q) or (q - 1)/(q + 1) -- and the odd
+// degree-21 minimax polynomial on |t| < 7/16.  atan2(0, 0) = 0.
+//
+// Attribution: breakpoints, atan(1/2) / atan(1) hi + lo parts and the coefficients aT[0..10] are those of FreeBSD msun
+// / fdlibm's s_atan.c: "Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.  Developed at SunPro, a Sun
+// Microsystems, Inc. business.  Permission to use, copy, modify, and distribute this software is freely granted,
+// provided that this notice is preserved."
+__device__ __forceinline__ double atan2_fast(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double q = (mx > 0.0) ? mn * rcp_newton(mx) : 0.0;
+    const bool r0 = q < 0.4375, r1 = q < 0.6875;
+    const double num = r0 ? q : (r1 ? __builtin_fma(2.0, q, -1.0) : q - 1.0);
+    const double den = r0 ? 1.0 : (r1 ? 2.0 + q : q + 1.0);
+    const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : 7.85398163397448278999e-01);
+    const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : 3.06161699786838301793e-17);
+    const double t = num * rcp_newton(den);
+    const double z = t * t, w = z * z;
+    double s1 = __builtin_fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    s1 = __builtin_fma(w, s1, 6.66107313738753120669e-02);
+    s1 = __builtin_fma(w, s1, 9.09088713343650656196e-02);
+    s1 = __builtin_fma(w, s1, 1.42857142725034663711e-01);
+    s1 = __builtin_fma(w, s1, 3.33333333333329318027e-01);
+    s1 *= z;
+    double s2 = __builtin_fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    s2 = __builtin_fma(w, s2, -7.69187620504482999495e-02);
+    s2 = __builtin_fma(w, s2, -1.11111104054623557880e-01);
+    s2 = __builtin_fma(w, s2, -1.99999999998764832476e-01);
+    s2 *= w;
+    double r = hi - ((t * (s1 + s2) - lo) - t);      // atan(q) in [0, pi/4]
+    r = (ay > ax) ? 1.5707963267948966 - r : r;      // first quadrant
+    r = (x < 0.0) ? 3.141592653589793 - r : r;
+    return (y < 0.0) ? -r : r;
 }
 
 // Disk colour (LimitedRelativisticRenderEngine.py:427-436, :300): texture(texture_x, scale) * intensity with a
@@ -182,14 +231,12 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
             acc[2] += rgb[2];
             continue;
         }
-        double d0 = c0, d1 = c1, d2 = c2;
-        // exit directions are not unit vectors; normalise like the Cam edition (CamEdition.py:433-437)
-        const double inv = 1.0 / sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-        d0 *= inv;
-        d1 *= inv;
-        d2 *= inv;
-        const double theta = 1.0 - acos(d2) / M_PI;   // :373
-        const double phi = atan2(d1, d0) / M_PI;      // :374
+        // theta = 1 - acos(d_z / |d|) / pi (:373), phi = atan2(d_y, d_x) / pi (:374); exit directions are not unit
+        // vectors (the Cam edition normalises, CamEdition.py:433-437) -- both angles as scale-free atan2's:
+        // acos(d_z / |d|) = atan2(sqrt(d_x^2 + d_y^2), d_z)
+        const double rho = sqrt(c0 * c0 + c1 * c1);
+        const double theta = 1.0 - atan2_fast(rho, c2) * 0.3183098861837907;
+        const double phi = atan2_fast(c1, c0) * 0.3183098861837907;
         double rgb[3];
         sky_lookup(A.sky, A.sky_w, A.sky_h, -phi, 2.0 * theta - 1.0, rgb);  // :375
         acc[0] += rgb[0];
