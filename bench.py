@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 # -> 6 x 90 + 390 and 4 x 90 + 78
 FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468, ("dp54", "kerr"): 930,
                  ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130, ("rk4", "kerr"): 438}
+# What the kernels' own evaluation order of the Christoffel form amounts to under the same counting rules (mul / add 1, FMA 2,
+# rcp / rsqrt 1): 35 per RHS evaluation + 1 (r at the step's end) instead of SURVEY's 44 -- reported beside the
+# accounting figure as roofline.flop_per_ray_step_executed / frac_executed, never instead of it
+FLOP_PER_STEP_EXECUTED = {("dp54", "christoffel"): 6 * 35 + 1 + 390, ("rk4", "christoffel"): 4 * 35 + 1 + 78}
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
@@ -355,6 +359,8 @@ def main():
                 # attempted ray-steps: step loop + setup + pop + events; the instruction-stream ceiling is F*64 / (2*64*this)
                 "valu_insts_per_64_ray_steps": None if not valu_insts else valu_insts * 64.0 / ray_steps,
                 "flop_per_ray_step": F,
+                "flop_per_ray_step_executed": FLOP_PER_STEP_EXECUTED.get((method, a.rhs), F),
+                "frac_executed": achieved_tf / PEAK_FP64_VALU_TFLOPS * FLOP_PER_STEP_EXECUTED.get((method, a.rhs), F) / F,
                 "ray_steps_per_launch": ray_steps,
                 "kernel_ms": k_ms,
                 "trace_call_ms": call_ms,
