@@ -1104,7 +1104,14 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
         double xe[3];
         pos(r, xe);
         // cylindrical radius of the crossing point; Boyer-Lindquist: sqrt(x^2 + y^2) = sqrt(r^2 + a^2) |sin theta|
-        const double R = bl ? sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sin(xe[1])) : sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+        double R;
+        if (bl) {
+            double sn, cs;
+            sincos_pi4(xe[1], sn, cs);
+            R = sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sn);
+        } else {
+            R = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+        }
         if (R >= A.disk_r_in && R <= A.disk_r_out && r < best) {
             best = r;
             fl = BHG_FLAG_HIT_DISK_;
@@ -1214,7 +1221,9 @@ __device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const dou
             if (RHS != BHG_RHS_KERR_BL_) return dense_z(d, tt);
             double q[3];
             dense_pos(d, tt, q);
-            return cos(q[1]);  // z = r cos(theta), r > 0
+            double sn, cs;             // z = r cos(theta), r > 0; the RHS's own sincos (about an ulp, a quarter of
+            sincos_pi4(q[1], sn, cs);  // libm's cos with its large-argument ladder) -- once per Brent iterate
+            return cs;
         },
         [&](double tt, double xe[3]) { dense_pos(d, tt, xe); },
         [&](double tt, double xe[3], double ve[3]) {
@@ -1308,7 +1317,10 @@ __device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const doub
         [&](double tt) {
             double xx[3], vv[3];
             hermite_eval(d, tt, xx, vv);
-            return RHS == BHG_RHS_KERR_BL_ ? cos(xx[1]) : xx[2];
+            if (RHS != BHG_RHS_KERR_BL_) return xx[2];
+            double sn, cs;
+            sincos_pi4(xx[1], sn, cs);
+            return cs;
         },
         [&](double tt, double xe[3]) {
             double vv[3];
