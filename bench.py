@@ -41,6 +41,7 @@ FLOP_PER_STEP_EXECUTED = {("dp54", "christoffel"): 6 * 35 + 1 + 390, ("rk4", "ch
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
+BYTES_PER_RAY_DIR = 24 + 24 + 1 + 4 + 4  # direction-only traces (sky frames): the direction half of the end state
 
 
 def parse():
@@ -66,6 +67,8 @@ def parse():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--full-records", action="store_true",
+                    help="frame workload: have the trace write whole end states (48 B/ray) instead of the exit directions a sky frame reads")
     ap.add_argument("--lpt", type=int, default=1, help="1: visit tiles in order of decreasing expected cost")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time (0 = skip)")
     a = ap.parse_args()
@@ -186,8 +189,11 @@ def main():
             for f in frames:
                 f.set_disk(DISK[0], DISK[1], disk_tex)
         else:
+            # a sky frame reads only the exit directions of its rays (background_hit, :366-378): the trace writes those
+            # alone (bhg_trace_dir_device) unless --full-records asks for whole end states
             frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
-                                      pixels=pixels, jitter=jitter))
+                                      pixels=pixels, jitter=jitter,
+                                      directions_only=(a.workload == "frame" and not a.full_records)))
         del jitter
         for f in frames:
             f.set_sky(sky)
@@ -310,6 +316,7 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
         traffic, traffic_source, valu_insts = pmc_traffic(a, method)
+        bytes_per_ray = BYTES_PER_RAY_DIR if getattr(fr, "_dir_traced", False) else BYTES_PER_RAY
         out = {
             "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU"
                       if a.workload == "frame" else
@@ -341,7 +348,8 @@ def main():
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
                 "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
-                "tile": a.tile, "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0 + root-side assembly kernel" if collective else "in frame order"),
+                "tile": a.tile, "trace_output": "exit directions + flags + step counts (25 + 8 B/ray)" if getattr(fr, "_dir_traced", False) else "end states + flags + step counts (49 + 8 B/ray)",
+                "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0 + root-side assembly kernel" if collective else "in frame order"),
                 "collective": ("rccl gather, %d rank(s)%s" % (world, " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if collective else "none (single rank)",
                 "launch": m["launch"],
             },
@@ -364,8 +372,9 @@ def main():
                 "ray_steps_per_launch": ray_steps,
                 "kernel_ms": k_ms,
                 "trace_call_ms": call_ms,
-                "hbm_algorithmic_GBps": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9,
-                "hbm_frac": n * BYTES_PER_RAY / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "hbm_algorithmic_GBps": n * bytes_per_ray / (k_ms * 1e-3) / 1e9,
+                "hbm_frac": n * bytes_per_ray / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_bytes_per_ray": bytes_per_ray,
             },
         }
         if strong is not None:

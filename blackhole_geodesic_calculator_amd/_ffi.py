@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -45,7 +45,7 @@ EXPORTS = (
     "bhg_shade_device", "bhg_set_profiling", "bhg_last_pass_ms", "bhg_trajectory", "bhg_trace_objects",
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
     "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free", "bhg_rays_create", "bhg_rays_count",
-    "bhg_rays_destroy", "bhg_rays_trace",
+    "bhg_rays_destroy", "bhg_rays_trace", "bhg_trace_dir_device", "bhg_shade_dir_device",
 )
 
 
@@ -178,6 +178,11 @@ def load():
     L.bhg_trace_device.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
+    L.bhg_trace_dir_device.restype = C.c_int
+    L.bhg_trace_dir_device.argtypes = L.bhg_trace_device.argtypes
+    L.bhg_shade_dir_device.restype = C.c_int
+    L.bhg_shade_dir_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bhg_trace_objects.restype = C.c_int
     L.bhg_trace_objects.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int32, _dp, C.c_int, _dp, C.c_size_t, _dp,
                                     _u8p, _u32p, _u32p, C.POINTER(C.c_int8)]
@@ -499,6 +504,25 @@ class Context:
                                        C.c_void_p(d_k0), int(n), C.c_void_p(d_end),
                                        C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),
                                        C.c_void_p(d_n_accepted or None), C.c_void_p(stream or None)))
+
+    def trace_dir_device(self, params: Params, n, d_k0, d_end_dir, x0_shared=None, d_x0=0, d_flags=0,
+                         d_n_steps=0, d_n_accepted=0, stream=0):
+        """bhg_trace_dir_device: like trace_device, but only the direction half of the end states is written
+        (d_end_dir [n][3]) -- what a sky frame consumes."""
+        xs = None
+        if x0_shared is not None:
+            xs = (C.c_double * 3)(*[float(v) for v in x0_shared])
+        _check(load().bhg_trace_dir_device(self._h, C.byref(params), xs, C.c_void_p(d_x0 or None),
+                                           C.c_void_p(d_k0), int(n), C.c_void_p(d_end_dir),
+                                           C.c_void_p(d_flags or None), C.c_void_p(d_n_steps or None),
+                                           C.c_void_p(d_n_accepted or None), C.c_void_p(stream or None)))
+
+    def shade_dir_device(self, d_end_dir, d_flags, n_pixels, samples, d_sky, sky_w, sky_h, d_rgba=0, d_rgba_f32=0,
+                         d_scatter=0, stream=0):
+        _check(load().bhg_shade_dir_device(self._h, C.c_void_p(d_end_dir), C.c_void_p(d_flags), int(n_pixels),
+                                           int(samples), C.c_void_p(d_sky), int(sky_w), int(sky_h),
+                                           C.c_void_p(d_rgba or None), C.c_void_p(d_rgba_f32 or None),
+                                           C.c_void_p(d_scatter or None), C.c_void_p(stream or None)))
 
     def raygen_device(self, width, height, samples, fov_x, fov_y, d_jitter, d_k0, n_pixels, d_pixels=0,
                       rot=None, stream=0):

@@ -200,6 +200,8 @@ struct bhg_context {
     // per-ray workspace of the trace passes (prepare / event / resume records, internal flags)
     void *d_ws = nullptr;
     size_t d_ws_bytes = 0;
+    void *d_endws = nullptr;   // end records as workspace of direction-only calls
+    size_t d_endws_bytes = 0;
     int32_t last_launch[4] = {0, 0, 0, 0};
     int occupancy[48] = {0};  // resident waves per CU of each trace-kernel variant (0 = not asked yet)
     // optional per-pass timing (bhg_set_profiling)
@@ -358,6 +360,7 @@ void bhg_destroy(bhg_context *c)
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_endws) (void)hipFree(c->d_endws);
     if (c->pin_in) (void)hipHostFree(c->pin_in);
     if (c->pin_out) (void)hipHostFree(c->pin_out);
     for (int i = 0; i < 2; i++) {
@@ -440,9 +443,11 @@ int validate_spheres(const bhg_params *p, const double *spheres, int32_t n_spher
     return BHG_OK;
 }
 
+// d_end [n][6], or -- d_end == nullptr -- d_end_dir [n][3]: only the direction half of the final states is produced
 int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
                       const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
-                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream)
+                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream,
+                      double *d_end_dir = nullptr)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
@@ -450,7 +455,7 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     rc = validate_spheres(p, spheres, n_spheres);
     if (rc != BHG_OK) return rc;
     if (n == 0) return BHG_OK;
-    if (!d_k0 || !d_end) return fail(BHG_E_INVALID, "k0 / end is NULL");
+    if (!d_k0 || (!d_end && !d_end_dir)) return fail(BHG_E_INVALID, "k0 / end is NULL");
     if (!x0_shared && !d_x0) return fail(BHG_E_INVALID, "neither x0_shared nor d_x0 given");
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
     ENTER_DEVICE(c->device);
@@ -468,6 +473,15 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     const size_t sz_acc = !d_n_accepted ? sz_u32 : 0;
     rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + 64);
     if (rc != BHG_OK) return rc;
+    if (!d_end) {
+        // direction-only call: the end records are workspace (parked / resume records of the rays that need them; Kerr:
+        // the Boyer-Lindquist states the finalize pass converts), final directions go to d_end_dir
+        rc = ensure(&c->d_endws, &c->d_endws_bytes, n * 6 * sizeof(double) + 64);
+        if (rc != BHG_OK) return rc;
+        d_end = (double *)c->d_endws;
+    } else {
+        d_end_dir = nullptr;
+    }
     char *wsb = (char *)c->d_ws;
     uint8_t *w_flags = (uint8_t *)(wsb + sz_ws);
     uint32_t *w_steps = (uint32_t *)(wsb + sz_ws + sz_flags);
@@ -478,6 +492,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.k0 = d_k0;
     a.x0 = d_x0;
     a.end = d_end;
+    // (Kerr end states are converted from Boyer-Lindquist by a pass over whole records: directions are split off after it)
+    a.end_dir = p->rhs_form == BHG_RHS_KERR_BL ? nullptr : d_end_dir;
     a.ws = (double *)c->d_ws;
     a.flags = d_flags ? d_flags : w_flags;
     a.n_steps = d_n_steps ? d_n_steps : w_steps;
@@ -567,7 +583,10 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
     c->ev_valid = c->profiling;
     c->last_launch[3] = 1;
-    if (p->rhs_form == BHG_RHS_KERR_BL) HIP_TRY(bhg::launch_kerr_finalize(a, s));
+    if (p->rhs_form == BHG_RHS_KERR_BL) {
+        HIP_TRY(bhg::launch_kerr_finalize(a, s));
+        if (d_end_dir) HIP_TRY(bhg::launch_split_end(d_end, n, nullptr, d_end_dir, s));
+    }
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;
@@ -584,6 +603,15 @@ int bhg_trace_device(bhg_context *c, const bhg_params *p, const double *x0_share
 {
     return trace_device_impl(c, p, nullptr, 0, x0_shared, d_x0, d_k0, n, d_end, d_flags, d_n_steps, d_n_accepted, nullptr,
                              stream);
+}
+
+int bhg_trace_dir_device(bhg_context *c, const bhg_params *p, const double *x0_shared, const double *d_x0,
+                         const double *d_k0, size_t n, double *d_end_dir, uint8_t *d_flags, uint32_t *d_n_steps,
+                         uint32_t *d_n_accepted, void *stream)
+{
+    if (n && !d_end_dir) return fail(BHG_E_INVALID, "end_dir is NULL");
+    return trace_device_impl(c, p, nullptr, 0, x0_shared, d_x0, d_k0, n, nullptr, d_flags, d_n_steps, d_n_accepted, nullptr,
+                             stream, d_end_dir);
 }
 
 int bhg_trace_objects_device(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
@@ -645,7 +673,8 @@ int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, in
     }
     const bool upload = io.d_k0 == nullptr;
     const bool per_ray_x0 = io.h_x0 != nullptr;
-    const bool split = io.loc || io.dir;
+    const bool dir_only = io.dir && !io.end && !io.loc;   // the trace writes the directions itself: no records, no split pass
+    const bool split = (io.loc || io.dir) && !dir_only;
     // device arrays for the whole call (chunks are sub-ranges of each)
     const size_t in_bytes = upload ? n * 3 * sizeof(double) * (per_ray_x0 ? 2 : 1) : 0;
     const size_t off_flags = n * 6 * sizeof(double);
@@ -654,7 +683,7 @@ int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, in
     const size_t off_obj = off_acc + n * sizeof(uint32_t);
     const size_t off_loc = (off_obj + n + 7) & ~size_t(7);
     const size_t off_dir = off_loc + (split ? n * 3 * sizeof(double) : 0);
-    const size_t out_bytes = off_dir + (split ? n * 3 * sizeof(double) : 0);
+    const size_t out_bytes = off_dir + ((split || dir_only) ? n * 3 * sizeof(double) : 0);
     int rc = BHG_OK;
     if (upload) {
         rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
@@ -736,8 +765,8 @@ int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, in
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_in[slot], 0));
         }
         rc = trace_device_impl(c, p, spheres, n_spheres, io.x0_shared, per_ray_x0 ? d_x0 + off * 3 : nullptr, d_k0 + off * 3, m,
-                               d_end + off * 6, d_flags + off, d_steps + off, d_acc + off, d_obj ? d_obj + off : nullptr,
-                               c->stream);
+                               dir_only ? nullptr : d_end + off * 6, d_flags + off, d_steps + off, d_acc + off,
+                               d_obj ? d_obj + off : nullptr, c->stream, dir_only ? d_dir + off * 3 : nullptr);
         if (rc != BHG_OK) return rc;
         if (split)
             HIP_TRY(bhg::launch_split_end(d_end + off * 6, m, io.loc ? d_loc + off * 3 : nullptr, io.dir ? d_dir + off * 3 : nullptr,
@@ -956,6 +985,31 @@ int bhg_shade_device(bhg_context *c, const double *d_end, const uint8_t *d_flags
     a.flags = d_flags;
     a.sky = d_sky;
     a.rgba = d_rgba;
+    a.n_pixels = n_pixels;
+    a.samples = samples;
+    a.sky_w = sky_w;
+    a.sky_h = sky_h;
+    HIP_TRY(bhg::launch_shade(a, (hipStream_t)stream));
+    return BHG_OK;
+}
+
+int bhg_shade_dir_device(bhg_context *c, const double *d_end_dir, const uint8_t *d_flags, size_t n_pixels, int32_t samples,
+                         const float *d_sky, int32_t sky_w, int32_t sky_h, double *d_rgba, float *d_rgba_f32,
+                         const int64_t *d_scatter, void *stream)
+{
+    if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
+    if (samples <= 0 || sky_w <= 0 || sky_h <= 0) return fail(BHG_E_INVALID, "samples, sky_w, sky_h must be > 0");
+    if (n_pixels == 0) return BHG_OK;
+    if (!d_end_dir || !d_flags || !d_sky || (!d_rgba && !d_rgba_f32)) return fail(BHG_E_INVALID, "NULL device pointer");
+    ENTER_DEVICE(c->device);
+    bhg::ShadeArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.dir = d_end_dir;
+    a.flags = d_flags;
+    a.sky = d_sky;
+    a.rgba = d_rgba;
+    a.rgba_f32 = d_rgba_f32;
+    a.scatter = d_scatter;
     a.n_pixels = n_pixels;
     a.samples = samples;
     a.sky_w = sky_w;

@@ -200,8 +200,11 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
     double acc[3] = {0.0, 0.0, 0.0};
     // software pipeline: the next sample's flag and exit direction are in flight while this sample's
     // acos / atan2 / texel gathers run (the samples of a pixel are n_pixels records apart)
+    // exit directions: the second half of the end records, or (direction-only traces of sky frames) an array of their own
+    const double *dsrc = A.dir ? A.dir : A.end + 3;
+    const uint64_t dstride = A.dir ? 3 : 6;
     uint8_t fl_next = A.flags[p];
-    double dn0 = A.end[p * 6 + 3], dn1 = A.end[p * 6 + 4], dn2 = A.end[p * 6 + 5];
+    double dn0 = dsrc[p * dstride], dn1 = dsrc[p * dstride + 1], dn2 = dsrc[p * dstride + 2];
     for (int s = 0; s < A.samples; s++) {
         const uint64_t i = (uint64_t)s * A.n_pixels + p;
         const uint8_t fl = fl_next;
@@ -209,13 +212,13 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
         if (s + 1 < A.samples) {
             const uint64_t in = i + A.n_pixels;
             fl_next = A.flags[in];
-            dn0 = A.end[in * 6 + 3];
-            dn1 = A.end[in * 6 + 4];
-            dn2 = A.end[in * 6 + 5];
+            dn0 = dsrc[in * dstride];
+            dn1 = dsrc[in * dstride + 1];
+            dn2 = dsrc[in * dstride + 2];
         }
         if (fl & BHG_FLAG_HIT_HORIZON_) continue;  // black (:242-244)
         const double *e = A.end + i * 6;
-        if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0) {
+        if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0 && A.end) {
             double rgb[3];
             disk_colour(A, e, rgb);
             acc[0] += rgb[0];
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
             acc[2] += rgb[2];
             continue;
         }
-        if (fl == BHG_FLAG_HIT_OBJECT_ && A.object_id) {
+        if (fl == BHG_FLAG_HIT_OBJECT_ && A.object_id && A.end) {
             double rgb[3];
             object_colour(A, e, (int)A.object_id[i], rgb);
             acc[0] += rgb[0];

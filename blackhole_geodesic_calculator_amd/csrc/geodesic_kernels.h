@@ -42,6 +42,8 @@ struct TraceArgs {
     double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
     double h_fixed;
     // ---- chunk 2: parking (in the step loop's event branch), then the rare paths
+    double *end_dir;             // nullptr, or [n][3]: FINAL states are written as their direction half only, here (end then
+                                 // only holds the parked / resume records of rays that need them: a workspace)
     double *ws;                  // [n][ws_stride] per-ray records: prepare {a0, h0, r0, 0, E, L}, park {a1, t, h, h_next, E, L}, resume {a, h, r, t, E, L}
                                  // (park / resume records are written and read back by ONE wavefront of the trace kernel)
     uint32_t max_steps;
@@ -78,7 +80,8 @@ struct RaygenArgs {
 
 // shading + per-pixel multisample mean (frame_kernels.hip)
 struct ShadeArgs {
-    const double *end;     // [S*n_pixels][6]
+    const double *end;     // [S*n_pixels][6], or nullptr when dir is given
+    const double *dir;     // [S*n_pixels][3] exit directions alone (sky-only scenes), or nullptr
     const uint8_t *flags;  // [S*n_pixels]
     const float *sky;      // [sky_h][sky_w][4] RGBA float32, equirectangular
     double *rgba;          // [n_pixels][4] fp64, or nullptr

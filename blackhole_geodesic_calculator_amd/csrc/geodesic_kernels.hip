@@ -693,6 +693,24 @@ struct Wave {
 #endif
 };
 
+// A ray's FINAL state: the whole record end[idx] = {x, v}, or -- direction-only calls (A.end_dir; sky frames read
+// nothing else) -- v alone into end_dir[idx]: 24 instead of 48 bytes written per ray and read by the shade kernel.
+__device__ __forceinline__ void store_end_state(const TraceArgs &A, uint32_t idx, const double x[3], const double v[3])
+{
+    if (A.end_dir) {  // (wave-uniform)
+        double *e = A.end_dir + (size_t)idx * 3;
+        e[0] = v[0];
+        e[1] = v[1];
+        e[2] = v[2];
+        return;
+    }
+    double *e = A.end + (size_t)idx * 6;
+    // 48 contiguous bytes per lane: three 16-byte stores
+    reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
+    reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
+    reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
+}
+
 __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
                                              const double v[3], uint32_t flags, uint32_t n_att,
                                              uint32_t n_acc)
@@ -701,11 +719,7 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     // instead of six class tests and their combination (the state is O(1e2) at most, the sum cannot overflow)
     const bool bad = !isfinite(((x[0] + x[1]) + (x[2] + v[0])) + (v[1] + v[2]));
     if (bad) flags |= BHG_FLAG_NAN_;
-    double *e = A.end + (size_t)idx * 6;
-    // 48 contiguous bytes per lane: three 16-byte stores
-    reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
-    reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
-    reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
+    store_end_state(A, idx, x, v);
     // (flags, n_steps, n_accepted are never null here: the C-ABI layer points them at its workspace when the caller
     // passes NULL -- three pointer tests less in a path that runs in nearly every iteration of the step loop)
     A.flags[idx] = (uint8_t)flags;
@@ -720,10 +734,7 @@ __device__ __forceinline__ void store_event_result(const TraceArgs &A, uint32_t 
     bool bad = !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(v[0]) &&
                  isfinite(v[1]) && isfinite(v[2]));
     if (bad) flags |= BHG_FLAG_NAN_;
-    double *e = A.end + (size_t)idx * 6;
-    reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
-    reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
-    reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
+    store_end_state(A, idx, x, v);
     A.flags[idx] = (uint8_t)flags;
 }
 

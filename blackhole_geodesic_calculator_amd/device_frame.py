@@ -31,8 +31,15 @@ class DeviceFrame:
 
     def __init__(self, ctx: _ffi.Context, width, height, samples, *, fov_x=1.0, fov_y=1.0, sampling_seed=42.0,
                  origin=(1e-4, 0.0, 30.0), rotation_euler=(0.0, 0.0, 0.0), bh_loc=(0.0, 0.0, 0.0), pixels=None,
-                 jitter=None, device=None, buffers=None):
+                 jitter=None, device=None, buffers=None, directions_only=False):
+        """directions_only: a frame without disk or objects reads only the exit DIRECTIONS of its rays (the sky
+        lookup, :366-378) -- trace() then has the kernel write those alone (d_dir [n, 3], bhg_trace_dir_device: half
+        the bytes written per ray and read by the shade kernel; d_end is not filled) and shade() / shade_f32() read
+        them.  With a disk or objects set the frame falls back to whole end records by itself."""
         self.ctx = ctx
+        self.directions_only = bool(directions_only)
+        self.d_dir = None
+        self._dir_traced = False
         self.W, self.H, self.S = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
         self.origin = np.asarray(origin, dtype=np.float64) - np.asarray(bh_loc, dtype=np.float64)  # :278
@@ -115,6 +122,14 @@ class DeviceFrame:
             params = _copy_params(params)
             params.order_blocks = self.S
         has_obj = self.spheres is not None and len(self.spheres) > 0
+        self._dir_traced = self.directions_only and not has_obj and self.disk is None and not (params.disk_r_out > 0.0)
+        if self._dir_traced:
+            if self.d_dir is None:
+                self.d_dir = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
+            self.ctx.trace_dir_device(params, self.n, self.d_k0.data_ptr(), self.d_dir.data_ptr(), x0_shared=self.origin,
+                                      d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
+                                      d_n_accepted=self.d_acc.data_ptr(), stream=self._stream())
+            return
         self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), x0_shared=self.origin,
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
                               d_n_accepted=self.d_acc.data_ptr(), stream=self._stream(),
@@ -138,6 +153,10 @@ class DeviceFrame:
                                         d_object_id=0 if self.d_obj is None else self.d_obj.data_ptr(),
                                         stream=self._stream())
             return self.d_rgba
+        if self._dir_traced:
+            self.ctx.shade_dir_device(self.d_dir.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
+                                      self.sky_wh[0], self.sky_wh[1], d_rgba=self.d_rgba.data_ptr(), stream=self._stream())
+            return self.d_rgba
         self.ctx.shade_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
                               self.sky_wh[0], self.sky_wh[1], self.d_rgba.data_ptr(), stream=self._stream())
         return self.d_rgba
@@ -148,6 +167,11 @@ class DeviceFrame:
         if self.d_sky is None:
             raise RuntimeError("set_sky() first")
         assert out.dtype == torch.float32 and out.is_contiguous()
+        if self._dir_traced:
+            self.ctx.shade_dir_device(self.d_dir.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
+                                      self.sky_wh[0], self.sky_wh[1], d_rgba_f32=out.data_ptr(),
+                                      d_scatter=0 if scatter is None else scatter.data_ptr(), stream=self._stream())
+            return out
         self.ctx.shade_scene_f32_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.scene(),
                                         out.data_ptr(), d_object_id=0 if self.d_obj is None else self.d_obj.data_ptr(),
                                         d_scatter=0 if scatter is None else scatter.data_ptr(), stream=self._stream())

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 4
+#define BHG_ABI_VERSION 5
 
 /* return codes */
 #define BHG_OK 0
@@ -193,6 +193,16 @@ int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_sha
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
 
+/* The same call for a caller that consumes only the DIRECTION half of the end states -- what a sky frame reads of
+ * spacetime_ray_cast's return values (end_dir, RelativisticRenderEngine.py:308, :366-378; the flags say which rays
+ * hit the hole): d_end_dir [n][3].  The trace kernel writes 24 instead of 48 bytes per ray and bhg_shade_dir_device
+ * reads as many; bit-for-bit the directions bhg_trace_device gives.  (Kerr: traced into an internal record array and
+ * split off -- same result, no saving.)  bhg_rays_trace takes this path by itself when only end_dir (and flags,
+ * counts) are asked for. */
+int bhg_trace_dir_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared, const double *d_x0,
+                         const double *d_k0, size_t n, double *d_end_dir, uint8_t *d_flags, uint32_t *d_n_steps,
+                         uint32_t *d_n_accepted, void *stream);
+
 /* Objects inside the curved region (the reference holds only the stub at
  * RelativisticRenderEngine.py:304-305, "hit = False", and README.md:225 lists it as a goal): up to
  * BHG_MAX_SPHERES spheres, HOST array spheres [n_spheres][4] = {cx, cy, cz, radius} in BH-centred
@@ -258,6 +268,14 @@ int bhg_shade_scene_device(bhg_context *ctx, const double *d_end, const uint8_t 
 int bhg_shade_scene_f32_device(bhg_context *ctx, const double *d_end, const uint8_t *d_flags,
                                const int8_t *d_object_id, size_t n_pixels, int32_t samples, const bhg_scene *scene,
                                float *d_rgba_f32, const int64_t *d_scatter, void *stream);
+
+/* Sky-only shading + sample mean from exit directions alone (d_end_dir [samples*n_pixels][3] of bhg_trace_dir_device):
+ * the same kernel, same filter and same bits as bhg_shade_device / bhg_shade_scene_f32_device on the records those
+ * directions are halves of.  d_rgba (fp64 [n_pixels][4]) and / or d_rgba_f32 (float RGBA, optionally scattered by
+ * d_scatter) -- either may be NULL, not both. */
+int bhg_shade_dir_device(bhg_context *ctx, const double *d_end_dir, const uint8_t *d_flags, size_t n_pixels,
+                         int32_t samples, const float *d_sky, int32_t sky_w, int32_t sky_h, double *d_rgba,
+                         float *d_rgba_f32, const int64_t *d_scatter, void *stream);
 
 /* Frame end on the root GPU of a sharded frame: the ranks' float RGBA slabs, gathered into one block
  * d_slabs [n_ranks * slab_pixels][4], are put into frame order, d_frame[p] = d_slabs[d_index[p]] for the n_pixels

@@ -262,3 +262,42 @@ def test_c_example_runs_on_the_gpu(tmp_path):
     head = r.stdout.splitlines()[0]
     assert "6144 rays" in head and " 0 left the region" in head   # curve_end 60 ends the far-side rays before r = 40
     assert "#" in r.stdout and "o" in r.stdout.split("\n", 1)[1]
+
+
+@pytest.mark.parametrize("kw", [dict(r_s=1.0, lambda_end=50.0), dict(r_s=1.0, lambda_end=80.0, r_exit=35.0),
+                                dict(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45),
+                                dict(r_s=1.0, lambda_end=40.0, method=1, h_fixed=0.1)])
+def test_direction_only_trace_and_shade_match_whole_records(ctx, kw):
+    """bhg_trace_dir_device writes the direction half of the end states alone and bhg_shade_dir_device reads it: the
+    directions, flags, step counts and the shaded frame (fp64 and float32) are bit-for-bit those of the whole-record
+    calls -- with the exit sphere (events located in the kernel), Kerr (split off after the finalize pass) and RK4."""
+    import torch
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
+    W, H, S = 96, 64, 3
+    full = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6)
+    dirs = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, directions_only=True)
+    sky = synthetic_sky(256, 128, seed=2)
+    p = _ffi.make_params(**kw)
+    out = []
+    for fr in (full, dirs):
+        fr.set_sky(sky)
+        fr.generate_rays()
+        fr.d_end.fill_(float("nan"))
+        fr.trace(p)
+        rgba = fr.shade().clone()
+        f32 = torch.zeros((fr.P, 4), dtype=torch.float32, device="cuda")
+        fr.shade_f32(f32)
+        torch.cuda.synchronize()
+        out.append((rgba, f32, fr.d_flags.clone(), fr.d_steps.clone(), fr.d_acc.clone()))
+    assert dirs._dir_traced and not full._dir_traced
+    assert torch.isnan(dirs.d_end).all()                       # the record array of the direction-only frame is not touched
+    fin = ~torch.isnan(full.d_end[:, 3:6]).any(1)
+    assert torch.equal(dirs.d_dir[fin], full.d_end[:, 3:6][fin]) and torch.equal(torch.isnan(dirs.d_dir), torch.isnan(full.d_end[:, 3:6]))
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
+    assert int((out[0][2] & 1).sum()) > 0 and int((out[0][2] & 1).sum()) < full.n
+    # a frame with a disk needs the end locations: the option falls back to whole records by itself
+    dirs.set_disk(4.5, 10.5)
+    dirs.trace(_ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=35.0, disk_r_in=4.5, disk_r_out=10.5))
+    assert not dirs._dir_traced
