@@ -536,15 +536,18 @@ constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 // Does the accepted step x0 -> x1 possibly enter one of the object spheres?  A ray outside sphere j at the
 // step's start enters it if the step ends inside, or if the chord between the step ends passes through
 // (closest point of the chord at s* = b / cc in (0, 1) with squared distance d0 - b^2 / cc < rho^2, written
-// without the division).  The CPU checker states the same expressions in the same order.
+// without the division).
 __device__ __forceinline__ bool sphere_candidate(const double sp[4], const double x0[3], const double x1[3], double &bb,
                                                  double &cc, bool &ends_inside)
 {
+    // (sums of products as FMA chains: this test runs for every lane in every step of an object frame; the CPU
+    // checker rounds each product -- the candidate decision could only differ for a chord grazing the sphere within
+    // an ulp, and what a candidate is worth is decided by the root search on the dense output either way)
     const double rho2 = sp[3] * sp[3];
     const double a0[3] = {x0[0] - sp[0], x0[1] - sp[1], x0[2] - sp[2]};
     const double a1[3] = {x1[0] - sp[0], x1[1] - sp[1], x1[2] - sp[2]};
-    const double d0 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2];
-    const double d1 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+    const double d0 = __builtin_fma(a0[2], a0[2], __builtin_fma(a0[1], a0[1], a0[0] * a0[0]));
+    const double d1 = __builtin_fma(a1[2], a1[2], __builtin_fma(a1[1], a1[1], a1[0] * a1[0]));
     bb = cc = 0.0;
     ends_inside = false;
     if (!(d0 > rho2)) return false;
@@ -553,8 +556,8 @@ __device__ __forceinline__ bool sphere_candidate(const double sp[4], const doubl
         return true;
     }
     const double ch[3] = {a1[0] - a0[0], a1[1] - a0[1], a1[2] - a0[2]};
-    cc = ch[0] * ch[0] + ch[1] * ch[1] + ch[2] * ch[2];
-    bb = -(a0[0] * ch[0] + a0[1] * ch[1] + a0[2] * ch[2]);
+    cc = __builtin_fma(ch[2], ch[2], __builtin_fma(ch[1], ch[1], ch[0] * ch[0]));
+    bb = -__builtin_fma(a0[2], ch[2], __builtin_fma(a0[1], ch[1], a0[0] * ch[0]));
     return bb > 0.0 && bb < cc && (d0 - rho2) * cc < bb * bb;
 }
 
