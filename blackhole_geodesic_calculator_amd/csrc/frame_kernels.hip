@@ -77,9 +77,9 @@ __device__ __forceinline__ void sky_lookup(const float *sky, int TW, int TH, dou
     const float4 t10 = reinterpret_cast<const float4 *>(sky)[(long)y1 * TW + x0];
     const float4 t11 = reinterpret_cast<const float4 *>(sky)[(long)y1 * TW + x1];
     const double w00 = (1.0 - ax) * (1.0 - ay), w01 = ax * (1.0 - ay), w10 = (1.0 - ax) * ay, w11 = ax * ay;
-    rgb[0] = w00 * t00.x + w01 * t01.x + w10 * t10.x + w11 * t11.x;
-    rgb[1] = w00 * t00.y + w01 * t01.y + w10 * t10.y + w11 * t11.y;
-    rgb[2] = w00 * t00.z + w01 * t01.z + w10 * t10.z + w11 * t11.z;
+    rgb[0] = __builtin_fma(w11, (double)t11.x, __builtin_fma(w10, (double)t10.x, __builtin_fma(w01, (double)t01.x, w00 * (double)t00.x)));
+    rgb[1] = __builtin_fma(w11, (double)t11.y, __builtin_fma(w10, (double)t10.y, __builtin_fma(w01, (double)t01.y, w00 * (double)t00.y)));
+    rgb[2] = __builtin_fma(w11, (double)t11.z, __builtin_fma(w10, (double)t10.z, __builtin_fma(w01, (double)t01.z, w00 * (double)t00.z)));
 }
 
 // 1/x: v_rcp_f64 + one cubic Newton step (about an ulp), as in the trace kernels
