@@ -415,7 +415,8 @@ def pipelined_figure(ctx, fr, params, a, device):
     buf = (fr.d_k0, torch.empty((n, 6), dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda"),
            torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"))
     fr2 = DeviceFrame(ctx2, fr.W, fr.H, fr.S, fov_x=fr.fov_x, fov_y=fr.fov_y, origin=fr.origin, pixels=fr.d_pixels.cpu().numpy(),
-                      jitter=np.zeros(2), buffers=buf)          # same rays (shared d_k0), its own result buffers
+                      jitter=np.zeros(2), buffers=buf,           # same rays (shared d_k0), its own result buffers
+                      directions_only=fr.directions_only)
     fr2.d_sky, fr2.sky_wh = fr.d_sky, fr.sky_wh
     frames = (fr, fr2)
     streams = (torch.cuda.Stream(), torch.cuda.Stream())
