@@ -301,3 +301,29 @@ def test_direction_only_trace_and_shade_match_whole_records(ctx, kw):
     dirs.set_disk(4.5, 10.5)
     dirs.trace(_ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=35.0, disk_r_in=4.5, disk_r_out=10.5))
     assert not dirs._dir_traced
+
+
+@pytest.mark.parametrize("n", [0, 1, 65, 4099])
+def test_direction_only_entry_point_ragged_sizes_and_per_ray_origins(ctx, n):
+    """bhg_trace_dir_device on ragged sizes with per-ray origins: the directions of bhg_trace_device, bit for bit;
+    n = 0 is a no-op; a NULL direction array is refused."""
+    import torch
+    from blackhole_geodesic_calculator_amd import _ffi
+    rng = np.random.default_rng(n)
+    x0 = rng.normal(size=(max(n, 1), 3)) * 6.0 + np.array([0.0, 0.0, 25.0])
+    k0 = -x0 / np.linalg.norm(x0, axis=1)[:, None] + rng.normal(size=x0.shape) * 0.15
+    k0 /= np.linalg.norm(k0, axis=1)[:, None]
+    d_x0, d_k0 = torch.as_tensor(x0).cuda(), torch.as_tensor(k0).cuda()
+    p = _ffi.make_params(r_s=1.0, lambda_end=60.0, r_exit=45.0)
+    end = torch.full((max(n, 1), 6), float("nan"), dtype=torch.float64, device="cuda")
+    dirs = torch.full((max(n, 1), 3), float("nan"), dtype=torch.float64, device="cuda")
+    fl = [torch.full((max(n, 1),), 255, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    ctx.trace_device(p, n, d_k0.data_ptr(), end.data_ptr(), d_x0=d_x0.data_ptr(), d_flags=fl[0].data_ptr())
+    ctx.trace_dir_device(p, n, d_k0.data_ptr(), dirs.data_ptr(), d_x0=d_x0.data_ptr(), d_flags=fl[1].data_ptr())
+    torch.cuda.synchronize()
+    if n == 0:
+        assert torch.isnan(dirs).all() and int(fl[1][0]) == 255
+    else:
+        assert torch.equal(fl[0], fl[1]) and torch.equal(dirs, end[:, 3:6])
+        with pytest.raises(_ffi.BhgError):
+            ctx.trace_dir_device(p, n, d_k0.data_ptr(), 0, d_x0=d_x0.data_ptr())
