@@ -677,7 +677,7 @@ int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, in
     const bool split = (io.loc || io.dir) && !dir_only;
     // device arrays for the whole call (chunks are sub-ranges of each)
     const size_t in_bytes = upload ? n * 3 * sizeof(double) * (per_ray_x0 ? 2 : 1) : 0;
-    const size_t off_flags = n * 6 * sizeof(double);
+    const size_t off_flags = dir_only ? 0 : n * 6 * sizeof(double);   // (no record array in a direction-only call)
     const size_t off_steps = off_flags + ((n + 7) & ~size_t(7));
     const size_t off_acc = off_steps + n * sizeof(uint32_t);
     const size_t off_obj = off_acc + n * sizeof(uint32_t);
