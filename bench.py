@@ -90,8 +90,41 @@ def grid_for(n):
     return nx, ny
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves, as CHILD processes of a
+    parent that has not touched the GPU (never an exec), the way the driver would --
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    -- relay their output, print rank 0's JSON line last and exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:   # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for line in p.stdout:
+        s = line.strip()
+        if s.startswith("{") and s.endswith("}") and '"metric"' in s:
+            last_json = s           # held back: it must be the LAST line of our stdout
+        else:
+            sys.stdout.write(line)
+    rc = p.wait()
+    sys.stdout.flush()
+    if last_json is not None:
+        print(last_json, flush=True)
+    if rc == 0 and last_json is None:
+        rc = 1
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a.gpus)     # (before anything touches the GPU)
     import torch
     import torch.distributed as dist
 

@@ -272,7 +272,8 @@ class _PinnedBlock:
 
     def __init__(self, nbytes, pool):
         p = C.c_void_p()
-        _check(load().bhg_host_alloc(None, int(nbytes), C.byref(p)))
+        # (the owning context: the allocation is made with ITS device current, not device 0)
+        _check(load().bhg_host_alloc(pool.ctx_handle() if pool is not None else None, int(nbytes), C.byref(p)))
         self.ptr, self.nbytes, self.pool = p.value, int(nbytes), pool
 
     def release(self):
@@ -285,16 +286,21 @@ class PinnedPool:
     """Page-locked result arrays for the host-buffer calls (Context.trace): numpy arrays over bhg_host_alloc
     memory, so the device's copy engines write results straight into what the caller gets -- no staging copy."""
 
-    def __init__(self, max_free_bytes=2 << 30):
+    def __init__(self, max_free_bytes=2 << 30, ctx=None):
         self._free = {}          # nbytes -> [blocks]
         self._free_bytes = 0
         self.max_free_bytes = int(max_free_bytes)
+        self._ctx = ctx          # the owning Context (None: allocations are made on the current device)
+        self._closed = False
+
+    def ctx_handle(self):
+        return getattr(self._ctx, "_h", None) if self._ctx is not None else None
 
     def _give_back(self, blk):
         if blk.ptr is None:
             return
-        if self._free_bytes + blk.nbytes > self.max_free_bytes:
-            blk.release()
+        if self._closed or self._free_bytes + blk.nbytes > self.max_free_bytes:
+            blk.release()        # (a block that comes home after Context.close() is freed, not pooled for nobody)
             return
         self._free.setdefault(blk.nbytes, []).append(blk)
         self._free_bytes += blk.nbytes
@@ -311,7 +317,12 @@ class PinnedPool:
             blk = lst.pop()
             self._free_bytes -= blk.nbytes
         else:
-            blk = _PinnedBlock(size, self)
+            try:
+                blk = _PinnedBlock(size, self)
+            except BhgError:
+                # page-locking failed (pin limit, a 67-M-ray frame): a pageable array still works, it crosses the
+                # library's staging ring instead of being written by the copy engines directly
+                return np.empty(shape, dtype)
         buf = (C.c_char * n).from_address(blk.ptr)
         weakref.finalize(buf, PinnedPool._give_back, self, blk)   # the array's base chain holds `buf`
         return np.frombuffer(buf, dtype=dtype).reshape(shape)
@@ -322,6 +333,10 @@ class PinnedPool:
                 blk.release()
         self._free.clear()
         self._free_bytes = 0
+
+    def close(self):
+        self.clear()
+        self._closed = True
 
 
 class RaySet:
@@ -390,11 +405,11 @@ class Context:
         _check(L.bhg_create(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
-        self.pinned = PinnedPool()
+        self.pinned = PinnedPool(ctx=self)
 
     def close(self):
         if getattr(self, "_h", None):
-            self.pinned.clear()
+            self.pinned.close()
             load().bhg_destroy(self._h)
             self._h = None
 

@@ -671,6 +671,18 @@ int pipeline_impl(bhg_context *c, const bhg_params *p, const double *spheres, in
             HIP_TRY(hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
         }
     }
+    // Whatever way this call ends, nothing of it may still be running when it returns: copies and kernels of earlier
+    // chunks DMA into the caller's page-locked arrays and into the pinned ring, and the next call's ensure() may free
+    // buffers they use.  (The success path has waited already; the guard then costs three no-op synchronisations.)
+    struct StreamsQuiet {
+        bhg_context *c;
+        ~StreamsQuiet()
+        {
+            if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+            if (c->stream) (void)hipStreamSynchronize(c->stream);
+            if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+        }
+    } quiet{c};
     const bool upload = io.d_k0 == nullptr;
     const bool per_ray_x0 = io.h_x0 != nullptr;
     const bool dir_only = io.dir && !io.end && !io.loc;   // the trace writes the directions itself: no records, no split pass
@@ -926,7 +938,11 @@ int bhg_host_alloc(bhg_context *c, size_t bytes, void **out)
     if (!out) return fail(BHG_E_INVALID, "out is NULL");
     *out = nullptr;
     if (bytes == 0) return BHG_OK;
-    DeviceGuard _device_guard(c ? c->device : 0);
+    if (c) {   // with the owning context's device current; without a context: whatever device the caller is on
+        ENTER_DEVICE(c->device);
+        HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+        return BHG_OK;
+    }
     HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return BHG_OK;
 }
@@ -1201,7 +1217,7 @@ int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const
     double *dx = (double *)c->d_in, *dk = dx + 3 * n;
     HIP_TRY(hipMemcpyAsync(dx, x, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dk, k, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(bhg::launch_accel(dx, dk, p->r_s, n, (double *)c->d_out, p->rhs_form, c->stream));
+    HIP_TRY(bhg::launch_accel(dx, dk, p->r_s, p->spin, n, (double *)c->d_out, p->rhs_form, c->stream));
     HIP_TRY(hipMemcpyAsync(acc, c->d_out, n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BHG_OK;

@@ -118,7 +118,9 @@ hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu);
 hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
-hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
+// rhs = Kerr: x, k and acc are Boyer-Lindquist (r, theta, phi) triples, E and L fixed by the null condition at each point
+hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, int rhs,
                         hipStream_t s);
+hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, hipStream_t s);
 
 }  // namespace bhg

@@ -1893,6 +1893,43 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 }
 
 #ifdef BHG_TU_KERR
+// Acceleration probe for the Boyer-Lindquist form: x = (r, theta, phi), k = d/dlambda of those; the Killing constants
+// E = -k_t, L = k_phi from the null condition AT THE POINT (the formula the prepare pass applies at the camera), then the
+// right-hand side the trace kernels run (accel_kerr_bl).  acc is d^2 (r, theta, phi) / dlambda^2.
+__global__ void accel_kerr_kernel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double q[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]}, u[3] = {k[3 * i], k[3 * i + 1], k[3 * i + 2]};
+    Metric met;
+    met.r_s = r_s;
+    met.M = 0.5 * r_s;
+    met.a = spin;
+    const double a = met.a, M = met.M, r = q[0];
+    const double st = sin(q[1]), ct = cos(q[1]), s2 = st * st, c2 = ct * ct;
+    const double Sig = r * r + a * a * c2, Del = r * r - 2.0 * M * r + a * a;
+    const double gtt = -(1.0 - 2.0 * M * r / Sig), gtp = -2.0 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
+    const double gpp = (r * r + a * a + 2.0 * M * a * a * r * s2 / Sig) * s2;
+    const double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+    const double B = gtp * u[2];
+    const double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
+    met.E = -(gtt * kt + gtp * u[2]);
+    met.L = gtp * kt + gpp * u[2];
+    double a3[3], rr;
+    accel_kerr_bl(q, u, met, a3, rr);
+    acc[3 * i] = a3[0];
+    acc[3 * i + 1] = a3[1];
+    acc[3 * i + 2] = a3[2];
+}
+
+hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, hipStream_t s)
+{
+    const int grid = (int)((n + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(accel_kerr_kernel, dim3(grid), dim3(256), 0, s, x, k, r_s, spin, n, acc);
+    return hipGetLastError();
+}
+
 // Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into
 // the Cartesian frame the boundary speaks (rays that started inside were stored Cartesian already).
 __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
@@ -2229,9 +2266,10 @@ hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
                                    : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }
 
-hipError_t launch_accel(const double *x, const double *k, double r_s, uint64_t n, double *acc, int rhs,
+hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, int rhs,
                         hipStream_t s)
 {
+    if (rhs == BHG_RHS_KERR_BL_) return launch_accel_kerr(x, k, r_s, spin, n, acc, s);
     int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
     if (rhs == BHG_RHS_REDUCED_)

@@ -40,6 +40,7 @@ class DeviceFrame:
         self.directions_only = bool(directions_only)
         self.d_dir = None
         self._dir_traced = False
+        self._traced = None      # what the last trace wrote: None (nothing usable), "dir" or "end"
         self.W, self.H, self.S = int(width), int(height), int(samples)
         self.fov_x, self.fov_y = float(fov_x), float(fov_y)
         self.origin = np.asarray(origin, dtype=np.float64) - np.asarray(bh_loc, dtype=np.float64)  # :278
@@ -62,7 +63,8 @@ class DeviceFrame:
             assert self.d_k0.shape == (n, 3) and self.d_end.shape == (n, 6) and self.d_flags.numel() == n
         else:
             self.d_k0 = torch.empty((n, 3), dtype=torch.float64, device=self.dev)
-            self.d_end = torch.empty((n, 6), dtype=torch.float64, device=self.dev)
+            # whole end records: allocated when a full-record trace is first issued (a direction-only frame never needs them)
+            self.d_end = None if self.directions_only else torch.empty((n, 6), dtype=torch.float64, device=self.dev)
             self.d_flags = torch.empty(n, dtype=torch.uint8, device=self.dev)
             self.d_steps = torch.empty(n, dtype=torch.int32, device=self.dev)
             self.d_acc = torch.empty(n, dtype=torch.int32, device=self.dev)
@@ -93,6 +95,7 @@ class DeviceFrame:
         profile: disk_phase, disk_mean, disk_stddev, disk_intensity (:55-58).  The trace must be run with the
         same radii in its params (make_params(disk_r_in=..., disk_r_out=...))."""
         self.disk = (float(r_in), float(r_out))
+        self._traced = None      # the scene changed: what the last trace wrote no longer matches it
         self.disk_profile.update(profile)
         if texture_rgba_f32 is not None:
             tex = np.ascontiguousarray(texture_rgba_f32, dtype=np.float32)
@@ -103,7 +106,10 @@ class DeviceFrame:
         """Object spheres [[cx, cy, cz, radius]] (BH-centred), their colours and the point lamps
         [[x, y, z, intensity]] that light them.  Cheap to call per frame (an animation moves them): the
         values travel as kernel arguments."""
-        self.spheres = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+        spheres = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
+        if (self.spheres is None or len(self.spheres) == 0) != (len(spheres) == 0):
+            self._traced = None  # objects appeared / went away: the next shade needs a trace in the matching form
+        self.spheres = spheres
         self.sphere_rgb = sphere_rgb
         self.lamps = lamps
         if self.d_obj is None:
@@ -123,6 +129,7 @@ class DeviceFrame:
             params.order_blocks = self.S
         has_obj = self.spheres is not None and len(self.spheres) > 0
         self._dir_traced = self.directions_only and not has_obj and self.disk is None and not (params.disk_r_out > 0.0)
+        self._traced = "dir" if self._dir_traced else "end"
         if self._dir_traced:
             if self.d_dir is None:
                 self.d_dir = torch.empty((self.n, 3), dtype=torch.float64, device=self.dev)
@@ -130,6 +137,8 @@ class DeviceFrame:
                                       d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
                                       d_n_accepted=self.d_acc.data_ptr(), stream=self._stream())
             return
+        if self.d_end is None:
+            self.d_end = torch.empty((self.n, 6), dtype=torch.float64, device=self.dev)
         self.ctx.trace_device(params, self.n, self.d_k0.data_ptr(), self.d_end.data_ptr(), x0_shared=self.origin,
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
                               d_n_accepted=self.d_acc.data_ptr(), stream=self._stream(),
@@ -144,16 +153,28 @@ class DeviceFrame:
                                disk=self.disk, spheres=self.spheres, sphere_rgb=self.sphere_rgb, lamps=self.lamps,
                                **self.disk_profile)
 
-    def shade(self):
+    def _shade_form(self):
+        """ONE predicate for both shade paths: "dir" (exit directions, sky only) or "end" (whole records, any scene);
+        raises when the scene was changed after the last trace so that its output no longer fits."""
         if self.d_sky is None:
             raise RuntimeError("set_sky() first")
+        traced = self._traced
+        if traced is None:
+            raise RuntimeError("trace() first (the scene changed since the last trace, or nothing was traced yet)")
+        has_scene = self.disk is not None or (self.spheres is not None and len(self.spheres) > 0)
+        if traced == "dir" and has_scene:
+            raise RuntimeError("the last trace wrote exit directions only, but the frame now has a disk / objects: trace() again")
+        return traced
+
+    def shade(self):
+        form = self._shade_form()
         if self.disk is not None or (self.spheres is not None and len(self.spheres) > 0):
             self.ctx.shade_scene_device(self.d_end.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.scene(),
                                         self.d_rgba.data_ptr(),
                                         d_object_id=0 if self.d_obj is None else self.d_obj.data_ptr(),
                                         stream=self._stream())
             return self.d_rgba
-        if self._dir_traced:
+        if form == "dir":
             self.ctx.shade_dir_device(self.d_dir.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
                                       self.sky_wh[0], self.sky_wh[1], d_rgba=self.d_rgba.data_ptr(), stream=self._stream())
             return self.d_rgba
@@ -164,10 +185,9 @@ class DeviceFrame:
     def shade_f32(self, out, scatter=None):
         """Shade + sample mean written as float32 RGBA into `out` ([P, 4], or [H*W, 4] with scatter = this shard's
         flat pixel ids): what layer.rect takes, without the fp64 intermediate."""
-        if self.d_sky is None:
-            raise RuntimeError("set_sky() first")
+        form = self._shade_form()
         assert out.dtype == torch.float32 and out.is_contiguous()
-        if self._dir_traced:
+        if form == "dir":
             self.ctx.shade_dir_device(self.d_dir.data_ptr(), self.d_flags.data_ptr(), self.P, self.S, self.d_sky.data_ptr(),
                                       self.sky_wh[0], self.sky_wh[1], d_rgba_f32=out.data_ptr(),
                                       d_scatter=0 if scatter is None else scatter.data_ptr(), stream=self._stream())
@@ -234,6 +254,8 @@ class FrameBatch:
                               d_flags=self.d_flags.data_ptr(), d_n_steps=self.d_steps.data_ptr(),
                               d_n_accepted=self.d_acc.data_ptr(),
                               stream=torch.cuda.current_stream(self.dev).cuda_stream)
+        for f in self.frames:    # (whole records, whatever the members were constructed with)
+            f._dir_traced, f._traced = False, "end"
 
     def shade(self):
         return [f.shade() for f in self.frames]

@@ -284,7 +284,10 @@ int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const 
                                   float *d_frame, void *stream);
 
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
- * Lets tests compare the device RHS with the oracle's term by term. */
+ * Lets tests compare the device RHS with the oracle's term by term.  With rhs_form = BHG_RHS_KERR_BL the triples
+ * are Boyer-Lindquist: x = (r, theta, phi), k = d(r, theta, phi)/dlambda, acc = d^2(r, theta, phi)/dlambda^2, and the
+ * Killing constants E = -k_t, L = k_phi the right-hand side needs are fixed by the null condition at each point
+ * (the trace fixes them the same way at the camera); p->spin is the Kerr a. */
 int bhg_acceleration(bhg_context *ctx, const bhg_params *p, const double *x, const double *k,
                      size_t n, double *acc);
 

@@ -962,7 +962,27 @@ int bhgo_trajectory(const bhgo_params *p, const double *x0, int x0_shared, const
 int bhgo_acceleration(const bhgo_params *p, const double *x, const double *k, size_t n, double *acc)
 {
     for (size_t i = 0; i < n; i++) {
-        if (p->rhs_form == BHGO_RHS_REDUCED)
+        if (p->rhs_form == BHGO_RHS_KERR_BL) {
+            /* x = (r, theta, phi), k = d/dlambda of those; E, L from the null condition AT THIS POINT (as trace_one
+               fixes them at the camera), then the generated Boyer-Lindquist right-hand side; acc in (r, theta, phi) */
+            rayctx rc;
+            memset(&rc, 0, sizeof(rc));
+            const double M = 0.5 * p->r_s, a = p->spin;
+            const double *q = x + 3 * i, *u = k + 3 * i;
+            rc.kerr = 1;
+            rc.M = M;
+            rc.a = a;
+            double r = q[0], th = q[1], s2 = sin(th) * sin(th), c2 = cos(th) * cos(th);
+            double Sig = r * r + a * a * c2, Del = r * r - 2 * M * r + a * a;
+            double gtt = -(1 - 2 * M * r / Sig), gtp = -2 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
+            double gpp = (r * r + a * a + 2 * M * a * a * r * s2 / Sig) * s2;
+            double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+            double B = gtp * u[2];
+            double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
+            rc.E = -(gtt * kt + gtp * u[2]);
+            rc.L = gtp * kt + gpp * u[2];
+            acc_kerr_bl(&rc, q, u, acc + 3 * i);
+        } else if (p->rhs_form == BHGO_RHS_REDUCED)
             acc_reduced(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);
         else
             acc_christoffel(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);

@@ -1,7 +1,7 @@
 """Cost of putting 8 ranks' slabs into frame order on the root GPU: one index_select vs one index_put per rank."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import dist as bd
 W, H, T, world = 4096, 2048, 32, 8
 pix = [bd.rank_pixels(W, H, T, r, world) for r in range(world)]

@@ -1,7 +1,7 @@
 """Does the trace kernel speed up when launched back-to-back (DVFS ramp)?"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi
 from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
 ctx = _ffi.Context(0)

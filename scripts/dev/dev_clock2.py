@@ -1,7 +1,7 @@
 """Which property of the adaptive frame lowers the clock: kernel length or memory intensity?"""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi
 from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
 ctx = _ffi.Context(0)

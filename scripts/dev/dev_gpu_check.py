@@ -2,7 +2,7 @@
 import glob, json, os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi, camera_directions
 from oracle import oracle as oc
 

@@ -1,7 +1,7 @@
 """Reproduce one draw of tests/test_gpu_parity.py::test_randomised_kerr and print the per-class differences."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi
 from oracle import oracle as oc
 seed = int(sys.argv[1])

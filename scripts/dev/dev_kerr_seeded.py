@@ -1,7 +1,7 @@
 """The three calls of tests/test_gpu_parity.py::test_kerr_seeded_rays_and_rk4, with the rays that differ printed."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi
 from oracle import oracle as oc
 cam = np.array([4.0, -24.0, 13.0])

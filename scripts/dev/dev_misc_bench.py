@@ -1,7 +1,7 @@
 """Numbers for DESIGN.md: PCIe-inclusive host call, config-3 disk frames (five inclinations), RK4 / fine."""
 import os, sys, time, math
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi, camera_directions
 from blackhole_geodesic_calculator_amd.raygen import euler_xyz_matrix
 ctx = _ffi.Context(0)

@@ -1,7 +1,7 @@
 """Experiment: consecutive frames on two streams / two contexts (tails and small kernels overlap)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from blackhole_geodesic_calculator_amd import _ffi
 from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
 from blackhole_geodesic_calculator_amd.raygen import python_random_stream

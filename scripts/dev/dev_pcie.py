@@ -1,7 +1,7 @@
 """PCIe / host-copy speeds of the box next to the host-buffer call's figure (development aid)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 n = 5242880
 d = torch.empty(n * 6, dtype=torch.float64, device="cuda")
 hp = torch.empty(n * 6, dtype=torch.float64).pin_memory()

@@ -17,7 +17,7 @@ PY
 done
 if [ -f build/variants/libbhgeo_diag.so ]; then
 for w in frame exit disk orbit; do
-  BHGEO_LIB=$PWD/build/variants/libbhgeo_diag.so timeout 120 python scripts/dev_diag_run.py $w gpurun_out/diag_$w.bin > /dev/null 2>&1
+  BHGEO_LIB=$PWD/build/variants/libbhgeo_diag.so timeout 120 python scripts/dev/dev_diag_run.py $w gpurun_out/diag_$w.bin > /dev/null 2>&1
   echo "== $w"; python scripts/diag_analyze.py gpurun_out/diag_$w.bin | tail -3
 done
 fi

@@ -283,7 +283,8 @@ def test_direction_only_trace_and_shade_match_whole_records(ctx, kw):
     for fr in (full, dirs):
         fr.set_sky(sky)
         fr.generate_rays()
-        fr.d_end.fill_(float("nan"))
+        if fr.d_end is not None:
+            fr.d_end.fill_(float("nan"))
         fr.trace(p)
         rgba = fr.shade().clone()
         f32 = torch.zeros((fr.P, 4), dtype=torch.float32, device="cuda")
@@ -291,7 +292,7 @@ def test_direction_only_trace_and_shade_match_whole_records(ctx, kw):
         torch.cuda.synchronize()
         out.append((rgba, f32, fr.d_flags.clone(), fr.d_steps.clone(), fr.d_acc.clone()))
     assert dirs._dir_traced and not full._dir_traced
-    assert torch.isnan(dirs.d_end).all()                       # the record array of the direction-only frame is not touched
+    assert dirs.d_end is None                                  # a direction-only frame allocates no record array at all
     fin = ~torch.isnan(full.d_end[:, 3:6]).any(1)
     assert torch.equal(dirs.d_dir[fin], full.d_end[:, 3:6][fin]) and torch.equal(torch.isnan(dirs.d_dir), torch.isnan(full.d_end[:, 3:6]))
     for a, b in zip(out[0], out[1]):
@@ -299,8 +300,13 @@ def test_direction_only_trace_and_shade_match_whole_records(ctx, kw):
     assert int((out[0][2] & 1).sum()) > 0 and int((out[0][2] & 1).sum()) < full.n
     # a frame with a disk needs the end locations: the option falls back to whole records by itself
     dirs.set_disk(4.5, 10.5)
+    with pytest.raises(RuntimeError):      # the scene changed after the last trace: both shade paths refuse, neither reads stale data
+        dirs.shade()
+    with pytest.raises(RuntimeError):
+        dirs.shade_f32(torch.zeros((dirs.P, 4), dtype=torch.float32, device="cuda"))
     dirs.trace(_ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=35.0, disk_r_in=4.5, disk_r_out=10.5))
-    assert not dirs._dir_traced
+    assert not dirs._dir_traced and dirs.d_end is not None
+    dirs.shade()
 
 
 @pytest.mark.parametrize("n", [0, 1, 65, 4099])

@@ -172,6 +172,28 @@ def test_acceleration_matches_oracle(ctx, oracle, rhs_form):
     assert np.median(rel) < 1e-15
 
 
+@pytest.mark.parametrize("M,a", [(0.5, 0.45), (1.3, -0.9)])
+def test_kerr_acceleration_on_the_device_matches_oracle_and_hamiltonian_form(ctx, oracle, M, a):
+    """The DEVICE Kerr right-hand side (accel_kerr_bl: Newton reciprocals, the shared sincos, product inversion),
+    probed point by point through bhg_acceleration with rhs_form = BHG_RHS_KERR_BL -- Boyer-Lindquist triples in and
+    out, E and L from the null condition at the point -- against the oracle's evaluation of the same generated
+    snippet (libm sin / cos, IEEE divisions) and against Hamilton's equations with the inverse metric
+    (tests/kerr_hamiltonian.py: no Christoffel symbols, nothing generated)."""
+    import kerr_hamiltonian as kh
+    q, u = kh.sample_points(3000, M, a, seed=11)
+    got = ctx.acceleration(q, u, _params(r_s=2 * M, rhs_form=2, spin=a))
+    ref = oracle.acceleration(q, u, r_s=2 * M, rhs_form=2, spin=a)
+    scale = np.abs(ref).max(1) + 1e-300
+    r_plus = M + np.sqrt(M * M - a * a)
+    near = 1.0 / ((q[:, 0] - r_plus) / r_plus) ** 2      # both lose digits to the cancellation in Delta near r_plus
+    rel = np.abs(got - ref).max(1) / scale
+    assert np.all(rel < 1e-12 + 1e-15 * near), float((rel / (1e-12 + 1e-15 * near)).max())
+    assert np.median(rel) < 5e-15
+    ham = np.array([kh.acceleration(q[i], u[i], M, a) for i in range(400)])
+    rel_h = np.abs(got[:400] - ham).max(1) / (np.abs(ham).max(1) + 1e-300)
+    assert np.all(rel_h < 1e-9 + 1e-12 * near[:400]) and np.median(rel_h) < 1e-12
+
+
 @pytest.mark.parametrize("rhs_form", [0, 1])
 def test_seeded_rays_default_controller(ctx, oracle, rhs_form):
     k = frame_rays(50000, seed=21)

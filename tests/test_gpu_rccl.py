@@ -89,3 +89,21 @@ def test_bench_takes_the_collective_path_on_one_gpu():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["collective"].startswith("rccl gather, 1 rank")
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_bench_self_launches_two_ranks_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` started the way the driver starts N = 1 (no torch.distributed.run, WORLD_SIZE unset)
+    must start its own ranks: two ranks share the box's one GPU over gloo (RCCL refuses two ranks per device), the
+    N > 1 code path runs -- weak-scaling headline + the `strong` block -- and rank 0's JSON line is the parent's last line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BHGEO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--width", "256", "--samples", "2",
+                          "--steps", "4", "--warmup", "2", "--ramp-seconds", "0", "--cpu-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("{"), out.stdout[-500:]
+    line = json.loads(last)
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["strong"]["value"] > 0 and line["strong"]["scaling"] == "strong"
+    assert "2 rank" in line["config"]["collective"]

@@ -5,6 +5,7 @@ import ctypes
 import os
 import random
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -131,3 +132,18 @@ def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
         pytest.skip("a GPU is present: the example would run")
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+def test_bench_self_launch_relays_a_failing_launch(tmp_path):
+    """bench.py --gpus N > 1 without a launcher starts its own ranks as child processes (never an exec) and exits with
+    the launcher's code; on this GPU-less box the ranks fail, and that failure must come back as a non-zero exit."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--width", "64", "--samples", "1",
+                          "--steps", "1", "--warmup", "0", "--ramp-seconds", "0", "--cpu-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the launch succeeds (covered by tests/test_gpu_rccl.py)")
+    assert out.returncode != 0
+    assert "torch.distributed" in out.stderr or "Traceback" in out.stderr or "Error" in out.stderr

@@ -380,3 +380,22 @@ def test_kerr_snippet_is_the_generators_output_and_matches_the_contraction():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_kerr_rhs.py"), "--check"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_kerr_acceleration_probe_against_hamiltonian_form(oracle):
+    """The oracle's Kerr right-hand side, point by point (not through trajectories): bhgo_acceleration with
+    rhs_form = Kerr takes Boyer-Lindquist (r, theta, phi) and velocities, fixes E and L by the null condition at the
+    point and evaluates the generated snippet; judged by Hamilton's equations with the inverse metric
+    (tests/kerr_hamiltonian.py), for two masses (the generator's own check used to fix M = 1/2)."""
+    import kerr_hamiltonian as kh
+    for M, a in ((0.5, 0.45), (1.3, -0.9), (0.5, 0.0)):
+        q, u = kh.sample_points(400, M, a, seed=int(M * 10))
+        got = oracle.acceleration(q, u, r_s=2 * M, rhs_form=oracle.RHS_KERR_BL, spin=a)
+        ref = np.array([kh.acceleration(q[i], u[i], M, a) for i in range(len(q))])
+        scale = np.abs(ref).max(1) + 1e-300
+        rel = np.abs(got - ref).max(1) / scale
+        # close to the horizon Delta -> 0 and both forms lose digits to cancellation
+        r_plus = M + np.sqrt(M * M - a * a)
+        tol = 1e-9 + 1e-12 / ((q[:, 0] - r_plus) / r_plus) ** 2
+        assert np.all(rel < tol), (M, a, float((rel / tol).max()))
+        assert np.median(rel) < 1e-12
