@@ -484,41 +484,51 @@ __device__ __forceinline__ double pow_0p2(double x)
 }
 
 // ------------------------------------------------------------------------------------------
-// Per-wave LDS: a queue of prepared rays (filled converged, drained lane by lane), the list of rays
-// whose last step is parked for the event drain (filled lane by lane, drained converged) and the
-// list of rays the drain hands back for more steps.
+// Per-wave LDS: ONE pool of ray records.  A record (112 bytes; Kerr 128) is a ray's whole state between steps --
+// position, direction, acceleration, step size, radius, lambda, index and step counts -- and a slot of the pool holds
+//   * a QUEUED ray (prepared by the converged queue fill, or handed back by the event drain to carry on), or
+//   * a PARKED step: the start state of an accepted step that (may have) crossed an event surface, waiting for the
+//     converged event drain, or
+//   * for the duration of a drain, the state of the lane that is busy draining.
+// Three byte lists say which slot is what: the queue (a ring, popped lane by lane), the parked steps (a stack, drained
+// 64 at a time) and the free slots (a stack).  Nothing of this ever goes to global memory: a trace launch reads k0
+// (x0) and writes final results, and that is all of its HBM traffic.  Round 2 parked in the rays' own output slots:
+// 2 x 96 bytes per parked step through L2, 3.3 - 5 x the algorithmic bytes on the event-heavy frames.
 // ------------------------------------------------------------------------------------------
-// Rays a wave owns at any time: <= 64 in its lanes, <= 64 queued, the rest parked or waiting to resume.  A new batch
-// is only claimed when the resume list is empty and fewer than 64 events are parked, so a wave never owns more
-// than 64 + 63 + 64 = 191 rays: neither list can overflow its 192 slots.
-constexpr int EVQ_CAP = 192;
+// Slots per wave.  Schwarzschild forms run 12 waves per CU (3 per SIMD): 160 KiB / 12 = 13,653 bytes per wave
+// = 118 records of 112 bytes + the lists.  Kerr runs 8 waves per CU and has room to spare.
+#ifndef BHG_NSLOT
+#define BHG_NSLOT 118
+#endif
+constexpr int NSLOT = BHG_NSLOT;
+constexpr int QRING = 128;   // ring size of the queue list (a power of two >= NSLOT)
+static_assert(NSLOT >= 65 && NSLOT <= QRING, "the pool must hold a 64-ray batch plus one, slot ids are ring indices");
 
-// One queued ray: 12 doubles + 3 counters, laid out so that a lane moves it with seven 16-byte LDS accesses
-// (ds_read_b128 / ds_write_b128) instead of twenty-three 8- and 4-byte ones -- the pop runs in almost every iteration
-// of the step loop (some lane of the wave finishes a ray in nearly each one).
+// One record: 12 doubles + 4 words, laid out so that a lane moves it with seven 16-byte LDS accesses
+// (ds_read_b128 / ds_write_b128) -- the pop runs in almost every iteration of the step loop (some lane of the wave
+// finishes a ray in nearly each one).
 template <int RHS>
 struct alignas(16) QEntry {
-    double2 d[6];   // {x0, x1} {x2, k0} {k1, k2} {a0, a1} {a2, |h| to try first} {r, lambda} at the start point
-    uint4 i;        // ray index, attempted steps, accepted steps, (drain: lane state bits)
+    double2 d[6];   // {x0, x1} {x2, k0} {k1, k2} {a0, a1} {a2, h} {r, lambda}
+                    //   queued ray: h = |h| to try first, r = radius at the start point
+                    //   parked step: h = |h| the controller chose for the step AFTER this one, r = |h| this step tried
+    uint4 i;        // ray index, attempted steps, accepted steps, bits (parked: EV_* kinds; saved lane: its state bits)
     double2 el[(RHS == BHG_RHS_KERR_BL_) ? 1 : 0];  // Kerr: the ray's Killing constants E, L
 };
 
 template <int RHS>
 struct WaveLds {
-    // prepared rays (filled converged -- start records worked out in place or read from the prepare / resume
-    // records -- and drained lane by lane); while the event drain runs, the lanes' own rays are kept here
-    QEntry<RHS> q[64];
-    uint32_t ev_idx[EVQ_CAP];   // rays whose last accepted step (may have) crossed an event surface
-    uint32_t res_idx[EVQ_CAP];  // rays whose parked step held no terminal event after all: they carry on
-    uint8_t ev_kind[EVQ_CAP];   // EV_* bits of the parked step
+    QEntry<RHS> slot[NSLOT];
+    uint8_t q_list[QRING];      // slots of the queued rays, a ring: q_head .. q_head + q_count - 1 (mod QRING)
+    uint8_t free_list[NSLOT];   // free slots, a stack of n_free entries
+    uint8_t ev_list[NSLOT];     // slots of the parked steps, a stack of n_ev entries
 };
 
 template <int RHS>
-__device__ __forceinline__ void q_put(WaveLds<RHS> &Q, uint32_t s, const double x[3], const double k[3], const double a[3],
-                                      double h, double r, double t, double E, double Lz, uint32_t idx, uint32_t natt,
-                                      uint32_t nacc, uint32_t bits = 0u)
+__device__ __forceinline__ void entry_put(QEntry<RHS> &e, const double x[3], const double k[3], const double a[3], double h,
+                                          double r, double t, double E, double Lz, uint32_t idx, uint32_t natt,
+                                          uint32_t nacc, uint32_t bits)
 {
-    QEntry<RHS> &e = Q.q[s];
     e.d[0] = make_double2(x[0], x[1]);
     e.d[1] = make_double2(x[2], k[0]);
     e.d[2] = make_double2(k[1], k[2]);
@@ -529,7 +539,7 @@ __device__ __forceinline__ void q_put(WaveLds<RHS> &Q, uint32_t s, const double 
     if (RHS == BHG_RHS_KERR_BL_) e.el[0] = make_double2(E, Lz);
 }
 
-// Kinds of event a parked step may hold (bits of WaveLds::ev_kind; they never reach flags[]).
+// Kinds of event a parked step may hold (the `bits` word of its record; they never reach flags[]).
 constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 
@@ -655,12 +665,21 @@ struct Lane {
     // 0 / 1, as full words: a bool is kept as a byte and compared through SDWA against a zero held in a VGPR for the
     // life of the kernel -- a register the allocator then spills around the event drain and reloads in the loop
     uint32_t active, rejected;
+    // EV_* bits of an accepted step this lane has to park: x, v, a1, t are still the step's START, h_abs is the
+    // controller's choice for the NEXT step and r_cur has been overwritten with the |h| THIS step tried (the drain
+    // recomputes the step from exactly these).  The record goes into the pool the next time the lane is served.
+    uint32_t pend;
 };
 
 template <int RHS>
-__device__ __forceinline__ uint32_t q_get(const WaveLds<RHS> &Q, uint32_t s, Lane &L)
+__device__ __forceinline__ void slot_put(QEntry<RHS> &e, const Lane &L, uint32_t bits)
 {
-    const QEntry<RHS> &e = Q.q[s];
+    entry_put<RHS>(e, L.x, L.v, L.a1, L.h_abs, L.r_cur, L.t, L.E, L.Lz, L.idx, L.n_att, L.n_acc, bits);
+}
+
+template <int RHS>
+__device__ __forceinline__ uint32_t slot_get(const QEntry<RHS> &e, Lane &L)
+{
     const double2 d0 = e.d[0], d1 = e.d[1], d2 = e.d[2], d3 = e.d[3], d4 = e.d[4], d5 = e.d[5];
     const uint4 i = e.i;
     L.x[0] = d0.x;
@@ -686,13 +705,22 @@ __device__ __forceinline__ uint32_t q_get(const WaveLds<RHS> &Q, uint32_t s, Lan
     return i.w;
 }
 
+// state bits of a lane whose registers wait in a slot while the lane drains events
+__device__ __forceinline__ uint32_t lane_bits(const Lane &L) { return L.active | (L.rejected << 1) | (L.pend << 4); }
+__device__ __forceinline__ void lane_set_bits(Lane &L, uint32_t b)
+{
+    L.active = b & 1u;
+    L.rejected = (b >> 1) & 1u;
+    L.pend = b >> 4;
+}
+
 struct Wave {
-    int q_head, q_count;
-    int ev_count, res_count;     // entries of the parked-event list and of the resume list
+    int q_head, q_count;         // the queue ring
+    int n_free, n_ev;            // entries of the free-slot stack and of the parked-step stack
     bool exhausted;
     uint32_t slice, dry;         // current slice, number of slices found dry so far
 #ifdef BHG_DIAG
-    unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0, diag_refill_cyc = 0;
+    unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0, diag_refill_cyc = 0, diag_general = 0;
 #endif
 };
 
@@ -730,16 +758,6 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     A.n_accepted[idx] = n_acc;
 }
 
-// final state of a ray whose event the resolve pass located (step counts were stored when parked)
-__device__ __forceinline__ void store_event_result(const TraceArgs &A, uint32_t idx, const double x[3],
-                                                   const double v[3], uint32_t flags)
-{
-    bool bad = !(isfinite(x[0]) && isfinite(x[1]) && isfinite(x[2]) && isfinite(v[0]) &&
-                 isfinite(v[1]) && isfinite(v[2]));
-    if (bad) flags |= BHG_FLAG_NAN_;
-    store_end_state(A, idx, x, v);
-    A.flags[idx] = (uint8_t)flags;
-}
 
 // Work distribution.  One device-wide counter saturates near 90 fetches/us, and this kernel
 // wants 50+/us at config 2; so the 64-ray batches are dealt into NSLICE interleaved slices
@@ -820,9 +838,9 @@ __device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric 
     }
 }
 
-// Fill the LDS ray queue with rays base .. base+63: coalesced loads of k0, x0 and -- Kerr -- of the prepare
+// Put rays base .. base+63 into the ray queue: coalesced loads of k0, x0 and -- Kerr -- of the prepare
 // pass's record {a0, h0, r0, 0, E, L}; the Schwarzschild forms work the records out here, all lanes together.
-// Items that pass (h >= 0) are compacted with ballot/mbcnt.
+// Items that pass (h >= 0) take a free slot each (ballot/mbcnt ranks); the caller has made sure 64 are free.
 template <int RHS, bool ADAPTIVE>
 __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane, uint64_t base)
 {
@@ -894,55 +912,16 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, 
     }
     const bool valid = ph >= 0.0;
     const uint64_t vmask = __ballot(valid);
+    const int cnt = __builtin_popcountll(vmask);
     if (valid) {
-        const uint32_t s = lane_rank(vmask);
-        q_put<RHS>(Q, s, px, pk, pa, ph, pr, 0.0, pE, pL, (uint32_t)i, 0u, 0u);
+        const uint32_t rk = lane_rank(vmask);
+        const uint32_t s = Q.free_list[W.n_free - 1 - (int)rk];
+        Q.q_list[(W.q_head + W.q_count + (int)rk) & (QRING - 1)] = (uint8_t)s;
+        entry_put<RHS>(Q.slot[s], px, pk, pa, ph, pr, 0.0, pE, pL, (uint32_t)i, 0u, 0u, 0u);
     }
     wave_lds_sync();
-    W.q_head = 0;
-    W.q_count = __builtin_popcountll(vmask);
-}
-
-// Fill the ray queue from the wave's resume list (up to 64 rays): the event drain left each of them a record
-// {x, k} in its end[] slot and {a, h_next, r, lambda, (E, L)} in its ws[] slot, step counts in n_steps / n_accepted.
-// Written and read by this one wavefront (in-order through the CU's vector cache): no other wave ever sees them.
-template <int RHS>
-__device__ __forceinline__ void fill_resumed(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane)
-{
-    const int take = W.res_count < 64 ? W.res_count : 64;
-    const int base = W.res_count - take;
-    double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = 0.0, pt = 0.0;
-    double pE = 0.0, pL = 0.0;
-    uint32_t natt = 0, nacc = 0, i = 0;
-    if ((int)lane < take) {
-        i = Q.res_idx[base + lane];
-        const double *e = A.end + (uint64_t)i * 6;
-        px[0] = e[0];
-        px[1] = e[1];
-        px[2] = e[2];
-        pk[0] = e[3];
-        pk[1] = e[4];
-        pk[2] = e[5];
-        const double *w = A.ws + (uint64_t)i * (uint64_t)A.ws_stride;
-        pa[0] = w[0];
-        pa[1] = w[1];
-        pa[2] = w[2];
-        ph = w[3];
-        pr = w[4];
-        pt = w[5];
-        if (RHS == BHG_RHS_KERR_BL_) {
-            pE = w[6];
-            pL = w[7];
-        }
-        natt = A.n_steps[i];
-        nacc = A.n_accepted[i];
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (see fill_batch)
-    if ((int)lane < take) q_put<RHS>(Q, lane, px, pk, pa, ph, pr, pt, pE, pL, i, natt, nacc);
-    wave_lds_sync();
-    W.res_count = base;
-    W.q_head = 0;
-    W.q_count = take;
+    W.n_free -= cnt;
+    W.q_count += cnt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1089,15 +1068,18 @@ __device__ __forceinline__ double dp54_factor(double errsq)
 // Horizon and sphere exit always end the ray; a disk-plane crossing only inside the annulus
 // R_in <= R <= R_out (LimitedRelativisticRenderEngine.py:423-424); an object sphere when the curve enters
 // it (the reference's collision stub, RelativisticRenderEngine.py:304-305).
-// g_r(t, R) = r(t) - R, g_z(t) = z(t), pos(t, x) / eval(t, x, v) = interpolated state.  Returns true if the ray ended.
-template <int EVT, class GR, class GZ, class POS, class EV>
-__device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind, uint32_t idx, double t, double t_new,
-                                              const double x0[3], const double x1[3], const GR &g_r, const GZ &g_z,
-                                              const POS &pos, const EV &eval, bool bl)
+// g_r(t, R) = r(t) - R, g_z(t) = z(t), pos(t, x) = interpolated position.  Returns the flag of the event that ends
+// the ray (0: none does) with its root in `best` and, for an object hit, the sphere in `obj`.
+// The general search: Brent on the interpolant, scipy's solve_event_equation step for step.  Steps whose one event
+// function is provably monotone over the step never come here (dp54_resolve_parked's certified Newton search).
+template <int EVT, class GR, class GZ, class POS>
+__device__ __forceinline__ uint32_t settle_events(const TraceArgs &A, uint32_t kind, double t, double t_new,
+                                                  const double x0[3], const double x1[3], const GR &g_r, const GZ &g_z,
+                                                  const POS &pos, bool bl, double &best, int &obj)
 {
-    double best = __builtin_inf();
+    best = __builtin_inf();
     uint32_t fl = 0;
-    int obj = -1;
+    obj = -1;
     if (kind & EV_HORIZON) {
         const double r = brent_root([&](double tt) { return g_r(tt, A.r_hor); }, t, t_new);
         if (r < best) {
@@ -1156,43 +1138,16 @@ __device__ __forceinline__ bool settle_events(const TraceArgs &A, uint32_t kind,
             }
         }
     }
-    if (!fl) return false;
-    double xe[3], ve[3];
-    eval(best, xe, ve);
-    store_event_result(A, idx, xe, ve, fl);
-    if (obj >= 0 && A.object_id) A.object_id[idx] = (int8_t)obj;
-    return true;
-}
-
-// The step held no terminal event after all: the ray is final if the step reached lambda_end
-// (base.py:203-204); otherwise it carries on from the step's end -- its resume record is left in its own end[] /
-// ws[] slots and the caller puts it on the wave's resume list (returns true).
-__device__ __forceinline__ bool finish_or_resume(const TraceArgs &A, uint32_t idx, const double xn[3], const double vn[3],
-                                                 const double an[3], double t_new, double r_new, double h_next)
-{
-    if (t_new - A.lambda_end >= 0.0) {
-        store_event_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_);
-        return false;
-    }
-    double *e = A.end + (size_t)idx * 6;
-    reinterpret_cast<double2 *>(e)[0] = make_double2(xn[0], xn[1]);
-    reinterpret_cast<double2 *>(e)[1] = make_double2(xn[2], vn[0]);
-    reinterpret_cast<double2 *>(e)[2] = make_double2(vn[1], vn[2]);
-    double *w = A.ws + (size_t)idx * (size_t)A.ws_stride;
-    w[0] = an[0];
-    w[1] = an[1];
-    w[2] = an[2];
-    w[3] = h_next;
-    w[4] = r_new;
-    w[5] = t_new;
-    return true;
+    return fl;
 }
 
 // The quartic dense output of one accepted DP5(4) step from its stage accelerations (rk.py:393-404, :552-574 in
-// Nystrom form).  One definition for the event drain and the sampled-trajectory kernel: both return the same bits.
-__device__ __forceinline__ void build_dense(Dense &d, double t, double h, const double x[3], const double v[3],
-                                            const double a1[3], const double a2[3], const double a3[3], const double a4[3],
-                                            const double a5[3], const double a6[3], const double a7[3])
+// Nystrom form), position part: x_c(th) = x_c + (h th) (qx[0][c] + th (qx[1][c] + th (qx[2][c] + th qx[3][c]))),
+// qx[0] = v.  One definition for the event drain and the sampled-trajectory kernel: both see the same bits.
+__device__ __forceinline__ void build_dense_pos(Dense &d, double t, double h, const double x[3], const double v[3],
+                                                const double a1[3], const double a2[3], const double a3[3],
+                                                const double a4[3], const double a5[3], const double a6[3],
+                                                const double a7[3])
 {
     d.t0 = t;
     d.h = h;
@@ -1204,49 +1159,287 @@ __device__ __forceinline__ void build_dense(Dense &d, double t, double h, const 
         d.v0[c] = v[c];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            // sum_j P[j][m] a_j and sum_j P~[j][m] a_j as FMA chains; coefficients that are zero (known at compile
-            // time: the whole m = 0 column of P~, P[2][.], P~[7][.]) are skipped
-            double qv = 0.0, qx = 0.0;
+            // sum_j P~[j][m] a_j as an FMA chain; coefficients that are zero (known at compile time: the whole
+            // m = 0 column, P~[7][.]) are skipped
+            double qx = 0.0;
 #pragma unroll
-            for (int j = 1; j <= 7; j++) {
-                if (TB.p[j][m] != 0.0) qv = __builtin_fma(TB.p[j][m], aj[j][c], qv);
+            for (int j = 1; j <= 7; j++)
                 if (TB.pt[j][m] != 0.0) qx = __builtin_fma(TB.pt[j][m], aj[j][c], qx);
-            }
-            d.qv[m][c] = qv;
             d.qx[m][c] = __builtin_fma(h, qx, TB.sig[m] * v[c]);
         }
     }
 }
 
-// Locate the terminal event inside one accepted DP5(4) step and write the ray's result.
-// Runs converged on the lanes of the event drain: the step is recomputed from its start state.
-template <int RHS, int EVT>
-__device__ __forceinline__ bool dp54_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                   const double a1[3], double t, double t_new, double h,
-                                                   double h_next, uint32_t kind, uint32_t idx, const Metric &m)
+// ... and its direction part: v_c(th) = v_c + (h th) (qv[0][c] + th (qv[1][c] + ...)), qv[m] = sum_j P[j][m] a_j
+__device__ __forceinline__ void build_dense_dir(Dense &d, const double a1[3], const double a2[3], const double a3[3],
+                                                const double a4[3], const double a5[3], const double a6[3],
+                                                const double a7[3])
 {
+    const double *aj[8] = {nullptr, a1, a2, a3, a4, a5, a6, a7};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            double qv = 0.0;
+#pragma unroll
+            for (int j = 1; j <= 7; j++)
+                if (TB.p[j][m] != 0.0) qv = __builtin_fma(TB.p[j][m], aj[j][c], qv);
+            d.qv[m][c] = qv;
+        }
+}
+
+__device__ __forceinline__ void build_dense(Dense &d, double t, double h, const double x[3], const double v[3],
+                                            const double a1[3], const double a2[3], const double a3[3], const double a4[3],
+                                            const double a5[3], const double a6[3], const double a7[3])
+{
+    build_dense_pos(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
+    build_dense_dir(d, a1, a2, a3, a4, a5, a6, a7);
+}
+
+// The direction of the dense output at ONE parameter th, straight from the stage accelerations:
+// v_c(th) = v_c + (h th) sum_j a_j[c] b_j(th), b_j(th) = sum_m P[j][m] th^m -- the same polynomial as dense_dir's,
+// summed stage-first (six scalar cubics + 18 FMAs instead of twelve coefficients of 6 FMAs each + 15): what a step
+// needs whose event root is already known.  Agrees with dense_dir to rounding.
+__device__ __forceinline__ void dense_dir_at(double th, double h, const double v[3], const double a1[3],
+                                             const double a3[3], const double a4[3], const double a5[3],
+                                             const double a6[3], const double a7[3], double out[3])
+{
+    double b[8];
+#pragma unroll
+    for (int j = 1; j <= 7; j++)
+        b[j] = __builtin_fma(__builtin_fma(__builtin_fma(TB.p[j][3], th, TB.p[j][2]), th, TB.p[j][1]), th, TB.p[j][0]);
+    const double hth = h * th;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double sacc = b[1] * a1[c];     // (P[2][.] = 0)
+        sacc = __builtin_fma(b[3], a3[c], sacc);
+        sacc = __builtin_fma(b[4], a4[c], sacc);
+        sacc = __builtin_fma(b[5], a5[c], sacc);
+        sacc = __builtin_fma(b[6], a6[c], sacc);
+        sacc = __builtin_fma(b[7], a7[c], sacc);
+        out[c] = __builtin_fma(hth, sacc, v[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One parked DP5(4) step, resolved by a lane of the event drain: recompute the step from its start state
+// (bit-identical stages), locate its event, write the ray's result -- or hand the ray back to carry on.
+//
+// P (in): the parked record -- x, v, a1, t at the step's start, h_abs = the controller's |h| for the NEXT step,
+//         r_cur = the |h| THIS step tried, idx and the step counts after the step.
+// R (out, when true is returned): the ray's state at the step's end; it carries on from there.
+//
+// Root search.  solve_ivp locates an event with brentq on the dense output to 4 eps (ivp.py:51-76).  Where the step
+// holds exactly ONE candidate event (horizon, exit sphere or disk plane) and its event function is provably MONOTONE
+// over the whole step, the root is unique and any bracketing search that converges to that tolerance returns it:
+// such lanes run a safeguarded Newton iteration on the polynomial itself (exact derivative, no square root: r^2 - R^2
+// in place of r - R), 3 iterations where Brent takes 7 or 8 of twice the length, the position half of the dense
+// output only, and the direction evaluated once at the root.  The certificate is a sufficient condition from the
+// coefficients: with x(th) = x + h th (v + e(th)), x'(th) = h (v + d(th)), |e_c| <= E_c = |q1| + |q2| + |q3| and
+// |d_c| <= D_c = 2|q1| + 3|q2| + 4|q3| on [0, 1]:
+//     plane:   |v_z| > D_z                                           (z' keeps its sign)
+//     sphere:  x.x'/h = x.v + h th |v|^2 + [x.d + h th (e.v + v.d + e.d)], bracket bounded by
+//              S = sum_c |x_c| D_c + h (|v_c| (E_c + D_c) + E_c D_c);  outward: x.v > S;  inward: x.v + h |v|^2 < -S
+//     Boyer-Lindquist: the event functions are single coordinates (r, theta): |u_c| > D_c.
+// Everything else -- several candidates in one step, object spheres, a failed certificate (a step diving through the
+// horizon with the Christoffel form's 1/f terms: round 2 found dense outputs with several crossings there, and
+// which one brentq lands on is part of the contract) -- goes through Brent, step for step as before.
+// ------------------------------------------------------------------------------------------
+template <int RHS, int EVT>
+__device__ __forceinline__ bool dp54_resolve_parked(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind,
+                                                    Lane &R, bool &went_general)
+{
+    constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
+    const double t = P.t, h_next = P.h_abs;
+    // the step as the integrate loop took it: same operations on the same bits
+    double t_new = t + P.r_cur;
+    if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
+    const double h = t_new - t;
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
-    dp54_stages<RHS>(x, v, a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+    dp54_stages<RHS>(P.x, P.v, P.a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
     Dense d;
-    build_dense(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
-    const bool ended = settle_events<EVT>(
-        A, kind, idx, t, t_new, x, xn, [&](double tt, double R) { return dense_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
-        [&](double tt) {
-            if (RHS != BHG_RHS_KERR_BL_) return dense_z(d, tt);
-            double q[3];
-            dense_pos(d, tt, q);
-            double sn, cs;             // z = r cos(theta), r > 0; the RHS's own sincos (about an ulp, a quarter of
-            sincos_pi4(q[1], sn, cs);  // libm's cos with its large-argument ladder) -- once per Brent iterate
-            return cs;
-        },
-        [&](double tt, double xe[3]) { dense_pos(d, tt, xe); },
-        [&](double tt, double xe[3], double ve[3]) {
-            dense_pos(d, tt, xe);
-            dense_dir(d, tt, ve);
-        },
-        RHS == BHG_RHS_KERR_BL_);
-    if (!(EVT & (EVT_DISK | EVT_OBJ))) return false;  // horizon / exit crossings always end the ray: nothing to resume
-    return ended ? false : finish_or_resume(A, idx, xn, vn, a7, t_new, r_new, h_next);
+    build_dense_pos(d, t, h, P.x, P.v, P.a1, a2, a3, a4, a5, a6, a7);
+
+    uint32_t fl = 0;            // flag of the event that ends the ray, 0 = none
+    double xe[3], ve[3];        // ... and the state there
+    int obj = -1;
+    bool settled = false;
+
+    // ---- certified monotone single event: Newton on the polynomial ----
+#ifdef BHG_NO_NEWTON
+    const bool single = false;
+#else
+    const bool single = kind == EV_HORIZON || ((EVT & EVT_EXIT) && kind == EV_EXIT) || ((EVT & EVT_DISK) && kind == EV_DISK);
+#endif
+    if (single) {
+        const bool is_disk = (EVT & EVT_DISK) && kind == EV_DISK;
+        double Ec[3], Dc[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double q1 = fabs(d.qx[1][c]), q2 = fabs(d.qx[2][c]), q3 = fabs(d.qx[3][c]);
+            Ec[c] = q1 + q2 + q3;
+            Dc[c] = __builtin_fma(4.0, q3, __builtin_fma(3.0, q2, 2.0 * q1));
+        }
+        bool mono;
+        int comp = 0;               // Boyer-Lindquist: the coordinate the event function is
+        double target = 0.0;        // BL: its value on the event surface;  Cartesian spheres: R^2
+        if (BL) {
+            comp = is_disk ? 1 : 0;
+            if (is_disk) {
+                // the plane theta* = pi/2 + k pi between the step ends (more than one: Brent decides)
+                const double k0 = floor((P.x[1] - 1.5707963267948966) * 0.3183098861837907);
+                const double k1 = floor((xn[1] - 1.5707963267948966) * 0.3183098861837907);
+                target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
+                mono = fabs(k1 - k0) == 1.0 && fabs(P.v[1]) > 1.0000001 * Dc[1];
+            } else {
+                target = kind == EV_HORIZON ? A.r_hor : A.r_exit;
+                mono = kind == EV_HORIZON ? (P.v[0] < -1.0000001 * Dc[0]) : (P.v[0] > 1.0000001 * Dc[0]);
+            }
+        } else if (is_disk) {
+            mono = fabs(P.v[2]) > 1.0000001 * Dc[2];
+        } else {
+            const double R = kind == EV_HORIZON ? A.r_hor : A.r_exit;
+            target = R * R;
+            double xv = 0.0, vv = 0.0, S = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                xv = __builtin_fma(P.x[c], P.v[c], xv);
+                vv = __builtin_fma(P.v[c], P.v[c], vv);
+                const double av = fabs(P.v[c]);
+                S = __builtin_fma(fabs(P.x[c]), Dc[c], S);
+                S = __builtin_fma(h, __builtin_fma(av, Ec[c] + Dc[c], Ec[c] * Dc[c]), S);
+            }
+            S *= 1.0000001;
+            mono = kind == EV_HORIZON ? (__builtin_fma(h, vv, xv) < -S) : (xv > S);
+        }
+        if (mono) {
+            // G(th) and dG/dth on the position polynomial
+            auto eval = [&](double th, double &g, double &dg, double xs[3]) {
+                double ds[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sx = __builtin_fma(d.qx[3][c], th, d.qx[2][c]);
+                    sx = __builtin_fma(sx, th, d.qx[1][c]);
+                    sx = __builtin_fma(sx, th, d.qx[0][c]);
+                    xs[c] = __builtin_fma(h * th, sx, d.x0[c]);     // = dense_pos
+                    double sd = __builtin_fma(4.0 * d.qx[3][c], th, 3.0 * d.qx[2][c]);
+                    sd = __builtin_fma(sd, th, 2.0 * d.qx[1][c]);
+                    sd = __builtin_fma(sd, th, d.qx[0][c]);
+                    ds[c] = h * sd;
+                }
+                if (BL) {
+                    g = (comp == 1 ? xs[1] : xs[0]) - target;
+                    dg = comp == 1 ? ds[1] : ds[0];
+                } else if (is_disk) {
+                    g = xs[2];
+                    dg = ds[2];
+                } else {
+                    g = __builtin_fma(xs[2], xs[2], __builtin_fma(xs[1], xs[1], xs[0] * xs[0])) - target;
+                    dg = 2.0 * __builtin_fma(xs[2], ds[2], __builtin_fma(xs[1], ds[1], xs[0] * ds[0]));
+                }
+            };
+            double g0, g1, dg, xs[3];
+            eval(0.0, g0, dg, xs);
+            eval(1.0, g1, dg, xs);
+            // the step ends bracket the root (that is what parked the step); G is monotone between them
+            double lo = 0.0, hi = 1.0;
+            const bool neg0 = g0 < 0.0;
+            double th = g0 * rcp_nr(g0 - g1);      // secant start
+            if (!(th > 0.0 && th < 1.0)) th = 0.5;
+            if (g0 == 0.0) th = 0.0;        // (an end exactly on the surface is the root, as in brentq)
+            else if (g1 == 0.0) th = 1.0;
+            // FOUR safeguarded Newton steps for every lane, no per-lane exit: from the secant start the error squares
+            // each time (1e-2, 1e-4, 1e-8, 1e-16 is typical), a lane that is there early repeats a step of ~0.  The
+            // root counts as found when the LAST step moved th by less than 1e-9 (the error left is then far below an
+            // ulp); anything slower -- a root next to an end of the bracket, a bisection on the way -- goes to Brent.
+            double dth = 1.0;
+            int dbg_it = 0;
+            (void)dbg_it;
+#pragma unroll 1
+            for (int it = 0; it < 4; it++) {
+                dbg_it++;
+                double g;
+                eval(th, g, dg, xs);
+                if ((g < 0.0) == neg0) lo = th; else hi = th;
+                dth = -g * rcp_nr(dg);
+                double thn = th + dth;
+                if (!(thn >= lo && thn <= hi)) {      // Newton left the bracket (or NaN): bisect
+                    thn = 0.5 * (lo + hi);
+                    dth = 1.0;
+                }
+                th = thn;
+            }
+            const bool conv = fabs(dth) <= 1e-9;
+            if (conv) {
+                double g;
+                eval(th, g, dg, xe);        // xe = position at the root
+                bool terminal = true;
+                if (is_disk) {
+                    double Rc;
+                    if (BL) {
+                        double sn, cs;
+                        sincos_pi4(xe[1], sn, cs);
+                        Rc = sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sn);
+                    } else {
+                        Rc = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+                    }
+                    terminal = Rc >= A.disk_r_in && Rc <= A.disk_r_out;
+                }
+                if (terminal) {
+                    dense_dir_at(th, h, P.v, P.a1, a3, a4, a5, a6, a7, ve);
+#ifdef BHG_DEBUG_NEWTON
+                    ve[0] = th; ve[1] = g; ve[2] = (double)dbg_it + 100.0 * (double)kind; xe[0] = g0; xe[1] = g1; xe[2] = h;
+#endif
+                    fl = kind == EV_HORIZON ? BHG_FLAG_HIT_HORIZON_ : (is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_);
+                }
+                settled = true;
+            }
+        }
+    }
+
+    // ---- everything else: Brent on the full dense output, scipy's search step for step ----
+    went_general = !settled;
+    if (__builtin_expect(!settled, 0)) {
+        build_dense_dir(d, P.a1, a2, a3, a4, a5, a6, a7);
+        double best;
+        fl = settle_events<EVT>(
+            A, kind, t, t_new, P.x, xn, [&](double tt, double Rr) { return dense_g(d, tt, Rr, BL); },
+            [&](double tt) {
+                if (!BL) return dense_z(d, tt);
+                double q[3];
+                dense_pos(d, tt, q);
+                double sn, cs;             // z = r cos(theta), r > 0; the RHS's own sincos (about an ulp, a quarter of
+                sincos_pi4(q[1], sn, cs);  // libm's cos with its large-argument ladder) -- once per Brent iterate
+                return cs;
+            },
+            [&](double tt, double xq[3]) { dense_pos(d, tt, xq); }, BL, best, obj);
+        if (fl) {
+            dense_pos(d, best, xe);
+            dense_dir(d, best, ve);
+        }
+    }
+
+    if (fl) {
+        store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
+        if (obj >= 0 && A.object_id) A.object_id[P.idx] = (int8_t)obj;
+        return false;
+    }
+    // The step held no terminal event after all: the ray is final if the step reached lambda_end
+    // (base.py:203-204); otherwise it carries on from the step's end
+    if (t_new - A.lambda_end >= 0.0) {
+        store_result(A, P.idx, xn, vn, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
+        return false;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        R.x[c] = xn[c];
+        R.v[c] = vn[c];
+        R.a1[c] = a7[c];
+    }
+    R.t = t_new;
+    R.h_abs = h_next;
+    R.r_cur = r_new;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1310,164 +1503,241 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
     return sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) - R;
 }
 
+// One parked RK4 step, resolved by a lane of the event drain (see dp54_resolve_parked for the record; the fixed-step
+// regime keeps Brent on the cubic Hermite interpolant for every event).
 template <int RHS, int EVT>
-__device__ __forceinline__ bool rk4_resolve_event(const TraceArgs &A, const double x[3], const double v[3],
-                                                  const double a1[3], double t, double t_new, double h,
-                                                  double h_next, uint32_t kind, uint32_t idx, const Metric &m)
+__device__ __forceinline__ bool rk4_resolve_parked(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
 {
+    constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
+    const double t = P.t;
+    double t_new = t + P.r_cur;
+    if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
+    const double h = t_new - t;
     Hermite d;
     double r_new;
-    rk4_step<RHS>(x, v, a1, h, m, d.x1, d.v1, d.a1, r_new);
+    rk4_step<RHS>(P.x, P.v, P.a1, h, m, d.x1, d.v1, d.a1, r_new);
     d.t0 = t;
     d.h = h;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        d.x0[c] = x[c];
-        d.v0[c] = v[c];
-        d.a0[c] = a1[c];
+        d.x0[c] = P.x[c];
+        d.v0[c] = P.v[c];
+        d.a0[c] = P.a1[c];
     }
-    const bool ended = settle_events<EVT>(
-        A, kind, idx, t, t_new, x, d.x1, [&](double tt, double R) { return hermite_g(d, tt, R, RHS == BHG_RHS_KERR_BL_); },
+    double best;
+    int obj;
+    const uint32_t fl = settle_events<EVT>(
+        A, kind, t, t_new, P.x, d.x1, [&](double tt, double Rr) { return hermite_g(d, tt, Rr, BL); },
         [&](double tt) {
             double xx[3], vv[3];
             hermite_eval(d, tt, xx, vv);
-            if (RHS != BHG_RHS_KERR_BL_) return xx[2];
+            if (!BL) return xx[2];
             double sn, cs;
             sincos_pi4(xx[1], sn, cs);
             return cs;
         },
-        [&](double tt, double xe[3]) {
+        [&](double tt, double xq[3]) {
             double vv[3];
-            hermite_eval(d, tt, xe, vv);
+            hermite_eval(d, tt, xq, vv);
         },
-        [&](double tt, double xe[3], double ve[3]) { hermite_eval(d, tt, xe, ve); }, RHS == BHG_RHS_KERR_BL_);
-    if (!(EVT & (EVT_DISK | EVT_OBJ))) return false;
-    return ended ? false : finish_or_resume(A, idx, d.x1, d.v1, d.a1, t_new, r_new, h_next);
-}
-
-// ------------------------------------------------------------------------------------------
-// A lane whose accepted step crossed (or may have crossed) an event surface parks the step's START state in
-// global memory (its own end[] slot and its ws[] record slot, both free by now) and refills at once; the ray's
-// index goes on the wave's parked-event list and the event drain below recomputes that step converged.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void park_event(const TraceArgs &A, const Lane &L, double h, double t_new)
-{
-    // ws[idx] = {a1, t_new, h, |h| the controller chose for the NEXT step (L.h_abs, already updated)}.
-    // t_new is stored as the integrate loop computed it (possibly clipped to lambda_end): t + h need
-    // not reproduce it bit for bit, and "did the step reach lambda_end" must not depend on that.
-    double *e = A.end + (size_t)L.idx * 6;
-    reinterpret_cast<double2 *>(e)[0] = make_double2(L.x[0], L.x[1]);
-    reinterpret_cast<double2 *>(e)[1] = make_double2(L.x[2], L.v[0]);
-    reinterpret_cast<double2 *>(e)[2] = make_double2(L.v[1], L.v[2]);
-    double *w = A.ws + (size_t)L.idx * (size_t)A.ws_stride;
-    w[0] = L.a1[0];
-    w[1] = L.a1[1];
-    w[2] = L.a1[2];
-    w[3] = t_new;
-    w[4] = h;
-    w[5] = L.h_abs;
-    A.n_steps[L.idx] = L.n_att;
-    A.n_accepted[L.idx] = L.n_acc;
-}
-
-// Put this iteration's parked rays on the wave's event list.  Called from uniform control flow with kind != 0 on
-// the lanes that parked.
-template <int RHS>
-__device__ __forceinline__ void push_events(WaveLds<RHS> &Q, Wave &W, uint32_t idx, uint32_t kind)
-{
-    const uint64_t pm = __ballot(kind != 0u);
-    if (pm) {
-        if (kind) {
-            const uint32_t s = (uint32_t)W.ev_count + lane_rank(pm);
-            Q.ev_idx[s] = idx;
-            Q.ev_kind[s] = (uint8_t)kind;
-        }
-        W.ev_count += __builtin_popcountll(pm);
+        BL, best, obj);
+    if (fl) {
+        double xe[3], ve[3];
+        hermite_eval(d, best, xe, ve);
+        store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
+        if (obj >= 0 && A.object_id) A.object_id[P.idx] = (int8_t)obj;
+        return false;
     }
+    if (t_new - A.lambda_end >= 0.0) {
+        store_result(A, P.idx, d.x1, d.v1, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
+        return false;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        R.x[c] = d.x1[c];
+        R.v[c] = d.v1[c];
+        R.a1[c] = d.a1[c];
+    }
+    R.t = t_new;
+    R.h_abs = P.h_abs;
+    R.r_cur = r_new;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
-// Event drain: up to 64 parked steps are recomputed, one per lane, their dense output built and the event roots
-// located by Brent (scipy's solve_event_equation); the earliest terminal root ends the ray.  A step that holds no
-// terminal event after all (disk plane crossed outside the annulus, a chord through an object sphere that the
-// curve itself misses) sends its ray to the wave's resume list.  Runs only when the ray queue is empty: the
-// lanes' own rays wait in the queue's storage meanwhile, so the drain has the whole register budget and the
-// root search always runs (nearly) 64 lanes wide -- never one lane wide inside the step loop.
+// Event drain: up to 64 parked steps are resolved, one per lane (dp54_resolve_parked / rk4_resolve_parked): the ray
+// ends there, or -- no terminal event after all: a disk plane crossed outside the annulus, a chord through an object
+// sphere that the curve itself misses -- goes back into the ray queue to carry on.  The root search therefore always
+// runs (nearly) 64 lanes wide, never one lane wide inside the step loop.
+//
+// Can run at ANY time: each draining lane SWAPS registers with the slot it drains (the parked record comes out, the
+// lane's own state goes in and comes back afterwards), so the drain has the whole register budget and needs no
+// storage of its own; the lanes of a partial drain that have nothing to resolve put their state into free slots
+// (take < 64 only happens with an empty queue, and then n_free = NSLOT - n_ev >= 64 - take).
 // ------------------------------------------------------------------------------------------
 template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, int take)
 {
-    q_put<RHS>(Q, lane, L.x, L.v, L.a1, L.h_abs, L.r_cur, L.t, L.E, L.Lz, L.idx, L.n_att, L.n_acc,
-               L.active | (L.rejected << 1));
-    wave_lds_sync();
+    const bool mine = (int)lane < take;
+    const uint32_t s = mine ? Q.ev_list[W.n_ev - take + (int)lane] : Q.free_list[W.n_free - 1 - ((int)lane - take)];
+    Lane P;
+    P.E = P.Lz = 0.0;
+    uint32_t kind = 0;
+    if (mine) kind = slot_get<RHS>(Q.slot[s], P);
+    slot_put<RHS>(Q.slot[s], L, lane_bits(L));
 
-    const int take = W.ev_count < 64 ? W.ev_count : 64;
-    const int base = W.ev_count - take;
     bool resumed = false;
-    uint32_t i = 0;
-    if ((int)lane < take) {
-        i = Q.ev_idx[base + lane];
-        const uint32_t kind = Q.ev_kind[base + lane];
-        const double *e = A.end + (uint64_t)i * 6;
-        const double *w = A.ws + (uint64_t)i * (uint64_t)A.ws_stride;
-        double x[3] = {e[0], e[1], e[2]}, v[3] = {e[3], e[4], e[5]}, a1[3] = {w[0], w[1], w[2]};
-        const double t_new = w[3], h = w[4], h_next = w[5];
-        const double t = t_new - h;  // the step's start, good to an ulp: only brackets the root search
+    bool general = false;
+    Lane R;
+    if (mine) {
         Metric met;
         met.r_s = A.r_s;
         met.M = 0.5 * A.r_s;
         met.a = A.spin;
-        met.E = met.L = 0.0;
-        if (RHS == BHG_RHS_KERR_BL_) {
-            met.E = w[6];
-            met.L = w[7];
-        }
+        met.E = P.E;
+        met.L = P.Lz;
         if (ADAPTIVE)
-            resumed = dp54_resolve_event<RHS, EVT>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+            resumed = dp54_resolve_parked<RHS, EVT>(A, met, P, kind, R, general);
         else
-            resumed = rk4_resolve_event<RHS, EVT>(A, x, v, a1, t, t_new, h, h_next, kind, i, met);
+            resumed = rk4_resolve_parked<RHS, EVT>(A, met, P, kind, R);
     }
-    const uint64_t rm = __ballot(resumed);
-    if (resumed) Q.res_idx[(uint32_t)W.res_count + lane_rank(rm)] = i;
-    W.ev_count = base;
-    W.res_count += __builtin_popcountll(rm);
+#ifdef BHG_DIAG
+    W.diag_general += (unsigned long long)__builtin_popcountll(__ballot(general));
+#endif
+    (void)general;
+    // own state back; the slot then takes the ray that carries on (and joins the queue), or is free again
+    const uint32_t bits = slot_get<RHS>(Q.slot[s], L);
+    lane_set_bits(L, bits);
+    const uint64_t rm = __ballot(resumed), fm = __ballot(mine && !resumed);
+    if (resumed) {
+        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, 0u);
+        Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)] = (uint8_t)s;
+    } else if (mine) {
+        // (written at n_ev-relative positions of the FREE stack's top: the slots borrowed by the idle lanes of a partial
+        // drain sit below n_free and are not touched)
+        Q.free_list[W.n_free + (int)lane_rank(fm)] = (uint8_t)s;
+    }
     wave_lds_sync();
-
-    const uint32_t fl = q_get<RHS>(Q, lane, L);
-    L.active = fl & 1u;
-    L.rejected = (fl >> 1) & 1u;
-    wave_lds_sync();
+    // Nothing of the drain's own memory traffic (its register spills use scratch, i.e. vmcnt) may look pending to the
+    // step loop: the compiler would otherwise guard the loop's first use of such a register with a vmcnt(0), which also
+    // waits for the previous iteration's result stores -- in EVERY iteration (see fill_batch).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+    W.n_ev -= take;
+    W.q_count += __builtin_popcountll(rm);
+    W.n_free += __builtin_popcountll(fm);
 }
 
-// The ray queue is empty: work off parked events, then put rays into the queue -- resumed ones first, else a new batch.
-// Leaves the queue empty only if there is nothing to hand out right now (no batch left, nothing to resume; parked
-// events may still wait for the last active lanes).  The rare part of refill(), kept apart from the pop so that the
-// lanes' state is only touched here by the drain's save / restore (the step loop's common path then carries no
-// register copies for it).
+// Lanes that hold a step to park (L.pend) put its record into free slots, as many as there are.  A lane that finds
+// none keeps its record in its registers and stays inactive until slots come free: every pop frees one, and with an
+// empty queue and no free slot all NSLOT >= 64 slots hold parked steps, which the next service() drains.
+template <int RHS>
+__device__ __forceinline__ void deposit_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+{
+    const uint64_t pm = __ballot(L.pend != 0u);
+    if (!pm || W.n_free == 0) return;
+    const int n = __builtin_popcountll(pm);
+    const int can = n < W.n_free ? n : W.n_free;
+    const uint32_t rk = lane_rank(pm);
+    if (L.pend != 0u && (int)rk < can) {
+        const uint32_t s = Q.free_list[W.n_free - 1 - (int)rk];
+        slot_put<RHS>(Q.slot[s], L, L.pend);
+        Q.ev_list[W.n_ev + (int)rk] = (uint8_t)s;
+        L.pend = 0u;
+    }
+    wave_lds_sync();
+    W.n_free -= can;
+    W.n_ev += can;
+}
+
+// Serve the lanes that wait for a ray from the queue: at most one pop per lane, straight into the lane's registers;
+// the popped slots are free again.
+template <int RHS>
+__device__ __forceinline__ void pop_rays(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+{
+    const uint64_t need = __ballot(!L.active && L.pend == 0u);
+    const int n_need = __builtin_popcountll(need);
+    const int take = n_need < W.q_count ? n_need : W.q_count;
+    const uint32_t rk = lane_rank(need);
+    if (!L.active && L.pend == 0u && (int)rk < take) {
+        const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
+        (void)slot_get<RHS>(Q.slot[s], L);
+        Q.free_list[W.n_free + (int)rk] = (uint8_t)s;
+        L.rejected = 0u;
+        L.active = 1u;
+    }
+    wave_lds_sync();
+    W.q_head = (W.q_head + take) & (QRING - 1);
+    W.q_count -= take;
+    W.n_free += take;
+}
+
+// The pool is full (no free slot) while rays are queued, and lanes hold steps to park: such a lane SWAPS with the
+// head of the queue -- the queued ray comes out, the park record goes into its slot.  Without this a wave whose 64
+// lanes all wait to park next to a non-empty queue would wait for ever (nobody pops, so no slot comes free, and fewer
+// than 64 steps may be parked, so nothing drains).  Rare; kept apart so that the plain pop needs no register copies.
+template <int RHS>
+__device__ __forceinline__ void swap_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+{
+    const uint64_t pm = __ballot(L.pend != 0u);
+    const int n = __builtin_popcountll(pm);
+    const int take = n < W.q_count ? n : W.q_count;
+    const uint32_t rk = lane_rank(pm);
+    if (L.pend != 0u && (int)rk < take) {
+        const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
+        Lane T;
+        T.E = T.Lz = 0.0;
+        (void)slot_get<RHS>(Q.slot[s], T);
+        slot_put<RHS>(Q.slot[s], L, L.pend);
+        Q.ev_list[W.n_ev + (int)rk] = (uint8_t)s;
+        const uint32_t act = L.active;
+        L = T;
+        L.rejected = 0u;
+        L.pend = 0u;
+        L.active = 1u;
+        (void)act;
+    }
+    wave_lds_sync();
+    W.q_head = (W.q_head + take) & (QRING - 1);
+    W.q_count -= take;
+    W.n_ev += take;
+}
+
+// The rare part of service(): drain parked steps and / or put rays into the empty queue.
+//   * drain 64 parked steps whenever 64 are parked -- at any time, the queue need not be empty;
+//   * with an empty queue: a new 64-ray batch needs 64 free slots, so if fewer are free, what is parked (more than
+//     NSLOT - 64 steps then) is drained first, however few; once the work counters are dry and every lane has come to
+//     rest, what is still parked is drained too and the rays it hands back carry on;
+//   * (no prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries, and the
+//     s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's result stores --
+//     measured in round 2: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
+// ONE loop with one site each for the drain and the queue fill (each is several hundred instructions), kept apart from
+// the pop: a loop around the pop makes the whole lane state a loop-carried value and costs ~20 register copies in
+// every iteration of the step loop (round 2's "register-copy storm", met again here).
 template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, uint64_t idle)
+__device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     for (;;) {
-        // The queue's storage is free: the moment to work off parked events 64 lanes wide -- whenever 64 have
-        // piled up, or, at the very end (no batch left, nothing to resume, every lane idle), whatever is left.
-        while (W.ev_count >= 64 || (W.ev_count > 0 && W.exhausted && W.res_count == 0 && idle == ~0ull)) {
+        int take = 0;
+        if (W.n_ev >= 64)
+            take = 64;
+        else if (W.q_count == 0 && W.n_ev > 0 &&
+                 (W.exhausted ? (__ballot(L.active != 0u) == 0ull) : (W.n_free < 64)))
+            take = W.n_ev;
+        if (take) {
 #ifdef BHG_DIAG
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-            W.diag_drained += (unsigned long long)(W.ev_count < 64 ? W.ev_count : 64);
+            W.diag_drained += (unsigned long long)take;
 #endif
-            drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
+            drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane, take);
 #ifdef BHG_DIAG
             W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
 #endif
+            deposit_parked<RHS>(Q, W, L, lane);     // (lanes that found no slot before have one now)
+            continue;
         }
-        if (W.res_count > 0) {
-            fill_resumed<RHS>(A, Q, W, lane);  // resumed rays first: a new batch is only claimed without any
-            return;
-        }
-        if (W.exhausted) return;
-        // (No prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries,
-        // and the s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's
-        // result stores -- measured: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
+        if (W.n_free == 0 && W.q_count > 0 && __ballot(L.pend != 0u) != 0ull) swap_parked<RHS>(Q, W, L, lane);
+        if (W.q_count > 0 || W.exhausted || __ballot(!L.active) == 0ull) return;
+        // the queue is empty, lanes wait, 64 slots are free: claim a batch
         const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
         if (base >= A.n) {
             // this slice is dry: steal from the next one
@@ -1492,35 +1762,20 @@ __device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, W
 #ifdef BHG_DIAG
         W.diag_fill_cyc += __builtin_amdgcn_s_memtime() - c0;
 #endif
-        if (W.q_count > 0) return;
     }
 }
 
-// Give idle lanes new rays: at most one replenishment of the queue and one pop per call (lanes the queue could not
-// serve are served by the next iteration's call).  Returns the idle mask afterwards (all ones: the wave is done --
-// nothing in flight, queued, parked or waiting to resume, and no batch left to claim).
+// Some lane is not stepping: park what has to be parked, (rarely) drain and refill, give the waiting lanes rays from
+// the queue -- at most one pop per lane and call (a lane the queue could not serve is served by the next iteration's
+// call).  Returns true when the wave is done: nothing in flight, queued, parked or waiting to be parked, no batch left.
 template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ uint64_t refill(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane,
-                                           uint64_t idle)
+__device__ __forceinline__ bool service(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
-    if (W.q_count == 0) replenish<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane, idle);
-    if (W.q_count > 0) {
-        const int n_idle = __builtin_popcountll(idle);
-        const int take = n_idle < W.q_count ? n_idle : W.q_count;
-        if (!L.active) {
-            const int rk = (int)lane_rank(idle);
-            if (rk < take) {
-                (void)q_get<RHS>(Q, (uint32_t)(W.q_head + rk), L);
-                L.rejected = 0u;
-                L.active = 1u;
-            }
-        }
-        wave_lds_sync();
-        W.q_head += take;
-        W.q_count -= take;
-        idle = __ballot(!L.active);
-    }
-    return idle;
+    deposit_parked<RHS>(Q, W, L, lane);
+    if (__builtin_expect(W.n_ev >= 64 || (W.q_count == 0 && !(W.exhausted && W.n_ev == 0)) || W.n_free == 0, 0))
+        replenish<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
+    if (W.q_count > 0) pop_rays<RHS>(Q, W, L, lane);
+    return W.exhausted && W.q_count == 0 && W.n_ev == 0 && __ballot(L.active != 0u || L.pend != 0u) == 0ull;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1569,11 +1824,14 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     L.t = L.h_abs = L.r_cur = 0.0;
     L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
-    L.active = L.rejected = 0u;
+    L.active = L.rejected = L.pend = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
-    W.ev_count = W.res_count = 0;
+    W.n_ev = 0;
+    W.n_free = NSLOT;
     W.exhausted = false;
+    for (int i = (int)lane; i < NSLOT; i += 64) Q.free_list[i] = (uint8_t)i;
+    wave_lds_sync();
 #ifdef BHG_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
@@ -1583,23 +1841,21 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     W.dry = 0;
 
     for (;;) {
-        uint64_t idle = __ballot(!L.active);
-        if (idle) {
+        if (__ballot(!L.active)) {
 #ifdef BHG_DIAG
             const unsigned long long rc0 = __builtin_amdgcn_s_memtime();
 #endif
-            idle = refill<RHS, true, EVT>(A, Q, W, L, lane, idle);
+            const bool done = service<RHS, true, EVT>(A, Q, W, L, lane);
 #ifdef BHG_DIAG
             W.diag_refill_cyc += __builtin_amdgcn_s_memtime() - rc0;
 #endif
-            if (idle == ~0ull) break;  // nothing in flight, nothing queued, nothing left
+            if (done) break;  // nothing in flight, nothing queued or parked, nothing left
         }
 #ifdef BHG_DIAG
         diag_iters++;
         diag_lanes += __builtin_popcountll(__ballot(L.active));
 #endif
 
-        uint32_t parked = 0;  // EV_* bits if this lane parks its step in this iteration
         if (L.active) {
             // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
             uint32_t term = 0;
@@ -1619,7 +1875,8 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
                 L.active = 0u;
             } else {
-                double t_new = L.t + L.h_abs;
+                const double h_try = L.h_abs;   // (the event drain redoes the next three lines from this value)
+                double t_new = L.t + h_try;
                 if (t_new - t_bound > 0.0) t_new = t_bound;
                 const double h = t_new - L.t;
                 L.h_abs = fabs(h);
@@ -1666,9 +1923,11 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                                                   : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                         ev_d = false;
                     if (ev_h || ev_e || ev_d || ev_o) {
-                        // x, v, a1, t still hold the step's start: the event drain recomputes it
-                        park_event(A, L, h, t_new);
-                        parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
+                        // Park the step: x, v, a1, t still hold its START (the event drain recomputes it from there),
+                        // h_abs is already the controller's choice for the next step, the radius register takes the
+                        // |h| this step tried.  The record goes into the wave's LDS pool when the lane is next served.
+                        L.pend = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
+                        L.r_cur = h_try;
                         L.active = 0u;
                     } else {
                         // take the step (ONE place where the lane's state is overwritten: the compiler otherwise
@@ -1692,7 +1951,6 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 }
             }
         }
-        push_events<RHS>(Q, W, L.idx, parked);
     }
 #ifdef BHG_DIAG
     if (lane == 0 && A.diag) {
@@ -1730,21 +1988,19 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     L.t = L.h_abs = L.r_cur = 0.0;
     L.E = L.Lz = 0.0;
     L.idx = L.n_att = L.n_acc = 0;
-    L.active = L.rejected = 0u;
+    L.active = L.rejected = L.pend = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
-    W.ev_count = W.res_count = 0;
+    W.n_ev = 0;
+    W.n_free = NSLOT;
     W.exhausted = false;
+    for (int i = (int)lane; i < NSLOT; i += 64) Q.free_list[i] = (uint8_t)i;
+    wave_lds_sync();
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
 
     for (;;) {
-        uint64_t idle = __ballot(!L.active);
-        if (idle) {
-            idle = refill<RHS, false, EVT>(A, Q, W, L, lane, idle);
-            if (idle == ~0ull) break;
-        }
-        uint32_t parked = 0;
+        if (__ballot(!L.active) && service<RHS, false, EVT>(A, Q, W, L, lane)) break;
         if (L.active) {
             uint32_t term = 0;
             if (L.t >= t_bound)
@@ -1775,10 +2031,11 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                                               : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                     ev_d = false;
                 if (ev_h || ev_e || ev_d || ev_o) {
+                    // (park record as in the DP5(4) loop: next |h| and the |h| this step tried are both h_fixed)
                     L.n_acc = L.n_att;
                     L.h_abs = hf;
-                    park_event(A, L, h, t_new);
-                    parked = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
+                    L.r_cur = hf;
+                    L.pend = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
                     L.active = 0u;
                 } else if (!(r_new == r_new)) {
                     store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
@@ -1795,7 +2052,6 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 }
             }
         }
-        push_events<RHS>(Q, W, L.idx, parked);
     }
 }
 
