@@ -495,10 +495,13 @@ __device__ __forceinline__ double pow_0p2(double x)
 // (x0) and writes final results, and that is all of its HBM traffic.  Round 2 parked in the rays' own output slots:
 // 2 x 96 bytes per parked step through L2, 3.3 - 5 x the algorithmic bytes on the event-heavy frames.
 // ------------------------------------------------------------------------------------------
-// Slots per wave.  Schwarzschild forms run 12 waves per CU (3 per SIMD): 160 KiB / 12 = 13,653 bytes per wave
-// = 118 records of 112 bytes + the lists.  Kerr runs 8 waves per CU and has room to spare.
+// Slots per wave.  Schwarzschild forms run 12 waves per CU (3 per SIMD), and the CU hands its 160 KiB of LDS out in
+// 128 granules of 1,280 bytes: 10 granules = 12,800 bytes per wave = 111 records of 112 bytes + the lists.  (One
+// granule more and only 11 waves fit, whatever the occupancy API says: measured -- with 118 and with 115 slots a
+// twelfth of the persistent waves started when the first ones had finished; with 106 all start within 1.3 us.)
+// Kerr runs 8 waves per CU and has room to spare.
 #ifndef BHG_NSLOT
-#define BHG_NSLOT 118
+#define BHG_NSLOT 111
 #endif
 constexpr int NSLOT = BHG_NSLOT;
 constexpr int QRING = 128;   // ring size of the queue list (a power of two >= NSLOT)
@@ -521,8 +524,32 @@ struct WaveLds {
     QEntry<RHS> slot[NSLOT];
     uint8_t q_list[QRING];      // slots of the queued rays, a ring: q_head .. q_head + q_count - 1 (mod QRING)
     uint8_t free_list[NSLOT];   // free slots, a stack of n_free entries
-    uint8_t ev_list[NSLOT];     // slots of the parked steps, a stack of n_ev entries
+#ifdef BHG_CHECK
+    uint8_t tag[NSLOT];         // debugging: 0 free, 1 queued, 2 parked short, 3 parked long, 4 borrowed
+#endif
+    uint8_t ev_list[NSLOT];     // slots of the parked steps: the SHORT list (one candidate event, exit sphere or disk
+                                // plane: certified Newton search) grows up from [0], the LONG list (horizon, several
+                                // candidates, object spheres, failed certificates: Brent) grows down from [NSLOT - 1]
 };
+
+#ifdef BHG_CHECK
+#define SLOT_CHECK(Q, s, want, now, where)                                                                       \
+    do {                                                                                                         \
+        if ((s) >= (uint32_t)NSLOT || (Q).tag[(s)] != (want))                                                    \
+            printf("SLOT_CHECK %s: slot %u tag %d want %d (block %d lane %d)\n", where, (unsigned)(s),           \
+                   (s) < (uint32_t)NSLOT ? (int)(Q).tag[(s)] : -1, (int)(want), (int)blockIdx.x, (int)threadIdx.x); \
+        if ((s) < (uint32_t)NSLOT) (Q).tag[(s)] = (now);                                                         \
+    } while (0)
+#define INV_CHECK(W, where)                                                                                     \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && (W).n_free + (W).q_count + (W).n_evA + (W).n_evB != NSLOT)                       \
+            printf("INV_CHECK %s: free %d queue %d short %d long %d (block %d)\n", where, (W).n_free, (W).q_count, \
+                   (W).n_evA, (W).n_evB, (int)blockIdx.x);                                                       \
+    } while (0)
+#else
+#define SLOT_CHECK(Q, s, want, now, where) do { } while (0)
+#define INV_CHECK(W, where) do { } while (0)
+#endif
 
 template <int RHS>
 __device__ __forceinline__ void entry_put(QEntry<RHS> &e, const double x[3], const double k[3], const double a[3], double h,
@@ -716,11 +743,13 @@ __device__ __forceinline__ void lane_set_bits(Lane &L, uint32_t b)
 
 struct Wave {
     int q_head, q_count;         // the queue ring
-    int n_free, n_ev;            // entries of the free-slot stack and of the parked-step stack
+    int n_free;                  // entries of the free-slot stack
+    int n_evA, n_evB;            // parked steps on the short list and on the long list (see WaveLds::ev_list)
     bool exhausted;
     uint32_t slice, dry;         // current slice, number of slices found dry so far
 #ifdef BHG_DIAG
     unsigned long long diag_drain_cyc = 0, diag_drained = 0, diag_fill_cyc = 0, diag_refill_cyc = 0, diag_general = 0;
+    unsigned long long diag_drained_long = 0, diag_drain_long_cyc = 0;
 #endif
 };
 
@@ -916,12 +945,14 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, 
     if (valid) {
         const uint32_t rk = lane_rank(vmask);
         const uint32_t s = Q.free_list[W.n_free - 1 - (int)rk];
+        SLOT_CHECK(Q, s, 0, 1, "fill");
         Q.q_list[(W.q_head + W.q_count + (int)rk) & (QRING - 1)] = (uint8_t)s;
         entry_put<RHS>(Q.slot[s], px, pk, pa, ph, pr, 0.0, pE, pL, (uint32_t)i, 0u, 0u, 0u);
     }
     wave_lds_sync();
     W.n_free -= cnt;
     W.q_count += cnt;
+    INV_CHECK(W, "fill");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1245,9 +1276,14 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // horizon with the Christoffel form's 1/f terms: round 2 found dense outputs with several crossings there, and
 // which one brentq lands on is part of the contract) -- goes through Brent, step for step as before.
 // ------------------------------------------------------------------------------------------
+// Outcome of a parked step
+constexpr int PARK_ENDED = 0, PARK_RESUME = 1, PARK_UNCERTIFIED = 2;
+
+// The SHORT way: one candidate event (exit sphere or disk plane; the horizon too, where its certificate holds) whose
+// event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything when
+// the certificate (or the iteration) fails: the step then goes to the long list.
 template <int RHS, int EVT>
-__device__ __forceinline__ bool dp54_resolve_parked(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind,
-                                                    Lane &R, bool &went_general)
+__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
 {
     constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
     const double t = P.t, h_next = P.h_abs;
@@ -1260,175 +1296,126 @@ __device__ __forceinline__ bool dp54_resolve_parked(const TraceArgs &A, const Me
     Dense d;
     build_dense_pos(d, t, h, P.x, P.v, P.a1, a2, a3, a4, a5, a6, a7);
 
-    uint32_t fl = 0;            // flag of the event that ends the ray, 0 = none
-    double xe[3], ve[3];        // ... and the state there
-    int obj = -1;
-    bool settled = false;
-
-    // ---- certified monotone single event: Newton on the polynomial ----
-#ifdef BHG_NO_NEWTON
-    const bool single = false;
-#else
-    const bool single = kind == EV_HORIZON || ((EVT & EVT_EXIT) && kind == EV_EXIT) || ((EVT & EVT_DISK) && kind == EV_DISK);
-#endif
-    if (single) {
-        const bool is_disk = (EVT & EVT_DISK) && kind == EV_DISK;
-        double Ec[3], Dc[3];
+    const bool is_disk = (EVT & EVT_DISK) && kind == EV_DISK;
+    double Ec[3], Dc[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double q1 = fabs(d.qx[1][c]), q2 = fabs(d.qx[2][c]), q3 = fabs(d.qx[3][c]);
+        Ec[c] = q1 + q2 + q3;
+        Dc[c] = __builtin_fma(4.0, q3, __builtin_fma(3.0, q2, 2.0 * q1));
+    }
+    bool mono;
+    int comp = 0;               // Boyer-Lindquist: the coordinate the event function is
+    double target = 0.0;        // BL: its value on the event surface;  Cartesian spheres: R^2
+    if (BL) {
+        comp = is_disk ? 1 : 0;
+        if (is_disk) {
+            // the plane theta* = pi/2 + k pi between the step ends (more than one: Brent decides)
+            const double k0 = floor((P.x[1] - 1.5707963267948966) * 0.3183098861837907);
+            const double k1 = floor((xn[1] - 1.5707963267948966) * 0.3183098861837907);
+            target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
+            mono = fabs(k1 - k0) == 1.0 && fabs(P.v[1]) > 1.0000001 * Dc[1];
+        } else {
+            target = kind == EV_HORIZON ? A.r_hor : A.r_exit;
+            mono = kind == EV_HORIZON ? (P.v[0] < -1.0000001 * Dc[0]) : (P.v[0] > 1.0000001 * Dc[0]);
+        }
+    } else if (is_disk) {
+        mono = fabs(P.v[2]) > 1.0000001 * Dc[2];
+    } else {
+        const double Rr = kind == EV_HORIZON ? A.r_hor : A.r_exit;
+        target = Rr * Rr;
+        double xv = 0.0, vv = 0.0, S = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const double q1 = fabs(d.qx[1][c]), q2 = fabs(d.qx[2][c]), q3 = fabs(d.qx[3][c]);
-            Ec[c] = q1 + q2 + q3;
-            Dc[c] = __builtin_fma(4.0, q3, __builtin_fma(3.0, q2, 2.0 * q1));
+            xv = __builtin_fma(P.x[c], P.v[c], xv);
+            vv = __builtin_fma(P.v[c], P.v[c], vv);
+            const double av = fabs(P.v[c]);
+            S = __builtin_fma(fabs(P.x[c]), Dc[c], S);
+            S = __builtin_fma(h, __builtin_fma(av, Ec[c] + Dc[c], Ec[c] * Dc[c]), S);
         }
-        bool mono;
-        int comp = 0;               // Boyer-Lindquist: the coordinate the event function is
-        double target = 0.0;        // BL: its value on the event surface;  Cartesian spheres: R^2
+        S *= 1.0000001;
+        mono = kind == EV_HORIZON ? (__builtin_fma(h, vv, xv) < -S) : (xv > S);
+    }
+    // G(th) and dG/dth on the position polynomial
+    auto eval = [&](double th, double &g, double &dg, double xs[3]) {
+        double ds[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double sx = __builtin_fma(d.qx[3][c], th, d.qx[2][c]);
+            sx = __builtin_fma(sx, th, d.qx[1][c]);
+            sx = __builtin_fma(sx, th, d.qx[0][c]);
+            xs[c] = __builtin_fma(h * th, sx, d.x0[c]);     // = dense_pos
+            double sd = __builtin_fma(4.0 * d.qx[3][c], th, 3.0 * d.qx[2][c]);
+            sd = __builtin_fma(sd, th, 2.0 * d.qx[1][c]);
+            sd = __builtin_fma(sd, th, d.qx[0][c]);
+            ds[c] = h * sd;
+        }
         if (BL) {
-            comp = is_disk ? 1 : 0;
-            if (is_disk) {
-                // the plane theta* = pi/2 + k pi between the step ends (more than one: Brent decides)
-                const double k0 = floor((P.x[1] - 1.5707963267948966) * 0.3183098861837907);
-                const double k1 = floor((xn[1] - 1.5707963267948966) * 0.3183098861837907);
-                target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
-                mono = fabs(k1 - k0) == 1.0 && fabs(P.v[1]) > 1.0000001 * Dc[1];
-            } else {
-                target = kind == EV_HORIZON ? A.r_hor : A.r_exit;
-                mono = kind == EV_HORIZON ? (P.v[0] < -1.0000001 * Dc[0]) : (P.v[0] > 1.0000001 * Dc[0]);
-            }
+            g = (comp == 1 ? xs[1] : xs[0]) - target;
+            dg = comp == 1 ? ds[1] : ds[0];
         } else if (is_disk) {
-            mono = fabs(P.v[2]) > 1.0000001 * Dc[2];
+            g = xs[2];
+            dg = ds[2];
         } else {
-            const double R = kind == EV_HORIZON ? A.r_hor : A.r_exit;
-            target = R * R;
-            double xv = 0.0, vv = 0.0, S = 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                xv = __builtin_fma(P.x[c], P.v[c], xv);
-                vv = __builtin_fma(P.v[c], P.v[c], vv);
-                const double av = fabs(P.v[c]);
-                S = __builtin_fma(fabs(P.x[c]), Dc[c], S);
-                S = __builtin_fma(h, __builtin_fma(av, Ec[c] + Dc[c], Ec[c] * Dc[c]), S);
-            }
-            S *= 1.0000001;
-            mono = kind == EV_HORIZON ? (__builtin_fma(h, vv, xv) < -S) : (xv > S);
+            g = __builtin_fma(xs[2], xs[2], __builtin_fma(xs[1], xs[1], xs[0] * xs[0])) - target;
+            dg = 2.0 * __builtin_fma(xs[2], ds[2], __builtin_fma(xs[1], ds[1], xs[0] * ds[0]));
         }
-        if (mono) {
-            // G(th) and dG/dth on the position polynomial
-            auto eval = [&](double th, double &g, double &dg, double xs[3]) {
-                double ds[3];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double sx = __builtin_fma(d.qx[3][c], th, d.qx[2][c]);
-                    sx = __builtin_fma(sx, th, d.qx[1][c]);
-                    sx = __builtin_fma(sx, th, d.qx[0][c]);
-                    xs[c] = __builtin_fma(h * th, sx, d.x0[c]);     // = dense_pos
-                    double sd = __builtin_fma(4.0 * d.qx[3][c], th, 3.0 * d.qx[2][c]);
-                    sd = __builtin_fma(sd, th, 2.0 * d.qx[1][c]);
-                    sd = __builtin_fma(sd, th, d.qx[0][c]);
-                    ds[c] = h * sd;
-                }
-                if (BL) {
-                    g = (comp == 1 ? xs[1] : xs[0]) - target;
-                    dg = comp == 1 ? ds[1] : ds[0];
-                } else if (is_disk) {
-                    g = xs[2];
-                    dg = ds[2];
-                } else {
-                    g = __builtin_fma(xs[2], xs[2], __builtin_fma(xs[1], xs[1], xs[0] * xs[0])) - target;
-                    dg = 2.0 * __builtin_fma(xs[2], ds[2], __builtin_fma(xs[1], ds[1], xs[0] * ds[0]));
-                }
-            };
-            double g0, g1, dg, xs[3];
-            eval(0.0, g0, dg, xs);
-            eval(1.0, g1, dg, xs);
-            // the step ends bracket the root (that is what parked the step); G is monotone between them
-            double lo = 0.0, hi = 1.0;
-            const bool neg0 = g0 < 0.0;
-            double th = g0 * rcp_nr(g0 - g1);      // secant start
-            if (!(th > 0.0 && th < 1.0)) th = 0.5;
-            if (g0 == 0.0) th = 0.0;        // (an end exactly on the surface is the root, as in brentq)
-            else if (g1 == 0.0) th = 1.0;
-            // FOUR safeguarded Newton steps for every lane, no per-lane exit: from the secant start the error squares
-            // each time (1e-2, 1e-4, 1e-8, 1e-16 is typical), a lane that is there early repeats a step of ~0.  The
-            // root counts as found when the LAST step moved th by less than 1e-9 (the error left is then far below an
-            // ulp); anything slower -- a root next to an end of the bracket, a bisection on the way -- goes to Brent.
-            double dth = 1.0;
-            int dbg_it = 0;
-            (void)dbg_it;
+    };
+    double g0, g1, dg, xs[3];
+    eval(0.0, g0, dg, xs);
+    eval(1.0, g1, dg, xs);
+    // the step ends bracket the root (that is what parked the step); G is monotone between them
+    double lo = 0.0, hi = 1.0;
+    const bool neg0 = g0 < 0.0;
+    double th = g0 * rcp_nr(g0 - g1);      // secant start
+    if (!(th > 0.0 && th < 1.0)) th = 0.5;
+    if (g0 == 0.0) th = 0.0;        // (an end exactly on the surface is the root, as in brentq)
+    else if (g1 == 0.0) th = 1.0;
+    // FOUR safeguarded Newton steps for every lane, no per-lane exit: from the secant start the error squares
+    // each time (1e-2, 1e-4, 1e-8, 1e-16 is typical), a lane that is there early repeats a step of ~0.  The
+    // root counts as found when the LAST step moved th by less than 1e-9 (the error left is then far below an
+    // ulp); anything slower -- a root next to an end of the bracket, a bisection on the way -- goes to Brent.
+    double dth = 1.0;
 #pragma unroll 1
-            for (int it = 0; it < 4; it++) {
-                dbg_it++;
-                double g;
-                eval(th, g, dg, xs);
-                if ((g < 0.0) == neg0) lo = th; else hi = th;
-                dth = -g * rcp_nr(dg);
-                double thn = th + dth;
-                if (!(thn >= lo && thn <= hi)) {      // Newton left the bracket (or NaN): bisect
-                    thn = 0.5 * (lo + hi);
-                    dth = 1.0;
-                }
-                th = thn;
-            }
-            const bool conv = fabs(dth) <= 1e-9;
-            if (conv) {
-                double g;
-                eval(th, g, dg, xe);        // xe = position at the root
-                bool terminal = true;
-                if (is_disk) {
-                    double Rc;
-                    if (BL) {
-                        double sn, cs;
-                        sincos_pi4(xe[1], sn, cs);
-                        Rc = sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sn);
-                    } else {
-                        Rc = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
-                    }
-                    terminal = Rc >= A.disk_r_in && Rc <= A.disk_r_out;
-                }
-                if (terminal) {
-                    dense_dir_at(th, h, P.v, P.a1, a3, a4, a5, a6, a7, ve);
-#ifdef BHG_DEBUG_NEWTON
-                    ve[0] = th; ve[1] = g; ve[2] = (double)dbg_it + 100.0 * (double)kind; xe[0] = g0; xe[1] = g1; xe[2] = h;
-#endif
-                    fl = kind == EV_HORIZON ? BHG_FLAG_HIT_HORIZON_ : (is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_);
-                }
-                settled = true;
-            }
+    for (int it = 0; it < 4; it++) {
+        double g;
+        eval(th, g, dg, xs);
+        if ((g < 0.0) == neg0) lo = th; else hi = th;
+        dth = -g * rcp_nr(dg);
+        double thn = th + dth;
+        if (!(thn >= lo && thn <= hi)) {      // Newton left the bracket (or NaN): bisect
+            thn = 0.5 * (lo + hi);
+            dth = 1.0;
         }
+        th = thn;
     }
+    if (!(mono && fabs(dth) <= 1e-9)) return PARK_UNCERTIFIED;
 
-    // ---- everything else: Brent on the full dense output, scipy's search step for step ----
-    went_general = !settled;
-    if (__builtin_expect(!settled, 0)) {
-        build_dense_dir(d, P.a1, a2, a3, a4, a5, a6, a7);
-        double best;
-        fl = settle_events<EVT>(
-            A, kind, t, t_new, P.x, xn, [&](double tt, double Rr) { return dense_g(d, tt, Rr, BL); },
-            [&](double tt) {
-                if (!BL) return dense_z(d, tt);
-                double q[3];
-                dense_pos(d, tt, q);
-                double sn, cs;             // z = r cos(theta), r > 0; the RHS's own sincos (about an ulp, a quarter of
-                sincos_pi4(q[1], sn, cs);  // libm's cos with its large-argument ladder) -- once per Brent iterate
-                return cs;
-            },
-            [&](double tt, double xq[3]) { dense_pos(d, tt, xq); }, BL, best, obj);
-        if (fl) {
-            dense_pos(d, best, xe);
-            dense_dir(d, best, ve);
+    double g, xe[3], ve[3];
+    eval(th, g, dg, xe);        // xe = position at the root
+    bool terminal = true;
+    if (is_disk) {
+        double Rc;
+        if (BL) {
+            double sn, cs;
+            sincos_pi4(xe[1], sn, cs);
+            Rc = sqrt(xe[0] * xe[0] + A.spin * A.spin) * fabs(sn);
+        } else {
+            Rc = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
         }
+        terminal = Rc >= A.disk_r_in && Rc <= A.disk_r_out;
     }
-
-    if (fl) {
+    if (terminal) {
+        dense_dir_at(th, h, P.v, P.a1, a3, a4, a5, a6, a7, ve);
+        const uint32_t fl = kind == EV_HORIZON ? BHG_FLAG_HIT_HORIZON_ : (is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_);
         store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
-        if (obj >= 0 && A.object_id) A.object_id[P.idx] = (int8_t)obj;
-        return false;
+        return PARK_ENDED;
     }
-    // The step held no terminal event after all: the ray is final if the step reached lambda_end
-    // (base.py:203-204); otherwise it carries on from the step's end
+    // a disk-plane crossing outside the annulus: the ray is final if the step reached lambda_end (base.py:203-204),
+    // otherwise it carries on from the step's end
     if (t_new - A.lambda_end >= 0.0) {
         store_result(A, P.idx, xn, vn, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
-        return false;
+        return PARK_ENDED;
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -1439,7 +1426,60 @@ __device__ __forceinline__ bool dp54_resolve_parked(const TraceArgs &A, const Me
     R.t = t_new;
     R.h_abs = h_next;
     R.r_cur = r_new;
-    return true;
+    return PARK_RESUME;
+}
+
+// The LONG way, for everything else -- several candidates in one step, object spheres, the horizon (a step diving
+// through it with the Christoffel form's 1/f terms has a dense output of large curvature: its certificate practically
+// never holds, and round 2 found dense outputs with several crossings there: which one brentq lands on is part of the
+// contract), a failed certificate: Brent on the full dense output, scipy's search step for step.
+template <int RHS, int EVT>
+__device__ __forceinline__ int dp54_resolve_long(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
+{
+    constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
+    const double t = P.t, h_next = P.h_abs;
+    double t_new = t + P.r_cur;
+    if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
+    const double h = t_new - t;
+    double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+    dp54_stages<RHS>(P.x, P.v, P.a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+    Dense d;
+    build_dense(d, t, h, P.x, P.v, P.a1, a2, a3, a4, a5, a6, a7);
+    double best;
+    int obj;
+    const uint32_t fl = settle_events<EVT>(
+        A, kind, t, t_new, P.x, xn, [&](double tt, double Rr) { return dense_g(d, tt, Rr, BL); },
+        [&](double tt) {
+            if (!BL) return dense_z(d, tt);
+            double q[3];
+            dense_pos(d, tt, q);
+            double sn, cs;             // z = r cos(theta), r > 0; the RHS's own sincos (about an ulp, a quarter of
+            sincos_pi4(q[1], sn, cs);  // libm's cos with its large-argument ladder) -- once per Brent iterate
+            return cs;
+        },
+        [&](double tt, double xq[3]) { dense_pos(d, tt, xq); }, BL, best, obj);
+    if (fl) {
+        double xe[3], ve[3];
+        dense_pos(d, best, xe);
+        dense_dir(d, best, ve);
+        store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
+        if (obj >= 0 && A.object_id) A.object_id[P.idx] = (int8_t)obj;
+        return PARK_ENDED;
+    }
+    if (t_new - A.lambda_end >= 0.0) {
+        store_result(A, P.idx, xn, vn, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
+        return PARK_ENDED;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        R.x[c] = xn[c];
+        R.v[c] = vn[c];
+        R.a1[c] = a7[c];
+    }
+    R.t = t_new;
+    R.h_abs = h_next;
+    R.r_cur = r_new;
+    return PARK_RESUME;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1506,7 +1546,7 @@ __device__ __forceinline__ double hermite_g(const Hermite &d, double t, double R
 // One parked RK4 step, resolved by a lane of the event drain (see dp54_resolve_parked for the record; the fixed-step
 // regime keeps Brent on the cubic Hermite interpolant for every event).
 template <int RHS, int EVT>
-__device__ __forceinline__ bool rk4_resolve_parked(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
+__device__ __forceinline__ int rk4_resolve_parked(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
 {
     constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
     const double t = P.t;
@@ -1546,11 +1586,11 @@ __device__ __forceinline__ bool rk4_resolve_parked(const TraceArgs &A, const Met
         hermite_eval(d, best, xe, ve);
         store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
         if (obj >= 0 && A.object_id) A.object_id[P.idx] = (int8_t)obj;
-        return false;
+        return PARK_ENDED;
     }
     if (t_new - A.lambda_end >= 0.0) {
         store_result(A, P.idx, d.x1, d.v1, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
-        return false;
+        return PARK_ENDED;
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -1561,33 +1601,45 @@ __device__ __forceinline__ bool rk4_resolve_parked(const TraceArgs &A, const Met
     R.t = t_new;
     R.h_abs = P.h_abs;
     R.r_cur = r_new;
-    return true;
+    return PARK_RESUME;
 }
 
 // ------------------------------------------------------------------------------------------
-// Event drain: up to 64 parked steps are resolved, one per lane (dp54_resolve_parked / rk4_resolve_parked): the ray
-// ends there, or -- no terminal event after all: a disk plane crossed outside the annulus, a chord through an object
-// sphere that the curve itself misses -- goes back into the ray queue to carry on.  The root search therefore always
-// runs (nearly) 64 lanes wide, never one lane wide inside the step loop.
+// Event drains: parked steps are resolved up to 64 at a time, one per lane: the ray ends there, or -- no terminal event
+// after all: a disk plane crossed outside the annulus, a chord through an object sphere that the curve itself misses
+// -- goes back into the ray queue to carry on.  The root search therefore always runs many lanes wide, never one lane
+// wide inside the step loop.  Two lists, two drains:
 //
-// Can run at ANY time: each draining lane SWAPS registers with the slot it drains (the parked record comes out, the
-// lane's own state goes in and comes back afterwards), so the drain has the whole register budget and needs no
-// storage of its own; the lanes of a partial drain that have nothing to resolve put their state into free slots
-// (take < 64 only happens with an empty queue, and then n_free = NSLOT - n_ev >= 64 - take).
+//   SHORT list -> drain_short: steps with one candidate event, exit sphere or disk plane (every ray of a frame with an
+//     exit sphere ends on one).  dp54_resolve_short only; a step whose certificate fails moves to the long list.
+//     Can run at ANY time: each draining lane SWAPS registers with the slot it drains (the parked record comes out,
+//     the lane's own state goes in and comes back afterwards), so the drain has the whole register budget and needs
+//     no storage of its own; the lanes of a partial drain that have nothing to resolve put their state into free
+//     slots (the caller makes sure there are 64 - take).
+//   LONG list -> drain_long: horizon crossings, several candidates, object spheres: Brent (dp54_resolve_long).  A few
+//     per cent of the parked steps -- but with 64 lanes nearly every mixed drain held one, and then all 64 lanes
+//     waited for its search: kept apart they cost what they are.  Lanes keep their own state in registers here (no
+//     swap, no slots needed: the compiler spills what does not fit, this path is slow anyway), so it too runs at
+//     any time and at any width.
+// The fixed-step kernels (no certified search) put everything on the short list and resolve it with Brent there.
 // ------------------------------------------------------------------------------------------
 template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, int take)
+__device__ __forceinline__ void drain_short(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, int take)
 {
     const bool mine = (int)lane < take;
-    const uint32_t s = mine ? Q.ev_list[W.n_ev - take + (int)lane] : Q.free_list[W.n_free - 1 - ((int)lane - take)];
+    const uint32_t s = mine ? Q.ev_list[W.n_evA - take + (int)lane] : Q.free_list[W.n_free - 1 - ((int)lane - take)];
     Lane P;
     P.E = P.Lz = 0.0;
     uint32_t kind = 0;
+    if (mine) {
+        SLOT_CHECK(Q, s, 2, 4, "drain_short take");
+    } else {
+        SLOT_CHECK(Q, s, 0, 4, "drain_short borrow");
+    }
     if (mine) kind = slot_get<RHS>(Q.slot[s], P);
     slot_put<RHS>(Q.slot[s], L, lane_bits(L));
 
-    bool resumed = false;
-    bool general = false;
+    int outcome = PARK_ENDED;
     Lane R;
     if (mine) {
         Metric met;
@@ -1597,40 +1649,97 @@ __device__ __forceinline__ void drain_events(const TraceArgs &A, WaveLds<RHS> &Q
         met.E = P.E;
         met.L = P.Lz;
         if (ADAPTIVE)
-            resumed = dp54_resolve_parked<RHS, EVT>(A, met, P, kind, R, general);
+            outcome = dp54_resolve_short<RHS, EVT>(A, met, P, kind, R);
         else
-            resumed = rk4_resolve_parked<RHS, EVT>(A, met, P, kind, R);
+            outcome = rk4_resolve_parked<RHS, EVT>(A, met, P, kind, R);
     }
-#ifdef BHG_DIAG
-    W.diag_general += (unsigned long long)__builtin_popcountll(__ballot(general));
-#endif
-    (void)general;
-    // own state back; the slot then takes the ray that carries on (and joins the queue), or is free again
+    // own state back; the slot then takes the ray that carries on (and joins the queue), or the parked step again
+    // (on its way to the long list), or is free
     const uint32_t bits = slot_get<RHS>(Q.slot[s], L);
     lane_set_bits(L, bits);
-    const uint64_t rm = __ballot(resumed), fm = __ballot(mine && !resumed);
+    const bool resumed = outcome == PARK_RESUME, again = outcome == PARK_UNCERTIFIED;
+    const uint64_t rm = __ballot(resumed), am = __ballot(again), fm = __ballot(mine && !resumed && !again);
     if (resumed) {
+        SLOT_CHECK(Q, s, 4, 1, "drain_short resume");
         entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, 0u);
         Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)] = (uint8_t)s;
+    } else if (again) {
+        SLOT_CHECK(Q, s, 4, 3, "drain_short again");
+        slot_put<RHS>(Q.slot[s], P, kind);
+        Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(am)] = (uint8_t)s;
     } else if (mine) {
-        // (written at n_ev-relative positions of the FREE stack's top: the slots borrowed by the idle lanes of a partial
-        // drain sit below n_free and are not touched)
+        // (the slots borrowed by the idle lanes of a partial drain sit below n_free and are not touched)
+        SLOT_CHECK(Q, s, 4, 0, "drain_short free");
         Q.free_list[W.n_free + (int)lane_rank(fm)] = (uint8_t)s;
+    } else {
+        SLOT_CHECK(Q, s, 4, 0, "drain_short unborrow");
     }
     wave_lds_sync();
     // Nothing of the drain's own memory traffic (its register spills use scratch, i.e. vmcnt) may look pending to the
     // step loop: the compiler would otherwise guard the loop's first use of such a register with a vmcnt(0), which also
     // waits for the previous iteration's result stores -- in EVERY iteration (see fill_batch).
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-    W.n_ev -= take;
+    W.n_evA -= take;
+    W.n_evB += __builtin_popcountll(am);
     W.q_count += __builtin_popcountll(rm);
     W.n_free += __builtin_popcountll(fm);
+    INV_CHECK(W, "drain_short");
+#ifdef BHG_DIAG
+    W.diag_general += (unsigned long long)__builtin_popcountll(am);
+#endif
+}
+
+template <int RHS, int EVT>
+__device__ __forceinline__ void drain_long(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane, int take)
+{
+    const bool mine = (int)lane < take;
+    int outcome = PARK_ENDED;
+    uint32_t s = 0;
+    Lane P, R;
+    P.E = P.Lz = 0.0;
+    P.idx = P.n_att = P.n_acc = 0u;
+    if (mine) {
+        s = Q.ev_list[NSLOT - W.n_evB + (int)lane];
+        SLOT_CHECK(Q, s, 3, 4, "drain_long take");
+        const uint32_t kind = slot_get<RHS>(Q.slot[s], P);
+        Metric met;
+        met.r_s = A.r_s;
+        met.M = 0.5 * A.r_s;
+        met.a = A.spin;
+        met.E = P.E;
+        met.L = P.Lz;
+        outcome = dp54_resolve_long<RHS, EVT>(A, met, P, kind, R);
+    }
+    const bool resumed = outcome == PARK_RESUME;
+    const uint64_t rm = __ballot(resumed), fm = __ballot(mine && !resumed);
+    if (resumed) {
+        SLOT_CHECK(Q, s, 4, 1, "drain_long resume");
+        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, 0u);
+        Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)] = (uint8_t)s;
+    } else if (mine) {
+        SLOT_CHECK(Q, s, 4, 0, "drain_long free");
+        Q.free_list[W.n_free + (int)lane_rank(fm)] = (uint8_t)s;
+    }
+    wave_lds_sync();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (see drain_short)
+    W.n_evB -= take;
+    W.q_count += __builtin_popcountll(rm);
+    W.n_free += __builtin_popcountll(fm);
+    INV_CHECK(W, "drain_long");
+}
+
+// Which list does a parked step of these kinds go on?
+template <bool ADAPTIVE, int EVT>
+__device__ __forceinline__ bool short_kind(uint32_t kind)
+{
+    if (!ADAPTIVE) return true;
+    return ((EVT & EVT_EXIT) && kind == EV_EXIT) || ((EVT & EVT_DISK) && kind == EV_DISK);
 }
 
 // Lanes that hold a step to park (L.pend) put its record into free slots, as many as there are.  A lane that finds
 // none keeps its record in its registers and stays inactive until slots come free: every pop frees one, and with an
 // empty queue and no free slot all NSLOT >= 64 slots hold parked steps, which the next service() drains.
-template <int RHS>
+template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ void deposit_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     const uint64_t pm = __ballot(L.pend != 0u);
@@ -1638,15 +1747,24 @@ __device__ __forceinline__ void deposit_parked(WaveLds<RHS> &Q, Wave &W, Lane &L
     const int n = __builtin_popcountll(pm);
     const int can = n < W.n_free ? n : W.n_free;
     const uint32_t rk = lane_rank(pm);
-    if (L.pend != 0u && (int)rk < can) {
+    const bool dep = L.pend != 0u && (int)rk < can;
+    const bool shrt = short_kind<ADAPTIVE, EVT>(L.pend);
+    const uint64_t ma = __ballot(dep && shrt), mb = __ballot(dep && !shrt);
+    if (dep) {
         const uint32_t s = Q.free_list[W.n_free - 1 - (int)rk];
+        SLOT_CHECK(Q, s, 0, shrt ? 2 : 3, "deposit");
         slot_put<RHS>(Q.slot[s], L, L.pend);
-        Q.ev_list[W.n_ev + (int)rk] = (uint8_t)s;
+        if (shrt)
+            Q.ev_list[W.n_evA + (int)lane_rank(ma)] = (uint8_t)s;
+        else
+            Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(mb)] = (uint8_t)s;
         L.pend = 0u;
     }
     wave_lds_sync();
     W.n_free -= can;
-    W.n_ev += can;
+    W.n_evA += __builtin_popcountll(ma);
+    W.n_evB += __builtin_popcountll(mb);
+    INV_CHECK(W, "deposit");
 }
 
 // Serve the lanes that wait for a ray from the queue: at most one pop per lane, straight into the lane's registers;
@@ -1660,6 +1778,7 @@ __device__ __forceinline__ void pop_rays(WaveLds<RHS> &Q, Wave &W, Lane &L, uint
     const uint32_t rk = lane_rank(need);
     if (!L.active && L.pend == 0u && (int)rk < take) {
         const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
+        SLOT_CHECK(Q, s, 1, 0, "pop");
         (void)slot_get<RHS>(Q.slot[s], L);
         Q.free_list[W.n_free + (int)rk] = (uint8_t)s;
         L.rejected = 0u;
@@ -1669,73 +1788,104 @@ __device__ __forceinline__ void pop_rays(WaveLds<RHS> &Q, Wave &W, Lane &L, uint
     W.q_head = (W.q_head + take) & (QRING - 1);
     W.q_count -= take;
     W.n_free += take;
+    INV_CHECK(W, "pop");
 }
 
 // The pool is full (no free slot) while rays are queued, and lanes hold steps to park: such a lane SWAPS with the
 // head of the queue -- the queued ray comes out, the park record goes into its slot.  Without this a wave whose 64
 // lanes all wait to park next to a non-empty queue would wait for ever (nobody pops, so no slot comes free, and fewer
 // than 64 steps may be parked, so nothing drains).  Rare; kept apart so that the plain pop needs no register copies.
-template <int RHS>
+template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ void swap_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     const uint64_t pm = __ballot(L.pend != 0u);
     const int n = __builtin_popcountll(pm);
     const int take = n < W.q_count ? n : W.q_count;
     const uint32_t rk = lane_rank(pm);
-    if (L.pend != 0u && (int)rk < take) {
+    const bool dep = L.pend != 0u && (int)rk < take;
+    const bool shrt = short_kind<ADAPTIVE, EVT>(L.pend);
+    const uint64_t ma = __ballot(dep && shrt), mb = __ballot(dep && !shrt);
+    if (dep) {
         const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
         Lane T;
         T.E = T.Lz = 0.0;
+        SLOT_CHECK(Q, s, 1, shrt ? 2 : 3, "swap");
         (void)slot_get<RHS>(Q.slot[s], T);
         slot_put<RHS>(Q.slot[s], L, L.pend);
-        Q.ev_list[W.n_ev + (int)rk] = (uint8_t)s;
-        const uint32_t act = L.active;
+        if (shrt)
+            Q.ev_list[W.n_evA + (int)lane_rank(ma)] = (uint8_t)s;
+        else
+            Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(mb)] = (uint8_t)s;
         L = T;
         L.rejected = 0u;
         L.pend = 0u;
         L.active = 1u;
-        (void)act;
     }
     wave_lds_sync();
     W.q_head = (W.q_head + take) & (QRING - 1);
     W.q_count -= take;
-    W.n_ev += take;
+    W.n_evA += __builtin_popcountll(ma);
+    W.n_evB += __builtin_popcountll(mb);
+    INV_CHECK(W, "swap");
 }
 
 // The rare part of service(): drain parked steps and / or put rays into the empty queue.
-//   * drain 64 parked steps whenever 64 are parked -- at any time, the queue need not be empty;
+//   * a list is drained whenever it holds 64 steps -- at any time, the queue need not be empty;
 //   * with an empty queue: a new 64-ray batch needs 64 free slots, so if fewer are free, what is parked (more than
-//     NSLOT - 64 steps then) is drained first, however few; once the work counters are dry and every lane has come to
-//     rest, what is still parked is drained too and the rays it hands back carry on;
+//     NSLOT - 64 steps then) is drained first, the longer list, however few; once the work counters are dry and every
+//     lane has come to rest, what is still parked is drained too and the rays it hands back carry on.  A partial
+//     drain_short borrows 64 - take free slots for the idle lanes' states: with an empty queue NSLOT - n_evA - n_evB
+//     are free, enough as long as the long list holds no more than NSLOT - 64 -- otherwise the long list goes first;
 //   * (no prefetch of the next claim: a fetch kept in flight across iterations is a VGPR the loop carries, and the
 //     s_waitcnt vmcnt(0) in front of every copy of it also waits for the previous iteration's result stores --
 //     measured in round 2: config 2 +0.7 %, config 3 +4 %, config 4 +3.5 % without it.)
-// ONE loop with one site each for the drain and the queue fill (each is several hundred instructions), kept apart from
+// ONE loop with one site each for the drains and the queue fill (each is several hundred instructions), kept apart from
 // the pop: a loop around the pop makes the whole lane state a loop-carried value and costs ~20 register copies in
 // every iteration of the step loop (round 2's "register-copy storm", met again here).
 template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
     for (;;) {
-        int take = 0;
-        if (W.n_ev >= 64)
-            take = 64;
-        else if (W.q_count == 0 && W.n_ev > 0 &&
-                 (W.exhausted ? (__ballot(L.active != 0u) == 0ull) : (W.n_free < 64)))
-            take = W.n_ev;
-        if (take) {
+        int take_a = 0, take_b = 0;
+        if (W.n_evA >= 64)
+            take_a = 64;
+        else if (ADAPTIVE && W.n_evB >= 64)
+            take_b = 64;
+        else if (W.q_count == 0 && W.n_evA + W.n_evB > 0 &&
+                 (W.exhausted ? (__ballot(L.active != 0u) == 0ull) : (W.n_free < 64))) {
+            if (ADAPTIVE && (W.n_evB >= W.n_evA || W.n_evB > NSLOT - 64))
+                take_b = W.n_evB;
+            else
+                take_a = W.n_evA;
+        }
+        if (take_a) {
 #ifdef BHG_DIAG
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-            W.diag_drained += (unsigned long long)take;
+            W.diag_drained += (unsigned long long)take_a;
 #endif
-            drain_events<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane, take);
+            drain_short<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane, take_a);
 #ifdef BHG_DIAG
             W.diag_drain_cyc += __builtin_amdgcn_s_memtime() - c0;
 #endif
-            deposit_parked<RHS>(Q, W, L, lane);     // (lanes that found no slot before have one now)
+            deposit_parked<RHS, ADAPTIVE, EVT>(Q, W, L, lane);     // (lanes that found no slot before have one now)
             continue;
         }
-        if (W.n_free == 0 && W.q_count > 0 && __ballot(L.pend != 0u) != 0ull) swap_parked<RHS>(Q, W, L, lane);
+        if (ADAPTIVE && take_b) {
+#ifdef BHG_DIAG
+            const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+            W.diag_drained_long += (unsigned long long)take_b;
+#endif
+            drain_long<RHS, EVT>(A, Q, W, lane, take_b);
+#ifdef BHG_DIAG
+            W.diag_drain_long_cyc += __builtin_amdgcn_s_memtime() - c0;
+#endif
+            deposit_parked<RHS, ADAPTIVE, EVT>(Q, W, L, lane);
+            continue;
+        }
+        if (W.n_free == 0 && W.q_count > 0 && __ballot(L.pend != 0u) != 0ull) {
+            swap_parked<RHS, ADAPTIVE, EVT>(Q, W, L, lane);
+            continue;   // (the swap may have emptied the queue with no slot free: the drains above come first)
+        }
         if (W.q_count > 0 || W.exhausted || __ballot(!L.active) == 0ull) return;
         // the queue is empty, lanes wait, 64 slots are free: claim a batch
         const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
@@ -1771,11 +1921,12 @@ __device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, W
 template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ bool service(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
 {
-    deposit_parked<RHS>(Q, W, L, lane);
-    if (__builtin_expect(W.n_ev >= 64 || (W.q_count == 0 && !(W.exhausted && W.n_ev == 0)) || W.n_free == 0, 0))
+    deposit_parked<RHS, ADAPTIVE, EVT>(Q, W, L, lane);
+    const int n_ev = W.n_evA + W.n_evB;
+    if (__builtin_expect(W.n_evA >= 64 || W.n_evB >= 64 || (W.q_count == 0 && !(W.exhausted && n_ev == 0)) || W.n_free == 0, 0))
         replenish<RHS, ADAPTIVE, EVT>(A, Q, W, L, lane);
     if (W.q_count > 0) pop_rays<RHS>(Q, W, L, lane);
-    return W.exhausted && W.q_count == 0 && W.n_ev == 0 && __ballot(L.active != 0u || L.pend != 0u) == 0ull;
+    return W.exhausted && W.q_count == 0 && W.n_evA + W.n_evB == 0 && __ballot(L.active != 0u || L.pend != 0u) == 0ull;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1827,10 +1978,13 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     L.active = L.rejected = L.pend = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
-    W.n_ev = 0;
+    W.n_evA = W.n_evB = 0;
     W.n_free = NSLOT;
     W.exhausted = false;
     for (int i = (int)lane; i < NSLOT; i += 64) Q.free_list[i] = (uint8_t)i;
+#ifdef BHG_CHECK
+    for (int i = (int)lane; i < NSLOT; i += 64) Q.tag[i] = 0;
+#endif
     wave_lds_sync();
 #ifdef BHG_DIAG
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1918,7 +2072,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                 crossed_disk_plane<RHS>(L.x, xn);
                     const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                    if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) &&
+                    // (whatever else the step holds: a plane crossing that cannot lie in the annulus is no event -- and
+                    // a parked step with ONE candidate event takes the drain's short path)
+                    if ((EVT & EVT_DISK) && ev_d &&
                         !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
                                                   : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                         ev_d = false;
@@ -1958,10 +2114,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         d[0] = diag_t0;
         d[1] = __builtin_amdgcn_s_memrealtime();
         d[2] = diag_iters;
-        d[3] = diag_lanes;
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;
         d[5] = W.diag_drain_cyc;
-        d[6] = W.diag_drained;
+        d[6] = W.diag_drained | (W.diag_drained_long << 40);   // steps drained from the short list | from the long list
+        d[3] = diag_lanes | (W.diag_drain_long_cyc << 40);       // (lane-steps < 2^40) | cycles in drain_long
         d[7] = W.diag_fill_cyc | (W.diag_refill_cyc << 32);  // fill cycles < 2^32; refill() total in the high half
     }
 #endif
@@ -1991,10 +2147,13 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     L.active = L.rejected = L.pend = 0u;
     Wave W;
     W.q_head = W.q_count = 0;
-    W.n_ev = 0;
+    W.n_evA = W.n_evB = 0;
     W.n_free = NSLOT;
     W.exhausted = false;
     for (int i = (int)lane; i < NSLOT; i += 64) Q.free_list[i] = (uint8_t)i;
+#ifdef BHG_CHECK
+    for (int i = (int)lane; i < NSLOT; i += 64) Q.tag[i] = 0;
+#endif
     wave_lds_sync();
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
@@ -2026,7 +2185,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
                 const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                 bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
                 const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                if ((EVT & EVT_DISK) && ev_d && !(ev_h || ev_e || ev_o) &&
+                if ((EVT & EVT_DISK) && ev_d &&
                     !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
                                               : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                     ev_d = false;

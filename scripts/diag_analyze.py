@@ -1,6 +1,8 @@
 import numpy as np, sys
 d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
 d = d[d[:, 1] > 0]
+long_cyc = (d[:, 3] >> np.uint64(40)).astype(np.float64)
+d = d.copy(); d[:, 3] &= np.uint64((1 << 40) - 1)
 t0, t1, it, ln = d[:, 0].astype(np.int64), d[:, 1].astype(np.int64), d[:, 2], d[:, 3]
 T0 = t0.min()
 life = (t1 - t0) / 100.0  # us (100 MHz)
@@ -11,6 +13,8 @@ print("lifetime us: mean %.1f" % life.mean(), "iters/wave mean %.1f min %d max %
 print("lane utilisation %.4f" % (ln.sum() / (64.0 * it.sum())), "total lane-steps", ln.sum())
 print("shader clock GHz: mean %.3f" % np.mean(d[:, 4].astype(np.float64) / ((t1 - t0) * 10.0) / 1e3 * 1e3 / 1e3))
 print("us per iteration: %.3f" % (life.sum() / it.sum()))
+general = (d[:, 6] >> np.uint64(40)).astype(np.float64)
+d = d.copy(); d[:, 6] &= np.uint64((1 << 40) - 1)
 refill = (d[:, 7] >> np.uint64(32)).astype(np.float64)
 d = d.copy(); d[:, 7] &= np.uint64(0xFFFFFFFF)
 cyc = d[:, 4].astype(np.float64)
@@ -18,6 +22,9 @@ print("share of wave cycles: event drain %.4f  batch fill (setup) %.4f" % (d[:, 
 if d[:, 6].sum():
     print("events drained %d, cycles per drained event-wave (64 events) %.0f, per iteration %.0f" % (
         d[:, 6].sum(), d[:, 5].sum() / (d[:, 6].sum() / 64.0), (cyc.sum() - d[:, 5].sum() - d[:, 7].sum()) / it.sum()))
+if general.sum():
+    print("long list (Brent): %d steps = %.4f of all parked, %.4f of wave cycles, %.0f cycles per 64 steps" % (
+        general.sum(), general.sum() / max(d[:, 6].sum() + general.sum(), 1), long_cyc.sum() / cyc.sum(), long_cyc.sum() / (general.sum() / 64.0)))
 if refill.sum():
     other = refill.sum() - d[:, 5].sum() - d[:, 7].sum()
     print("refill() calls without drain / batch fill (LDS pops, work fetch): %.4f of wave cycles = %.0f cycles per iteration" % (other / cyc.sum(), other / it.sum()))
