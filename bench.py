@@ -71,6 +71,10 @@ def parse():
                     help="frame workload: have the trace write whole end states (48 B/ray) instead of the exit directions a sky frame reads")
     ap.add_argument("--lpt", type=int, default=1, help="1: visit tiles in order of decreasing expected cost")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time (0 = skip)")
+    ap.add_argument("--emulate-shards", type=str, default="2,4,8",
+                    help="N = 1, frame workload: also time rank 0's shard of a world-N dealing of the SAME fixed frame (no "
+                         "collective) for each N listed and report the predicted strong-scaling efficiency T1 / (N T_N) in "
+                         "a strong_predicted block; '' = off")
     a = ap.parse_args()
     dw, ds = {"frame": (1024, 5), "disk": (1024, 1), "orbit": (2048, 16)}[a.workload]
     a.width = a.width or dw
@@ -185,9 +189,24 @@ def main():
         ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
                                       stream=torch.cuda.current_stream().cuda_stream)
 
-    def measure(nx, ny, ramp):
+    def twin_of(fr_, ctx2):
+        """A second DeviceFrame over the SAME rays (shared d_k0) with result buffers of its own, on another library
+        context (its own work counters): consecutive frames of an animation are independent, so frame i + 1 can be
+        traced on a second stream while frame i's last waves drain."""
+        n_ = fr_.n
+        buf = (fr_.d_k0, None if fr_.directions_only else torch.empty((n_, 6), dtype=torch.float64, device="cuda"),
+               torch.empty(n_, dtype=torch.uint8, device="cuda"), torch.empty(n_, dtype=torch.int32, device="cuda"),
+               torch.empty(n_, dtype=torch.int32, device="cuda"))
+        f2 = DeviceFrame(ctx2, fr_.W, fr_.H, fr_.S, fov_x=fr_.fov_x, fov_y=fr_.fov_y, origin=fr_.origin,
+                         pixels=None if fr_.d_pixels is None else fr_.d_pixels.cpu().numpy(), jitter=np.zeros(2), buffers=buf,
+                         directions_only=fr_.directions_only)
+        f2.d_sky, f2.sky_wh = fr_.d_sky, fr_.sky_wh
+        return f2
+
+    def measure(nx, ny, ramp, overlap=False):
         """One timed region over a frame of (width * nx) x (height * ny) pixels sharded over the ranks.
-        Returns the figures of this rank (dt already the maximum over ranks)."""
+        Returns the figures of this rank (dt already the maximum over ranks).  overlap (frame workload): two frames in
+        flight -- consecutive frames alternate between two streams / library contexts."""
         W, H, S = a.width * nx, a.height * ny, a.samples
         # ---- synthetic input, resident in HBM before the timed region ----------------------------
         # this rank's tiles of the frame (all samples of a pixel together); jitter stream = the
@@ -241,8 +260,26 @@ def main():
                                        tile_cost=tcost, collective=collective)   # (the gatherer must know the shards' pixel order)
         assert np.array_equal(gatherer.pixels, pixels)
         kernel_ms = []
+        lanes = None
+        if overlap and a.workload == "frame":
+            ctx2 = _ffi.Context(local_rank)
+            lanes = [(fr, torch.cuda.Stream()), (twin_of(fr, ctx2), torch.cuda.Stream())]
 
         def step(i, timed):
+            if lanes is not None:
+                f, st = lanes[i & 1]
+                with torch.cuda.stream(st):
+                    if timed:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record(st)
+                        f.trace(params)
+                        e1.record(st)
+                        kernel_ms.append((e0, e1))
+                    else:
+                        f.trace(params)
+                    gatherer.submit_with(i, f.shade_f32)
+                return
             if a.workload == "orbit":
                 fr.set_objects(*orbit_scene(i))
             tracers = [batch] if batch is not None else frames
@@ -326,8 +363,45 @@ def main():
         tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(tot)
+        if lanes is not None:
+            ctx2.close()
         return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                     steps_all=float(tot[1].item()), launch=ctx.last_launch(), fr=fr)
+
+    def time_frame(fr_, steps, warmup, overlap=False):
+        """K timed steps of trace + shade (float RGBA in frame order) of ONE DeviceFrame on this GPU, no collective:
+        (ms per step by the wall clock around a synchronised region, trace-call ms by HIP events, attempted ray-steps).
+        overlap: two frames in flight, alternating between two streams / library contexts (the call times overlap then)."""
+        ctx2 = _ffi.Context(local_rank) if overlap else None
+        lanes_ = [(fr_, ts)] if not overlap else [(fr_, torch.cuda.Stream()), (twin_of(fr_, ctx2), torch.cuda.Stream())]
+        imgs = [torch.zeros((fr_.W * fr_.H, 4), dtype=torch.float32, device="cuda") for _ in lanes_]
+        evs = []
+
+        def run(k, timed):
+            for i in range(k):
+                f, st = lanes_[i % len(lanes_)]
+                with torch.cuda.stream(st):
+                    if timed:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record(st)
+                        f.trace(params)
+                        e1.record(st)
+                        evs.append((e0, e1))
+                    else:
+                        f.trace(params)
+                    f.shade_f32(imgs[i % len(lanes_)], fr_.d_pixels)
+        torch.cuda.synchronize()
+        run(warmup, False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out_ = dt / steps * 1e3, float(np.mean([x.elapsed_time(y) for x, y in evs])), int(fr_.d_steps.to(torch.int64).sum().item())
+        if ctx2 is not None:
+            ctx2.close()
+        return out_
 
     nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
     m = measure(nx, ny, a.ramp_seconds)
@@ -341,6 +415,13 @@ def main():
                               f"barrier + max-over-ranks timing",
                   "trace_kernel_ms_rank0": s_["k_ms"]}
         del s_
+        if a.workload == "frame":
+            # the same with two frames in flight per rank (consecutive frames on alternating streams): a shard's
+            # persistent launch ends with a tail of a few tens of microseconds, a quarter of a 1/8 shard's kernel
+            s2 = measure(1, 1, 0.0, overlap=True)
+            strong["two_frames_in_flight"] = {"value": s2["rays_all"] / (s2["dt"] / a.steps) / 1e6, "unit": "Mrays/s",
+                                              "ms_per_step": s2["dt"] / a.steps * 1e3}
+            del s2
     W, H, S, n, ray_steps, dt, call_ms, k_ms = m["W"], m["H"], m["S"], m["n"], m["ray_steps"], m["dt"], m["call_ms"], m["k_ms"]
     rays_all, steps_all, fr = m["rays_all"], m["steps_all"], m["fr"]
 
@@ -412,6 +493,51 @@ def main():
         }
         if strong is not None:
             out["strong"] = strong
+        if world == 1 and a.workload == "frame" and getattr(fr, "_dir_traced", False):
+            # what north_star names -- "exit position/direction written back": the same frame with whole end states
+            # (81 B/ray) instead of the exit directions a sky frame reads (57 B/ray); same K / W, same clock
+            frf = DeviceFrame(ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=cam,
+                              pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=False)
+            frf.d_k0 = fr.d_k0
+            frf.set_sky(sky)
+            ms_f, call_f, steps_f = time_frame(frf, a.steps, a.warmup)
+            out["full_records"] = {"value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
+                                   "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                   "algorithmic_bytes_per_ray": BYTES_PER_RAY,
+                                   "what": "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them"}
+            del frf
+        if world == 1 and a.workload == "frame" and a.emulate_shards.strip():
+            # BASELINE.json's metric is ONE 1024x1024x5 frame over 1, 2, 4, 8 GPUs.  Predicted on the one GPU at hand: rank
+            # 0's pixel list of a world-N dealing of that fixed frame (same tiles, same cost order), traced and shaded here
+            # without the collective; efficiency = T_1 / (N T_N).  What it leaves out: the gather (16 B/pixel, ~0.1 ms per
+            # peer, overlapped) and the root's assembly kernel.
+            jit = python_random_stream(42.0, 2 * S * W * H)
+            t1_ms, t1_call, _ = time_frame(fr, a.steps, a.warmup)
+            t1o_ms, _, _ = time_frame(fr, a.steps, a.warmup, overlap=True)
+            pred = {"T1_ms_per_step": t1_ms, "T1_trace_call_ms": t1_call, "T1_ms_per_step_two_in_flight": t1o_ms, "shards": {}}
+
+            def tile_cost1(cx, cy):
+                ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
+                return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
+            for N in [int(v) for v in a.emulate_shards.split(",") if v.strip()]:
+                pix = bdist.rank_pixels(W, H, a.tile, 0, N, tile_cost=tile_cost1 if a.lpt else None)
+                frs = DeviceFrame(ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=cam, pixels=pix,
+                                  jitter=jit, directions_only=fr.directions_only)
+                frs.set_sky(sky)
+                frs.generate_rays()
+                ms_n, call_n, steps_n = time_frame(frs, a.steps, a.warmup)
+                mso_n, _, _ = time_frame(frs, a.steps, a.warmup, overlap=True)
+                pred["shards"][str(N)] = {"rays": frs.n, "ms_per_step": ms_n, "trace_call_ms": call_n,
+                                          "attempted_steps_per_ray": steps_n / frs.n,
+                                          "efficiency": t1_ms / (N * ms_n), "efficiency_trace_call": t1_call / (N * call_n),
+                                          "ms_per_step_two_in_flight": mso_n, "efficiency_two_in_flight": t1o_ms / (N * mso_n)}
+                del frs
+            del jit
+            pred["what"] = ("rank 0's shard of a world-N dealing of the fixed %dx%d x%d frame, trace + shade on this one GPU, no "
+                            "collective; efficiency = T1 / (N T_N); two_in_flight: consecutive frames alternate between two "
+                            "streams / library contexts, so a frame's first waves start while the previous frame's last ones drain "
+                            "(both T1 and T_N measured that way)" % (W, H, S))
+            out["strong_predicted"] = pred
         if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
             out["pipelined"] = pipelined_figure(ctx, fr, params, a, local_rank)
             out["host_buffer_call"] = host_buffer_figures(ctx, fr, cam, params, n)

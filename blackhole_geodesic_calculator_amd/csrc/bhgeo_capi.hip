@@ -462,24 +462,26 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     hipStream_t s = (hipStream_t)stream;
 
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
-    //   ws      [n][8] doubles  per-ray records (Kerr prepare records; parked steps and resume records of the trace kernel)
+    //   ws      [n][8] doubles  Kerr only: the prepare pass's records {a0, h0, r0, 0, E, L} (the Schwarzschild trace kernel
+    //                           works its start records out itself, and parked steps live in the waves' LDS pools)
     //   flags   [n] bytes       when the caller does not want flags
     //   n_steps / n_accepted [n] u32 when the caller does not want them (the kernels never test these pointers)
     const bool has_exit = p->r_exit > 0.0;
-    const size_t sz_ws = n * 8 * sizeof(double);
+    const bool kerr = p->rhs_form == BHG_RHS_KERR_BL;
+    const size_t sz_ws = kerr ? n * 8 * sizeof(double) : 0;
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
     const size_t sz_steps = !d_n_steps ? sz_u32 : 0;
     const size_t sz_acc = !d_n_accepted ? sz_u32 : 0;
     rc = ensure(&c->d_ws, &c->d_ws_bytes, sz_ws + sz_flags + sz_steps + sz_acc + 64);
     if (rc != BHG_OK) return rc;
-    if (!d_end) {
-        // direction-only call: the end records are workspace (parked / resume records of the rays that need them; Kerr:
-        // the Boyer-Lindquist states the finalize pass converts), final directions go to d_end_dir
+    if (!d_end && kerr) {
+        // direction-only Kerr call: the end records are workspace (the Boyer-Lindquist states the finalize pass converts),
+        // final directions are split off into d_end_dir afterwards
         rc = ensure(&c->d_endws, &c->d_endws_bytes, n * 6 * sizeof(double) + 64);
         if (rc != BHG_OK) return rc;
         d_end = (double *)c->d_endws;
-    } else {
+    } else if (d_end) {
         d_end_dir = nullptr;
     }
     char *wsb = (char *)c->d_ws;
@@ -493,8 +495,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.x0 = d_x0;
     a.end = d_end;
     // (Kerr end states are converted from Boyer-Lindquist by a pass over whole records: directions are split off after it)
-    a.end_dir = p->rhs_form == BHG_RHS_KERR_BL ? nullptr : d_end_dir;
-    a.ws = (double *)c->d_ws;
+    a.end_dir = kerr ? nullptr : d_end_dir;
+    a.ws = kerr ? (double *)c->d_ws : nullptr;
     a.flags = d_flags ? d_flags : w_flags;
     a.n_steps = d_n_steps ? d_n_steps : w_steps;
     a.n_accepted = d_n_accepted ? d_n_accepted : w_acc;

@@ -630,15 +630,16 @@ __device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const 
     const double D = x0[2] - x1[2];
     const double Px = __builtin_fma(x0[2], x1[0], -(x1[2] * x0[0])), Py = __builtin_fma(x0[2], x1[1], -(x1[2] * x0[1]));
     const double P2 = __builtin_fma(Px, Px, Py * Py), D2 = D * D;
-    double n0 = 0.0, n1 = 0.0;
+    // (the two norms as 1-norms -- |e|_1 >= |e|_2, so still a bound: |.| is a free operand modifier where a square
+    // root is ten instructions; this test runs in practically every iteration of a disk frame's step loop)
+    double n01 = 0.0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const double dx = x1[c] - x0[c];
         const double e0 = __builtin_fma(h, v0[c], -dx), e1 = __builtin_fma(h, v1[c], -dx);
-        n0 = __builtin_fma(e0, e0, n0);
-        n1 = __builtin_fma(e1, e1, n1);
+        n01 += fabs(e0) + fabs(e1);
     }
-    const double delta = (sqrt_nr(n0) + sqrt_nr(n1)) * (1.0 + 1e-9);
+    const double delta = n01 * (1.0 + 1e-9);
     const double lo = A.disk_r_in - delta, hi = A.disk_r_out + delta;
     // R = |P| / |D| against [lo, hi], compared as squares times D^2; a step lying in the plane (D = 0, P = 0) and NaN
     // anywhere fall through to "may hit"
@@ -1361,9 +1362,14 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
             dg = 2.0 * __builtin_fma(xs[2], ds[2], __builtin_fma(xs[1], ds[1], xs[0] * ds[0]));
         }
     };
-    double g0, g1, dg, xs[3];
-    eval(0.0, g0, dg, xs);
-    eval(1.0, g1, dg, xs);
+    // the event function at the step's ends, from the end states themselves (the polynomial returns them to rounding)
+    auto gfun = [&](const double xs_[3]) {
+        if (BL) return (comp == 1 ? xs_[1] : xs_[0]) - target;
+        if (is_disk) return xs_[2];
+        return __builtin_fma(xs_[2], xs_[2], __builtin_fma(xs_[1], xs_[1], xs_[0] * xs_[0])) - target;
+    };
+    const double g0 = gfun(P.x), g1 = gfun(xn);
+    double dg, xs[3];
     // the step ends bracket the root (that is what parked the step); G is monotone between them
     double lo = 0.0, hi = 1.0;
     const bool neg0 = g0 < 0.0;

@@ -60,7 +60,7 @@ class DeviceFrame:
         if buffers is not None:
             # views into a caller-owned block shared by several frames (FrameBatch): one trace call for all
             self.d_k0, self.d_end, self.d_flags, self.d_steps, self.d_acc = buffers
-            assert self.d_k0.shape == (n, 3) and self.d_end.shape == (n, 6) and self.d_flags.numel() == n
+            assert self.d_k0.shape == (n, 3) and (self.d_end is None or self.d_end.shape == (n, 6)) and self.d_flags.numel() == n
         else:
             self.d_k0 = torch.empty((n, 3), dtype=torch.float64, device=self.dev)
             # whole end records: allocated when a full-record trace is first issued (a direction-only frame never needs them)
