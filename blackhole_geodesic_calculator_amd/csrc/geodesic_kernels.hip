@@ -2019,18 +2019,34 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         if (L.active) {
             // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
             uint32_t term = 0;
-            // 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound]: skip the exact value (rk.py:119)
-            // unless the step is already that small
-            // (written as selects: as nested ifs this prologue is eight divergent branches per iteration)
-            // (the exact 10 ulp(t) only when some lane's step is already that small: practically never)
-            const bool tiny = !(L.h_abs > A.min_step_cap);
-            double min_step = 0.0;
-            if (__ballot(tiny)) min_step = tiny ? 10.0 * ulp_of(L.t) : 0.0;
-            const double h_clamped = (L.h_abs > max_step) ? max_step : ((L.h_abs < min_step) ? min_step : L.h_abs);
-            L.h_abs = L.rejected ? L.h_abs : h_clamped;
-            term = (L.h_abs < min_step) ? (uint32_t)BHG_FLAG_STEP_TOO_SMALL_
-                                        : ((L.n_att >= A.max_steps) ? (uint32_t)BHG_FLAG_MAX_STEPS_ : 0u);
-            term = (term == 0u && L.t == t_bound) ? (uint32_t)BHG_FLAG_REACHED_END_ : term;  // base.py:189-194
+            // The step-size floor 10 ulp(t) (rk.py:119), the step budget and "already at t_bound" (base.py:189-194)
+            // practically never bite: 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound], so ONE wave-wide test
+            // covers them, and the common case is a min, a select and nothing else (the full prologue below is forty
+            // instructions in every iteration of every ray).
+            const bool odd = !(L.h_abs > A.min_step_cap) || L.n_att >= A.max_steps || L.t == t_bound;
+            if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
+                // (written as selects: as nested ifs this is eight divergent branches)
+                const bool tiny = !(L.h_abs > A.min_step_cap);
+                double min_step = 0.0;
+                if (__ballot(tiny)) min_step = tiny ? 10.0 * ulp_of(L.t) : 0.0;
+                const double h_clamped = (L.h_abs > max_step) ? max_step : ((L.h_abs < min_step) ? min_step : L.h_abs);
+                L.h_abs = L.rejected ? L.h_abs : h_clamped;
+                term = (L.h_abs < min_step) ? (uint32_t)BHG_FLAG_STEP_TOO_SMALL_
+                                            : ((L.n_att >= A.max_steps) ? (uint32_t)BHG_FLAG_MAX_STEPS_ : 0u);
+                term = (term == 0u && L.t == t_bound) ? (uint32_t)BHG_FLAG_REACHED_END_ : term;  // base.py:189-194
+            } else {
+                // (min_step = 0 here: the clamp of rk.py:121-124 is the upper one alone; not after a rejection)
+                // (the bound as a SCALAR operand of the min, pinned there by the empty asm: left to itself the compiler
+                // shares one VGPR copy of max_step between this path and the selects above, hoists it out of the loop,
+                // spills it -- and reloads it here behind a vmcnt(0) that waits for the previous iteration's result stores)
+                if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
+                    L.h_abs = L.rejected ? L.h_abs : fmin(L.h_abs, max_step);
+                } else {
+                    double ms = A.max_step;
+                    asm volatile("" : "+s"(ms));
+                    L.h_abs = L.rejected ? L.h_abs : fmin(L.h_abs, ms);
+                }
+            }
             if (term) {
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
                 L.active = 0u;
