@@ -20,7 +20,20 @@ Known deviations from the reference, all deliberate:
     image is the reference's: its spacetime_ray_cast always reports hit = False (:304-305), so scene meshes
     never affect a render.  Set to 1, the MESH objects of the scene (except the black-hole marker) are traced as
     lamp-lit bounding spheres inside the curved region -- the collision test the reference leaves as a stub;
-    at most 8 (the solver's limit), the nearest to the hole, with a warning when more are dropped.
+    at most 8 (the solver's limit), the nearest to the hole, with a warning when more are dropped.  ONE lighting
+    contract for an object hit, whichever path shades it: `spacetime_hit`'s Lambert lamps (:341-363) -- colour +=
+    intensity^2 n.l / d^2 per lamp, light paths straight, n.l clamped at 0 -- WITH its shadow rays (:352-356), cast
+    against the other traced spheres (the only geometry the curved region knows); the host routine below and the
+    device kernel (`object_colour`, csrc/frame_kernels.hip; restated in oracle/shade_reference.py) agree to rounding;
+  * a second extra property, `device_shading` (default 0 = off).  Off: every escaping ray is shaded by Blender's own
+    `Texture.evaluate`, one Python call per ray as in the reference (:366-378) -- at 1024 x 1024 that is a million
+    calls per sample next to a quarter-millisecond trace.  Set to 1: the sky image's pixels are read ONCE
+    (`bpy.data.images[...].pixels`), uploaded, and ray generation, trace, sky lookup, object lighting and the
+    multisample mean all run on the device (device_frame.DeviceFrame: bhg_raygen_device -> bhg_trace[_dir]_device ->
+    bhg_shade[_dir/_scene]_device); one array comes back per frame.  The lookup is then the library's bilinear
+    filter of the image, not Blender's texture filter (which cannot be reproduced outside Blender): the images agree
+    to the filter difference.  Needs the whole frame (no mark_* window: the window's RNG alignment is a host matter);
+    with a window set the host path is used.
 """
 import warnings
 import os
@@ -75,6 +88,7 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         self.mark_y_max = _unset(scene.mark_y_max, self.res_y)
         self.mark_x_min = _unset(scene.mark_x_min, 0)
         self.mark_x_max = _unset(scene.mark_x_max, self.res_x)
+        self.device_shading = float(getattr(scene, "device_shading", 0) or 0) != 0.0
 
         # one solver object per frame, as the reference builds it (:134)
         self.GeoInt = GeodesicIntegratorSchwarzschild(mass=self.mass, time_like=False, verbose=False)
@@ -105,11 +119,21 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         for i, frac in enumerate(self.ray_trace(depsgraph, self.res_x, self.res_y, 1, buf, self.samples)):
             self.update_progress(frac)
             if (i + 1) % rows_per_refresh == 0:
-                layer.rect = buf.reshape(-1, 4).tolist()
+                self._set_rect(layer, buf)
                 self.update_result(result)
-        layer.rect = buf.reshape(-1, 4).tolist()
+        self._set_rect(layer, buf)
         self.update_result(result)
         self.end_result(result)
+
+    @staticmethod
+    def _set_rect(layer, buf):
+        """layer.rect <- buf [H, W, 4]: ONE flat float32 array through foreach_set where the pass offers it (Blender's
+        bpy_prop_array does), else the reference's list of rows (:163; a million-pixel .tolist() is a second of Python)."""
+        rect = getattr(layer, "rect", None)
+        if rect is not None and hasattr(rect, "foreach_set"):
+            rect.foreach_set(np.ascontiguousarray(buf, dtype=np.float32).reshape(-1))
+        else:
+            layer.rect = buf.reshape(-1, 4).tolist()
 
     # ---- frame driver (:172-267): same generator protocol, batched hot path -------------------
     def ray_trace(self, depsgraph, width, height, depths, buf, samples, approx=False):
@@ -123,6 +147,10 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         # objects in the curved region are opt-in (scene.curved_space_objects): off reproduces the reference image
         want_objects = float(getattr(depsgraph.scene, "curved_space_objects", 0) or 0) != 0.0
         spheres = self.scene_spheres(depsgraph) if want_objects else np.zeros((0, 4))
+        self._lit_spheres = spheres
+        if getattr(self, "device_shading", False) and mark is None:
+            yield from self.ray_trace_device(width, height, samples, buf, origin, rotation, spheres)
+            return
         tracer = FrameTracer(
             self.GeoInt, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
             sampling_seed=self.sampling_seed, origin=origin, rotation_euler=rotation, bh_loc=self.bh_loc,
@@ -149,17 +177,83 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
             warnings.warn(f"{len(out)} mesh objects in the scene: only the 8 nearest to the hole are traced", RuntimeWarning)
         return np.array(out[:8], dtype=np.float64).reshape(-1, 4)
 
-    def spacetime_hit_many(self, loc, normal, index, intensity=10):
-        """Vectorised spacetime_hit (:317-363): white Lambert lamps with 1/d^2 falloff; no shadow rays (there
-        is no flat-space scene to cast them into here) and n.l clamped at 0."""
+    LAMP_INTENSITY = 10.0   # spacetime_hit's default `intensity` (:317)
+
+    def spacetime_hit_many(self, loc, normal, index, intensity=None):
+        """Vectorised spacetime_hit (:317-363): white Lambert lamps, colour += intensity^2 n.l / d^2, n.l clamped at 0,
+        light paths straight, shadow rays (:352-356) cast against the OTHER traced spheres (world coordinates) -- the
+        same model, term for term, as the device kernel's object_colour.  loc, normal [n, 3]; index [n] = sphere hit."""
+        intensity = self.LAMP_INTENSITY if intensity is None else intensity
+        loc = np.asarray(loc, dtype=np.float64).reshape(-1, 3)
+        normal = np.asarray(normal, dtype=np.float64).reshape(-1, 3)
+        index = np.asarray(index).reshape(-1)
+        spheres = np.asarray(getattr(self, "_lit_spheres", np.zeros((0, 4))), dtype=np.float64).reshape(-1, 4)
         color = np.zeros(loc.shape)
         for lamp in getattr(self, "lamps", []):
             light_vec = np.array(list(lamp.location), dtype=np.float64) - loc
-            light_dist = (light_vec * light_vec).sum(-1)
-            light_dir = light_vec / np.sqrt(light_dist)[:, None]
-            ndl = np.maximum((normal * light_dir).sum(-1), 0.0)
-            color += (intensity * intensity * ndl / light_dist)[:, None]
+            d2 = (light_vec * light_vec).sum(-1)
+            dist = np.sqrt(d2)
+            light_dir = light_vec / dist[:, None]
+            ndl = (normal * light_dir).sum(-1)
+            lit = ndl > 0.0
+            for q in range(len(spheres)):
+                oc = loc - spheres[q, 0:3]
+                b = (oc * light_dir).sum(-1)
+                disc = b * b - ((oc * oc).sum(-1) - spheres[q, 3] ** 2)
+                sd = np.sqrt(np.maximum(disc, 0.0))
+                t0, t1 = -b - sd, -b + sd
+                blocked = (disc > 0.0) & (((t0 > 1e-5) & (t0 < dist)) | ((t0 <= 1e-5) & (t1 > 1e-5))) & (index != q)
+                lit &= ~blocked
+            color += np.where(lit, intensity * intensity * ndl / d2, 0.0)[:, None]
         return color
+
+    # ---- the whole frame on the device (opt-in, scene.device_shading) ------------------------------------------------
+    def _sky_pixels(self):
+        """The sky image as float32 [h, w, 4], rows bottom-up as Blender stores them -- which is the library's
+        convention too (texture coordinate v = -1 is row 0).  None when there is no readable image."""
+        name = os.path.basename(getattr(self, "sky_image_path", "") or "")
+        if not name or name not in bpy.data.images:
+            return None
+        img = bpy.data.images[name]
+        size = getattr(img, "size", None)
+        if size is None or not hasattr(img, "pixels"):
+            return None
+        w, h = int(size[0]), int(size[1])
+        if w <= 0 or h <= 0:
+            return None
+        px = np.empty(w * h * 4, dtype=np.float32)
+        if hasattr(img.pixels, "foreach_get"):
+            img.pixels.foreach_get(px)
+        else:
+            px[:] = np.asarray(img.pixels[:], dtype=np.float32)
+        return px.reshape(h, w, 4)
+
+    def ray_trace_device(self, width, height, samples, buf, origin, rotation, spheres):
+        """The generator protocol of ray_trace with everything between the jitter stream and the averaged pixels on
+        the GPU: ONE ray-generation launch, ONE trace launch for all samples, ONE shade + mean launch, ONE array back."""
+        from .device_frame import DeviceFrame
+        sky = self._sky_pixels()
+        if sky is None:
+            sky = np.zeros((2, 2, 4), dtype=np.float32)     # no sky image: black, as background_hit returns (:369-370)
+        has_obj = len(spheres) > 0
+        fr = DeviceFrame(self.GeoInt.context, width, height, samples, fov_x=self.field_of_view_x,
+                         fov_y=self.field_of_view_y, sampling_seed=self.sampling_seed, origin=origin,
+                         rotation_euler=rotation, bh_loc=self.bh_loc, directions_only=not has_obj)
+        fr.set_sky(sky)
+        if has_obj:
+            sp = np.array(spheres, dtype=np.float64).reshape(-1, 4)
+            sp[:, 0:3] -= self.bh_loc                        # the solver and the shade kernel work BH-centred
+            lamps = [[*(np.array(list(l.location), dtype=np.float64) - self.bh_loc), self.LAMP_INTENSITY]
+                     for l in getattr(self, "lamps", [])][:4]
+            fr.set_objects(sp, np.ones((len(sp), 3)), lamps)
+        fr.generate_rays()
+        fr.trace(self.GeoInt.params(self.max_integration_step, self.int_depth_curve_end))
+        rgba = fr.shade().cpu().numpy()
+        buf[:, :, :] = rgba.reshape(height, width, 4)
+        self.last_device_frame = fr
+        n = samples * height
+        for i in range(n):                                   # progress: one yield per sample and row, as ray_trace
+            yield (i + 1) / n
 
     # ---- shading (:366-378), Blender's own texture filter ------------------------------------
     def background_hit(self, direction):
@@ -185,7 +279,8 @@ class CUSTOM_RENDER_PT_blackhole(RenderButtonsPanel, Panel):
              ("integration_depth", "Integration depth"), ("field_of_view_x", "field_of_view_x"),
              ("field_of_view_y", "field_of_view_y"), ("sampling_seed", "Sampling seed"), ("sky_image", "Sky image"),
              ("mark_x_min", "mark_x_min"), ("mark_x_max", "mark_x_max"), ("mark_y_min", "mark_y_min"),
-             ("mark_y_max", "mark_y_max"), ("curved_space_objects", "Objects in curved space (0/1)"))
+             ("mark_y_max", "mark_y_max"), ("curved_space_objects", "Objects in curved space (0/1)"),
+             ("device_shading", "Shade on the GPU (0/1)"))
 
     def draw(self, context):
         col = self.layout.split().column()
@@ -209,9 +304,10 @@ PROPS = [
     ("mark_x_max", bpy.props.FloatProperty(name="mark_x_max", default=-1.0)),
 ]
 
-# beyond the reference: opt-in switch for objects inside the curved region (module docstring)
+# beyond the reference, both opt-in (module docstring): objects inside the curved region; the frame shaded on the GPU
 EXTRA_PROPS = [
     ("curved_space_objects", bpy.props.FloatProperty(name="curved_space_objects", default=0)),
+    ("device_shading", bpy.props.FloatProperty(name="device_shading", default=0)),
 ]
 
 _EXCLUDED_PANELS = {"VIEWLAYER_PT_filter", "VIEWLAYER_PT_layer_passes"}

@@ -22,10 +22,25 @@ class FakeTexture:
         return _Vec([0.5 + 0.5 * np.sin(np.pi * u), 0.5 + 0.5 * v, 0.25 + 0.25 * np.cos(2 * np.pi * u), 1.0])
 
 
+class FakeImage:
+    """bpy.types.Image as far as the add-on reads it: size (w, h) and pixels, a flat float RGBA sequence, rows
+    bottom-up.  The content is a deterministic synthetic sky (tests predict colours from `array`)."""
+
+    def __init__(self, path, width=64, height=32, seed=11):
+        self.filepath = path
+        self.size = (width, height)
+        rng = np.random.default_rng(seed)
+        v, u = np.meshgrid(np.linspace(0, 1, height), np.linspace(0, 1, width), indexing="ij")
+        img = np.stack([0.2 + 0.6 * u, 0.1 + 0.8 * v, 0.5 + 0.4 * np.sin(6.0 * u + 3.0 * v), np.ones_like(u)], -1)
+        img[..., :3] += 0.05 * rng.random((height, width, 3))
+        self.array = img.astype(np.float32)          # [h, w, 4], row 0 = bottom
+        self.pixels = self.array.reshape(-1).tolist()
+
+
 class _Store(dict):
     def load(self, path):
         import os
-        self[os.path.basename(path)] = types.SimpleNamespace(filepath=path)
+        self[os.path.basename(path)] = FakeImage(path)
 
     def new(self, name, kind):
         self[name] = FakeTexture(name, kind)

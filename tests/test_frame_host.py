@@ -2,6 +2,7 @@
 (flat-space straight lines computed in the test): checks the generator protocol, accumulation,
 mark-window and registration logic.  No geodesic is computed here; the GPU counterpart is
 tests/test_gpu_frame.py."""
+import importlib
 import numpy as np
 import pytest
 
@@ -248,3 +249,35 @@ def test_frame_tracer_disk_colour():
     # the profile: white texture, peak where scale == mean
     c = disk_colour(np.array([[3.0 + 0.2 * 4.0, 0.0, 0.0]]), 3.0, 7.0)
     assert np.allclose(c, 1.0 / np.sqrt(2 * np.pi * 0.3))
+
+
+def test_addon_object_lighting_is_the_contracts_lambert_model_with_shadow_rays():
+    """ONE lighting contract for objects in the curved region: the add-on's host routine (spacetime_hit_many) is, term
+    for term, what the device kernel implements and oracle/shade_reference.object_colour restates -- Lambert lamps,
+    intensity^2 n.l / d^2, n.l clamped at 0, straight light paths, shadow rays against the other traced spheres
+    (raytracer/RelativisticRenderEngine.py:341-363)."""
+    import types
+    from oracle import shade_reference as sh
+    bpy, depsgraph = fake_bpy.install(width=8, height=8, samples=1)
+    addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+    eng = addon.RelativisticRenderEngine()
+    spheres = np.array([[2.0, 1.0, 8.0, 1.5], [2.6, 1.6, 11.0, 0.8], [-3.0, 0.5, -1.0, 1.2]])
+    lamps = [types.SimpleNamespace(type="LIGHT", location=(4.0, 3.0, 20.0)), types.SimpleNamespace(type="LIGHT", location=(-10.0, 0.0, 2.0))]
+    eng.lamps, eng._lit_spheres = lamps, spheres
+    rng = np.random.default_rng(4)
+    idx = rng.integers(0, 3, 400)
+    n = rng.normal(size=(400, 3))
+    n /= np.linalg.norm(n, axis=1)[:, None]
+    loc = spheres[idx, 0:3] + spheres[idx, 3:4] * n
+    got = eng.spacetime_hit_many(loc, n, idx)
+    end = np.concatenate([loc, np.zeros((400, 3))], 1)
+    want = sh.object_colour(end, idx, spheres, np.ones((3, 3)), [[*l.location, 10.0] for l in lamps])
+    assert np.abs(got - want).max() < 1e-12
+    lit = want.sum(1) > 0
+    assert 0.2 < lit.mean() < 0.9            # some points lit, some on the far side
+    # the second sphere sits between the first one and lamp 0: with it removed more of sphere 0 is lit
+    eng._lit_spheres = spheres[[0, 2]]
+    alone = eng.spacetime_hit_many(loc[idx == 0], n[idx == 0], np.zeros((idx == 0).sum(), dtype=int))
+    assert (alone.sum(1) > got[idx == 0].sum(1) + 1e-12).any()
+    names = [p[0] for p in addon.PROPS + addon.EXTRA_PROPS]
+    assert "device_shading" in names and "curved_space_objects" in names and len(addon.PROPS) == 12

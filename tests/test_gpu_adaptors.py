@@ -177,3 +177,53 @@ def test_kerr_kernel_at_vanishing_spin_equals_schwarzschild_kernel(ctx):
     # horizon flags: the BL event sits at r_plus (1 + 1e-3), a hair outside r_s -- the same rays are captured
     assert np.array_equal(fa & 1, fb & 1)
     assert np.abs(ea - eb)[esc].max() < 1e-6
+
+
+def test_addon_with_device_shading_renders_the_frame_on_the_gpu(ctx, oracle):
+    """scene.device_shading = 1: the add-on reads the sky image's pixels once and ray generation, trace, sky lookup
+    and the sample mean all run on the device (DeviceFrame) -- config 1 geometry, 64 x 64 x 1 and x 3, against an
+    image built from the oracle's end states and the numpy restatement of the library's bilinear lookup."""
+    from oracle import shade_reference as sh
+    from blackhole_geodesic_calculator_amd import camera_directions
+    for S in (1, 3):
+        bpy, depsgraph = fake_bpy.install(width=64, height=64, samples=S, device_shading=1.0)
+        addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+        addon.register()
+        eng = addon.RelativisticRenderEngine()
+        eng.render(depsgraph)
+        assert eng.ended == 1 and len(eng.progress) == 64 * S and abs(eng.progress[-1] - 1.0) < 1e-12
+        rect = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(64, 64, 4)
+        sky = bpy.data.images["sky.png"].array
+        d = camera_directions(64, 64, S, 0.6, 0.6, 42.0).reshape(-1, 3)
+        o = oracle.trace(d, CAM, r_s=1.0, lambda_end=50.0)
+        want = sh.shade_reduce(o["end"], o["flags"], 64 * 64, S, sky).reshape(64, 64, 4)
+        assert np.abs(rect - want).max() < 1e-6 and (o["flags"] & 1).sum() > 50 * S
+        assert eng.last_device_frame._dir_traced              # a sky-only frame traces exit directions alone
+        addon.unregister()
+
+
+def test_addon_device_and_host_paths_light_objects_alike(ctx):
+    """One lighting contract for object hits (Lambert lamps with shadow rays against the other spheres): the pixels
+    whose rays end on a sphere come out the same from the host path (Python, spacetime_hit_many) and from the device
+    path (object_colour in the shade kernel)."""
+    import types
+    out = {}
+    for dev in (0.0, 1.0):
+        bpy, depsgraph = fake_bpy.install(width=48, height=48, samples=1, device_shading=dev, curved_space_objects=1.0,
+                                          integration_depth=70)
+        addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+        addon.register()
+        depsgraph.scene.objects[:] = [
+            types.SimpleNamespace(type="MESH", location=(1.5, 1.0, 10.0), dimensions=(3.0, 3.0, 3.0)),
+            types.SimpleNamespace(type="MESH", location=(2.3, 1.9, 13.0), dimensions=(1.4, 1.4, 1.4)),
+            types.SimpleNamespace(type="LIGHT", location=(5.0, 5.0, 30.0))]
+        eng = addon.RelativisticRenderEngine()
+        eng.render(depsgraph)
+        out[dev] = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(48, 48, 4)
+        if dev:
+            fr = eng.last_device_frame
+            hit = (fr.d_flags.cpu().numpy() == 0x88).reshape(48, 48)
+        addon.unregister()
+    assert hit.sum() > 30
+    assert np.abs(out[0.0][hit] - out[1.0][hit]).max() < 1e-9
+    assert out[1.0][hit][:, :3].max() > 0 and (out[1.0][hit][:, :3].sum(1) == 0).any()    # lit and shadowed / far-side points
