@@ -128,10 +128,33 @@ def test_config5_kerr_frame_full_size(ctx, oracle):
     assert set(census) <= {1, 4} and sum(census.values()) == n and 0.02 * n < census[1] < 0.1 * n
     assert bool(torch.isfinite(end).all())
     _order_independent(ctx, p, fr.d_k0, res, x0_shared=CAM, seed=5)
-    idx = torch.arange(0, n, 1543, device="cuda")
-    o = oracle.trace(fr.d_k0[idx].cpu().numpy(), CAM, **kw)
-    same = (fl[idx].cpu().numpy() == o["flags"]) & (st[idx].cpu().numpy().astype(np.uint32) == o["n_attempted"])
-    # the camera sits on the polar axis (x = 1e-4, the reference's own choice): phi amplifies rounding there
-    assert (~same).mean() < 0.01
-    d = np.abs(end[idx].cpu().numpy() - o["end"]).max(1)[same & (o["flags"] == 4)]
-    assert np.median(d) < 1e-8
+    # The camera sits on the polar axis (x = 1e-4, the reference's own choice, CamEdition.py:216-221): Boyer-Lindquist
+    # phi amplifies rounding for rays that pass close to the axis, and where the GPU's Newton reciprocals / shared sincos
+    # and the oracle's IEEE divisions / libm differ in the last bit an accept / reject decision can flip.  The CENSUS over
+    # EVERY ray of the frame, asserted with a margin over what was measured (round 3, DESIGN.md section 2:
+    # 21 rays of 5,242,880 differ in flag, 5,082 (0.097 %) in step count only -- 3,257 of them horizon rays --; of the
+    # shaded 1024 x 1024 image 285 pixels (0.027 %) differ by more than 1e-3, 4,746 (0.45 %) by more than 1e-6, the
+    # largest single difference 0.18 in one channel of one pixel):
+    from oracle import shade_reference as sh
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    o = oracle.trace(fr.d_k0.cpu().numpy(), CAM, **kw)
+    flg, stp = fl.cpu().numpy(), st.cpu().numpy().astype(np.uint32)
+    fbad = flg != o["flags"]
+    sbad = ~fbad & (stp != o["n_attempted"])
+    assert fbad.sum() <= 100, int(fbad.sum())
+    assert sbad.mean() < 0.003, float(sbad.mean())
+    # the rays that differ pass closer to the axis than the frame's typical ray
+    kperp = np.hypot(*fr.d_k0[:, 0:2].cpu().numpy().T)
+    assert np.median(kperp[fbad | sbad]) < 0.6 * np.median(kperp)
+    same = ~fbad & ~sbad
+    d = np.abs(end.cpu().numpy() - o["end"]).max(1)
+    assert np.median(d[same & (o["flags"] == 4)]) < 1e-11 and np.quantile(d[same & (o["flags"] == 4)], 0.99) < 1e-4
+    # ... and what it does to the picture: the frame shaded on the device against the frame shaded from the oracle's states
+    sky = synthetic_sky(2048, 1024)
+    fr.set_sky(sky)
+    fr.d_end, fr.d_flags, fr._traced = end, fl, "end"
+    img = fr.shade().cpu().numpy()
+    img_o = sh.shade_reduce(o["end"], o["flags"], 1024 * 1024, 5, sky)
+    dimg = np.abs(img - img_o)[:, :3].max(1)
+    assert (dimg > 1e-3).mean() < 1e-3 and (dimg > 1e-6).mean() < 0.015, ((dimg > 1e-3).sum(), (dimg > 1e-6).sum())
+    assert np.median(dimg) < 1e-12
