@@ -44,6 +44,11 @@
 #define BHG_INLINE_PREPARE 1
 #endif
 
+// slack factor on the disk pre-filter's excursion bound (tuning builds override it)
+#ifndef BHG_DISK_SLACK
+#define BHG_DISK_SLACK (1.0 + 1e-9)
+#endif
+
 namespace bhg {
 
 // ------------------------------------------------------------------------------------------
@@ -503,9 +508,17 @@ __device__ __forceinline__ double pow_0p2(double x)
 #ifndef BHG_NSLOT
 #define BHG_NSLOT 111
 #endif
-constexpr int NSLOT = BHG_NSLOT;
-constexpr int QRING = 128;   // ring size of the queue list (a power of two >= NSLOT)
-static_assert(NSLOT >= 65 && NSLOT <= QRING, "the pool must hold a 64-ray batch plus one, slot ids are ring indices");
+#ifndef BHG_NSLOT_KERR
+#define BHG_NSLOT_KERR 150   // 8 waves per CU: 16 granules = 20,480 bytes per wave = 150 records of 128 bytes + the lists
+#endif
+template <int RHS>
+struct Pool {
+    static constexpr int N = RHS == BHG_RHS_KERR_BL_ ? BHG_NSLOT_KERR : BHG_NSLOT;
+    static constexpr int RING = N <= 128 ? 128 : 256;   // ring size of the queue list (a power of two >= N)
+    static_assert(N >= 65 && N <= 255, "the pool must hold a 64-ray batch plus one; slot ids are bytes");
+};
+#define NSLOT (Pool<RHS>::N)
+#define QRING (Pool<RHS>::RING)
 
 // One record: 12 doubles + 4 words, laid out so that a lane moves it with seven 16-byte LDS accesses
 // (ds_read_b128 / ds_write_b128) -- the pop runs in almost every iteration of the step loop (some lane of the wave
@@ -639,7 +652,7 @@ __device__ __forceinline__ bool disk_crossing_may_hit(const TraceArgs &A, const 
         const double e0 = __builtin_fma(h, v0[c], -dx), e1 = __builtin_fma(h, v1[c], -dx);
         n01 += fabs(e0) + fabs(e1);
     }
-    const double delta = n01 * (1.0 + 1e-9);
+    const double delta = n01 * BHG_DISK_SLACK;
     const double lo = A.disk_r_in - delta, hi = A.disk_r_out + delta;
     // R = |P| / |D| against [lo, hi], compared as squares times D^2; a step lying in the plane (D = 0, P = 0) and NaN
     // anywhere fall through to "may hit"
@@ -665,12 +678,97 @@ __device__ __forceinline__ bool disk_crossing_may_hit_bl(const TraceArgs &A, con
     const double cr = dr * ih, cth = dth * ih;
     const double d_r = fabs(h) * (fabs(v0[0] - cr) + fabs(v1[0] - cr));
     const double d_th = fabs(h) * (fabs(v0[1] - cth) + fabs(v1[1] - cth));
-    const double D = __builtin_fma(fabs(dr), d_th * fabs(idth), d_r) * (1.0 + 1e-9);
+    const double D = __builtin_fma(fabs(dr), d_th * fabs(idth), d_r) * BHG_DISK_SLACK;
     const double a2 = A.spin * A.spin;
     const double r_lo = fmax(r_lin - D, 0.0), r_hi = r_lin + D;
     // R = sqrt(r^2 + a^2) against the annulus, compared in squares
     const double R2_lo = __builtin_fma(r_lo, r_lo, a2), R2_hi = __builtin_fma(r_hi, r_hi, a2);
     return !(R2_hi < A.disk_r_in * A.disk_r_in || R2_lo > A.disk_r_out * A.disk_r_out);  // NaN anywhere: may hit
+}
+
+// The sharp form of the same question, for the crossings the bound above lets through (next to an annulus most do: it
+// is 8 to 16 times the true excursion, and in Boyer-Lindquist coordinates, where dr/dlambda changes along a straight
+// line, far more).  EXACT relation between the step's dense output D and the cubic Hermite interpolant H through its
+// end states: both match x and dx/dlambda at both ends (the DP5 dense output is C1: D'(0) = h v0, D'(1) = h v1), so
+// their difference is the quartic with double roots at 0 and 1,
+//         D_c(th) - H_c(th) = (h q3_c) th^2 (1 - th)^2,     |D_c - H_c| <= |h q3_c| / 16,
+// q3 the dense output's leading coefficient -- six FMAs per component from the stage accelerations the step loop holds.
+// So: the plane crossing th_h of H (two Newton steps from the chord's), the crossing of D within
+// dth = 1.5 e_z / |H_z'(th_h)| of it where H_z is monotone (it is checked), and the crossing POINT of D within
+// e_xy + |H_xy'| dth of H_xy(th_h).  Outside the annulus widened by that: not terminal, the ray carries on.
+template <int RHS>
+__device__ __forceinline__ bool disk_crossing_may_hit_sharp(const TraceArgs &A, const double x0[3], const double v0[3],
+                                                            const double x1[3], const double v1[3], double h,
+                                                            const double a1[3], const double a2[3], const double a3[3],
+                                                            const double a4[3], const double a5[3], const double a6[3])
+{
+    constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
+    constexpr int ce = BL ? 1 : 2;      // the coordinate the plane is a level set of
+    double target = 0.0;
+    if (BL) {
+        const double k0 = floor((x0[1] - 1.5707963267948966) * 0.3183098861837907);
+        const double k1 = floor((x1[1] - 1.5707963267948966) * 0.3183098861837907);
+        if (fabs(k1 - k0) != 1.0) return true;      // (a lane that crossed no plane, or several: let the drain decide)
+        target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
+    }
+    // |h q3_c| / 16 (P~[7][3] = 0: stage 7 does not enter)
+    double e4[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        double qx = TB.pt[1][3] * a1[c];
+        qx = __builtin_fma(TB.pt[2][3], a2[c], qx);
+        qx = __builtin_fma(TB.pt[3][3], a3[c], qx);
+        qx = __builtin_fma(TB.pt[4][3], a4[c], qx);
+        qx = __builtin_fma(TB.pt[5][3], a5[c], qx);
+        qx = __builtin_fma(TB.pt[6][3], a6[c], qx);
+        e4[c] = fabs(h * __builtin_fma(h, qx, TB.sig[3] * v0[c])) * 0.0625;
+    }
+    // Hermite: H(th) = x0 + b1 th + b2 th^2 + b3 th^3, b1 = h v0, b2 = 3 d - 2 h v0 - h v1, b3 = -2 d + h v0 + h v1
+    double b1[3], b2[3], b3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double d = x1[c] - x0[c], m0 = h * v0[c], m1 = h * v1[c];
+        b1[c] = m0;
+        b2[c] = __builtin_fma(3.0, d, -__builtin_fma(2.0, m0, m1));
+        b3[c] = __builtin_fma(-2.0, d, m0 + m1);
+    }
+    const double z0 = x0[ce] - target, dz = x1[ce] - x0[ce];
+    // H_z monotone over the step?  H_z' is a parabola: its values at both ends and at an interior extremum must all have
+    // the sign of dz, and not be small against it (a tangential crossing: let the drain decide)
+    const double g0 = b1[ce], g1 = __builtin_fma(3.0, b3[ce], __builtin_fma(2.0, b2[ce], b1[ce]));
+    const double the = -b2[ce] * rcp_nr(3.0 * b3[ce]);                       // extremum of H_z' (NaN / inf: no interior one)
+    const double ge = (the > 0.0 && the < 1.0) ? __builtin_fma(b2[ce], the, b1[ce]) : g0;   // H_z'(the) = b1 + b2 the there
+    const double sgn = dz < 0.0 ? -1.0 : 1.0;
+    const double gmin = fmin(fmin(g0 * sgn, g1 * sgn), ge * sgn);
+    if (!(gmin > 0.125 * fabs(dz))) return true;
+    double th = -z0 * rcp_nr(dz);
+    th = fmin(fmax(th, 0.0), 1.0);
+    double f = 0.0, df = 1.0;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        f = __builtin_fma(__builtin_fma(__builtin_fma(b3[ce], th, b2[ce]), th, b1[ce]), th, z0);
+        df = __builtin_fma(__builtin_fma(3.0 * b3[ce], th, 2.0 * b2[ce]), th, b1[ce]);
+        th = fmin(fmax(__builtin_fma(-f, rcp_nr(df), th), 0.0), 1.0);
+    }
+    f = __builtin_fma(__builtin_fma(__builtin_fma(b3[ce], th, b2[ce]), th, b1[ce]), th, z0);
+    // the dense output's crossing lies within dth of th: |H_z| <= e_z there, H_z' >= gmin throughout
+    const double dth = (1.5 * e4[ce] + fabs(f)) * rcp_nr(gmin);
+    if (BL) {
+        const double r = __builtin_fma(__builtin_fma(__builtin_fma(b3[0], th, b2[0]), th, b1[0]), th, x0[0]);
+        // (|H_r'| <= |b1| + 2|b2| + 3|b3| on [0, 1])
+        const double er = __builtin_fma(fabs(b1[0]) + __builtin_fma(2.0, fabs(b2[0]), 3.0 * fabs(b3[0])), dth, e4[0]) * (1.0 + 1e-6);
+        const double aa = A.spin * A.spin;
+        const double r_lo = fmax(r - er, 0.0), r_hi = r + er;
+        return !(__builtin_fma(r_hi, r_hi, aa) < A.disk_r_in * A.disk_r_in || __builtin_fma(r_lo, r_lo, aa) > A.disk_r_out * A.disk_r_out);
+    }
+    const double X = __builtin_fma(__builtin_fma(__builtin_fma(b3[0], th, b2[0]), th, b1[0]), th, x0[0]);
+    const double Y = __builtin_fma(__builtin_fma(__builtin_fma(b3[1], th, b2[1]), th, b1[1]), th, x0[1]);
+    const double sl = (fabs(b1[0]) + __builtin_fma(2.0, fabs(b2[0]), 3.0 * fabs(b3[0]))) +
+                      (fabs(b1[1]) + __builtin_fma(2.0, fabs(b2[1]), 3.0 * fabs(b3[1])));
+    const double eps = __builtin_fma(sl, dth, e4[0] + e4[1]) * (1.0 + 1e-6);     // (1-norm of the error in (x, y) >= its length)
+    const double R2 = __builtin_fma(X, X, Y * Y);
+    const double lo = A.disk_r_in - eps, hi = A.disk_r_out + eps;
+    return !((lo > 0.0 && R2 < lo * lo) || R2 > hi * hi);       // NaN anywhere: may hit
 }
 
 __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
@@ -2100,6 +2198,16 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                         !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
                                                   : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
                         ev_d = false;
+#ifndef BHG_NO_SHARP_FILTER
+                    // ... and, in Boyer-Lindquist coordinates, what that bound lets through against the exact one (a
+                    // wave-wide skip when it let nothing through).  Measured: the chord bound passes 0.19 crossings per
+                    // Schwarzschild ray that the drain then finds outside the annulus, and 0.69 per Kerr ray (dr/dlambda
+                    // changes along a straight line); the exact test is 140 instructions: Kerr + disk +1.5 %, the
+                    // Schwarzschild disk frame -1.1 % with it -- so Kerr only.
+                    if (RHS == BHG_RHS_KERR_BL_ && (EVT & EVT_DISK) && __ballot(ev_d) != 0ull) {
+                        if (ev_d && !disk_crossing_may_hit_sharp<RHS>(A, L.x, L.v, xn, vn, h, L.a1, a2, a3, a4, a5, a6)) ev_d = false;
+                    }
+#endif
                     if (ev_h || ev_e || ev_d || ev_o) {
                         // Park the step: x, v, a1, t still hold its START (the event drain recomputes it from there),
                         // h_abs is already the controller's choice for the next step, the radius register takes the

@@ -6,10 +6,11 @@ from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, FrameBat
 what = sys.argv[1] if len(sys.argv) > 1 else "frame"
 out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/diag.bin"
 ctx = _ffi.Context(0)
-if what == "disk":
+if what in ("disk", "diskkerr"):
     cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0)) for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
     fr = FrameBatch(ctx, cams, 1024, 1024, 1, fov_x=0.9, fov_y=0.9)
-    p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)
+    p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5,
+                         **(dict(rhs_form=2, spin=0.45) if what == "diskkerr" else {}))
 elif what == "orbit":
     fr = DeviceFrame(ctx, 2048, 2048, 4, fov_x=0.6, fov_y=0.6)
     fr.set_objects([[8.0, 0.0, 0.0, 1.5]])
