@@ -75,7 +75,12 @@ def parse():
                     help="N = 1, frame workload: also time rank 0's shard of a world-N dealing of the SAME fixed frame (no "
                          "collective) for each N listed and report the predicted strong-scaling efficiency T1 / (N T_N) in "
                          "a strong_predicted block; '' = off")
+    ap.add_argument("--lean", action="store_true",
+                    help="profiling runs: the headline's timed region and nothing after it (no full_records, shard emulation, "
+                         "pipelined / host-buffer figures, CPU baseline), so that a profiler's per-kernel averages are the headline's")
     a = ap.parse_args()
+    if a.lean:
+        a.cpu_seconds, a.emulate_shards = 0.0, ""
     dw, ds = {"frame": (1024, 5), "disk": (1024, 1), "orbit": (2048, 16)}[a.workload]
     a.width = a.width or dw
     a.height = a.height or a.width
@@ -493,7 +498,7 @@ def main():
         }
         if strong is not None:
             out["strong"] = strong
-        if world == 1 and a.workload == "frame" and getattr(fr, "_dir_traced", False):
+        if world == 1 and a.workload == "frame" and getattr(fr, "_dir_traced", False) and not a.lean:
             # what north_star names -- "exit position/direction written back": the same frame with whole end states
             # (81 B/ray) instead of the exit directions a sky frame reads (57 B/ray); same K / W, same clock
             frf = DeviceFrame(ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=cam,

@@ -511,14 +511,18 @@ __device__ __forceinline__ double pow_0p2(double x)
 #ifndef BHG_NSLOT_KERR
 #define BHG_NSLOT_KERR 150   // 8 waves per CU: 16 granules = 20,480 bytes per wave = 150 records of 128 bytes + the lists
 #endif
-template <int RHS>
+#ifndef BHG_NSLOT_RK4
+#define BHG_NSLOT_RK4 88     // the fixed-step kernels hold ~120 VGPRs and run 16 waves per CU: 8 granules = 10,240 bytes
+#endif
+// pool size of a kernel: by right-hand side and stepper (the fixed-step Kerr kernel runs few waves: the Schwarzschild size)
+template <int RHS, bool ADAPTIVE>
 struct Pool {
-    static constexpr int N = RHS == BHG_RHS_KERR_BL_ ? BHG_NSLOT_KERR : BHG_NSLOT;
-    static constexpr int RING = N <= 128 ? 128 : 256;   // ring size of the queue list (a power of two >= N)
-    static_assert(N >= 65 && N <= 255, "the pool must hold a 64-ray batch plus one; slot ids are bytes");
+    static constexpr int N = ADAPTIVE ? (RHS == BHG_RHS_KERR_BL_ ? BHG_NSLOT_KERR : BHG_NSLOT)
+                                      : (RHS == BHG_RHS_KERR_BL_ ? BHG_NSLOT : BHG_NSLOT_RK4);
 };
-#define NSLOT (Pool<RHS>::N)
-#define QRING (Pool<RHS>::RING)
+// (inside the functions below `LDS` is the wave's WaveLds type)
+#define NSLOT (LDS::N)
+#define QRING (LDS::RING)
 
 // One record: 12 doubles + 4 words, laid out so that a lane moves it with seven 16-byte LDS accesses
 // (ds_read_b128 / ds_write_b128) -- the pop runs in almost every iteration of the step loop (some lane of the wave
@@ -532,15 +536,18 @@ struct alignas(16) QEntry {
     double2 el[(RHS == BHG_RHS_KERR_BL_) ? 1 : 0];  // Kerr: the ray's Killing constants E, L
 };
 
-template <int RHS>
+template <int RHS, int NS>
 struct WaveLds {
-    QEntry<RHS> slot[NSLOT];
-    uint8_t q_list[QRING];      // slots of the queued rays, a ring: q_head .. q_head + q_count - 1 (mod QRING)
-    uint8_t free_list[NSLOT];   // free slots, a stack of n_free entries
+    static constexpr int N = NS;
+    static constexpr int RING = NS <= 128 ? 128 : 256;   // ring size of the queue list (a power of two >= N)
+    static_assert(NS >= 65 && NS <= 255, "the pool must hold a 64-ray batch plus one; slot ids are bytes");
+    QEntry<RHS> slot[NS];
+    uint8_t q_list[RING];       // slots of the queued rays, a ring: q_head .. q_head + q_count - 1 (mod RING)
+    uint8_t free_list[NS];      // free slots, a stack of n_free entries
 #ifdef BHG_CHECK
-    uint8_t tag[NSLOT];         // debugging: 0 free, 1 queued, 2 parked short, 3 parked long, 4 borrowed
+    uint8_t tag[NS];            // debugging: 0 free, 1 queued, 2 parked short, 3 parked long, 4 borrowed
 #endif
-    uint8_t ev_list[NSLOT];     // slots of the parked steps: the SHORT list (one candidate event, exit sphere or disk
+    uint8_t ev_list[NS];        // slots of the parked steps: the SHORT list (one candidate event, exit sphere or disk
                                 // plane: certified Newton search) grows up from [0], the LONG list (horizon, several
                                 // candidates, object spheres, failed certificates: Brent) grows down from [NSLOT - 1]
 };
@@ -969,8 +976,8 @@ __device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric 
 // Put rays base .. base+63 into the ray queue: coalesced loads of k0, x0 and -- Kerr -- of the prepare
 // pass's record {a0, h0, r0, 0, E, L}; the Schwarzschild forms work the records out here, all lanes together.
 // Items that pass (h >= 0) take a free slot each (ballot/mbcnt ranks); the caller has made sure 64 are free.
-template <int RHS, bool ADAPTIVE>
-__device__ __forceinline__ void fill_batch(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane, uint64_t base)
+template <int RHS, bool ADAPTIVE, class LDS>
+__device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, uint32_t lane, uint64_t base)
 {
     // Schwarzschild forms: no prepare pass has run, the wave works the records out itself
     const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && A.inline_prepare;
@@ -1654,7 +1661,7 @@ __device__ __forceinline__ int rk4_resolve_parked(const TraceArgs &A, const Metr
 {
     constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
     const double t = P.t;
-    double t_new = t + P.r_cur;
+    double t_new = t + A.h_fixed;        // (as the integrate loop took the step)
     if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
     const double h = t_new - t;
     Hermite d;
@@ -1727,8 +1734,8 @@ __device__ __forceinline__ int rk4_resolve_parked(const TraceArgs &A, const Metr
 //     any time and at any width.
 // The fixed-step kernels (no certified search) put everything on the short list and resolve it with Brent there.
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void drain_short(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane, int take)
+template <int RHS, bool ADAPTIVE, int EVT, class LDS>
+__device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W, Lane &L, uint32_t lane, int take)
 {
     const bool mine = (int)lane < take;
     const uint32_t s = mine ? Q.ev_list[W.n_evA - take + (int)lane] : Q.free_list[W.n_free - 1 - ((int)lane - take)];
@@ -1793,8 +1800,8 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, WaveLds<RHS> &Q,
 #endif
 }
 
-template <int RHS, int EVT>
-__device__ __forceinline__ void drain_long(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, uint32_t lane, int take)
+template <int RHS, int EVT, class LDS>
+__device__ __forceinline__ void drain_long(const TraceArgs &A, LDS &Q, Wave &W, uint32_t lane, int take)
 {
     const bool mine = (int)lane < take;
     int outcome = PARK_ENDED;
@@ -1843,8 +1850,8 @@ __device__ __forceinline__ bool short_kind(uint32_t kind)
 // Lanes that hold a step to park (L.pend) put its record into free slots, as many as there are.  A lane that finds
 // none keeps its record in its registers and stays inactive until slots come free: every pop frees one, and with an
 // empty queue and no free slot all NSLOT >= 64 slots hold parked steps, which the next service() drains.
-template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void deposit_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+template <int RHS, bool ADAPTIVE, int EVT, class LDS>
+__device__ __forceinline__ void deposit_parked(LDS &Q, Wave &W, Lane &L, uint32_t lane)
 {
     const uint64_t pm = __ballot(L.pend != 0u);
     if (!pm || W.n_free == 0) return;
@@ -1873,8 +1880,8 @@ __device__ __forceinline__ void deposit_parked(WaveLds<RHS> &Q, Wave &W, Lane &L
 
 // Serve the lanes that wait for a ray from the queue: at most one pop per lane, straight into the lane's registers;
 // the popped slots are free again.
-template <int RHS>
-__device__ __forceinline__ void pop_rays(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+template <int RHS, class LDS>
+__device__ __forceinline__ void pop_rays(LDS &Q, Wave &W, Lane &L, uint32_t lane)
 {
     const uint64_t need = __ballot(!L.active && L.pend == 0u);
     const int n_need = __builtin_popcountll(need);
@@ -1899,8 +1906,8 @@ __device__ __forceinline__ void pop_rays(WaveLds<RHS> &Q, Wave &W, Lane &L, uint
 // head of the queue -- the queued ray comes out, the park record goes into its slot.  Without this a wave whose 64
 // lanes all wait to park next to a non-empty queue would wait for ever (nobody pops, so no slot comes free, and fewer
 // than 64 steps may be parked, so nothing drains).  Rare; kept apart so that the plain pop needs no register copies.
-template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void swap_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+template <int RHS, bool ADAPTIVE, int EVT, class LDS>
+__device__ __forceinline__ void swap_parked(LDS &Q, Wave &W, Lane &L, uint32_t lane)
 {
     const uint64_t pm = __ballot(L.pend != 0u);
     const int n = __builtin_popcountll(pm);
@@ -1946,8 +1953,8 @@ __device__ __forceinline__ void swap_parked(WaveLds<RHS> &Q, Wave &W, Lane &L, u
 // ONE loop with one site each for the drains and the queue fill (each is several hundred instructions), kept apart from
 // the pop: a loop around the pop makes the whole lane state a loop-carried value and costs ~20 register copies in
 // every iteration of the step loop (round 2's "register-copy storm", met again here).
-template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+template <int RHS, bool ADAPTIVE, int EVT, class LDS>
+__device__ __forceinline__ void replenish(const TraceArgs &A, LDS &Q, Wave &W, Lane &L, uint32_t lane)
 {
     for (;;) {
         int take_a = 0, take_b = 0;
@@ -2022,8 +2029,8 @@ __device__ __forceinline__ void replenish(const TraceArgs &A, WaveLds<RHS> &Q, W
 // Some lane is not stepping: park what has to be parked, (rarely) drain and refill, give the waiting lanes rays from
 // the queue -- at most one pop per lane and call (a lane the queue could not serve is served by the next iteration's
 // call).  Returns true when the wave is done: nothing in flight, queued, parked or waiting to be parked, no batch left.
-template <int RHS, bool ADAPTIVE, int EVT>
-__device__ __forceinline__ bool service(const TraceArgs &A, WaveLds<RHS> &Q, Wave &W, Lane &L, uint32_t lane)
+template <int RHS, bool ADAPTIVE, int EVT, class LDS>
+__device__ __forceinline__ bool service(const TraceArgs &A, LDS &Q, Wave &W, Lane &L, uint32_t lane)
 {
     deposit_parked<RHS, ADAPTIVE, EVT>(Q, W, L, lane);
     const int n_ev = W.n_evA + W.n_evB;
@@ -2051,7 +2058,8 @@ __device__ __forceinline__ bool service(const TraceArgs &A, WaveLds<RHS> &Q, Wav
 template <int RHS, int EVT>
 __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_PER_SIMD : BHG_DP54_WAVES_PER_SIMD)) trace_dp54_kernel(const TraceArgs A0)
 {
-    __shared__ WaveLds<RHS> Q;
+    using LDS = WaveLds<RHS, Pool<RHS, true>::N>;
+    __shared__ LDS Q;
     const uint32_t lane = threadIdx.x;
     TraceArgs A = A0;  // (a copy the Kerr variant below can move fields of into VGPRs; free for the others)
     double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
@@ -2259,7 +2267,8 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 template <int RHS, int EVT>
 __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 {
-    __shared__ WaveLds<RHS> Q;
+    using LDS = WaveLds<RHS, Pool<RHS, false>::N>;
+    __shared__ LDS Q;
     const uint32_t lane = threadIdx.x;
     const double r_s = A.r_hor, t_bound = A.lambda_end, hf = A.h_fixed;  // r_s: horizon EVENT radius
     Metric met;
@@ -2290,54 +2299,52 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
 
     for (;;) {
         if (__ballot(!L.active) && service<RHS, false, EVT>(A, Q, W, L, lane)) break;
+        // Rays at the end of the affine range or of their step budget leave first, in a branch of its own, so that the step
+        // below is ONE region with ONE place where the lane's state is overwritten (nested under the end test, the merged
+        // state was copied into a second register set at every level: 33 v_mov_b64 per iteration on 166 fp64 instructions).
+        if (L.active && (L.t >= t_bound || L.n_att >= A.max_steps)) {
+            store_result(A, L.idx, L.x, L.v, L.t >= t_bound ? BHG_FLAG_REACHED_END_ : BHG_FLAG_MAX_STEPS_, L.n_att, L.n_att);
+            L.active = 0u;
+        }
         if (L.active) {
-            uint32_t term = 0;
-            if (L.t >= t_bound)
-                term = BHG_FLAG_REACHED_END_;
-            else if (L.n_att >= A.max_steps)
-                term = BHG_FLAG_MAX_STEPS_;
-            if (term) {
-                store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_att);
+            double t_new = L.t + hf;
+            if (t_new - t_bound > 0.0) t_new = t_bound;
+            const double h = t_new - L.t;
+            double xn[3], vn[3], an[3], r_new;
+            if (RHS == BHG_RHS_KERR_BL_) {
+                met.E = L.E;
+                met.L = L.Lz;
+            }
+            rk4_step<RHS>(L.x, L.v, L.a1, h, met, xn, vn, an, r_new);
+            L.n_att++;
+            const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
+                              ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+            const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+            bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
+            const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+            if ((EVT & EVT_DISK) && ev_d &&
+                !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
+                                          : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
+                ev_d = false;
+            const bool ev = ev_h || ev_e || ev_d || ev_o, bad = !(r_new == r_new);
+            if (ev) {
+                // (the park record is the lane state as it stands -- the fixed-step drain takes |h| from the call's
+                // parameters, so no double of the state is written in this branch)
+                L.n_acc = L.n_att;
+                L.pend = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
                 L.active = 0u;
-            } else {
-                double t_new = L.t + hf;
-                if (t_new - t_bound > 0.0) t_new = t_bound;
-                const double h = t_new - L.t;
-                double xn[3], vn[3], an[3], r_new;
-                if (RHS == BHG_RHS_KERR_BL_) {
-                    met.E = L.E;
-                    met.L = L.Lz;
-                }
-                rk4_step<RHS>(L.x, L.v, L.a1, h, met, xn, vn, an, r_new);
-                L.n_att++;
-                const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
-                                  ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
-                const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
-                bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
-                const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
-                if ((EVT & EVT_DISK) && ev_d &&
-                    !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl(A, L.x, L.v, xn, vn, h)
-                                              : disk_crossing_may_hit(A, L.x, L.v, xn, vn, h)))
-                    ev_d = false;
-                if (ev_h || ev_e || ev_d || ev_o) {
-                    // (park record as in the DP5(4) loop: next |h| and the |h| this step tried are both h_fixed)
-                    L.n_acc = L.n_att;
-                    L.h_abs = hf;
-                    L.r_cur = hf;
-                    L.pend = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
-                    L.active = 0u;
-                } else if (!(r_new == r_new)) {
-                    store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
-                    L.active = 0u;
-                } else {
-                    L.t = t_new;
-                    L.r_cur = r_new;
+            } else if (bad) {
+                store_result(A, L.idx, xn, vn, 0, L.n_att, L.n_att);  // NaN flag added by store_result
+                L.active = 0u;
+            }
+            if (!ev && !bad) {
+                L.t = t_new;
+                L.r_cur = r_new;
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        L.x[c] = xn[c];
-                        L.v[c] = vn[c];
-                        L.a1[c] = an[c];
-                    }
+                for (int c = 0; c < 3; c++) {
+                    L.x[c] = xn[c];
+                    L.v[c] = vn[c];
+                    L.a1[c] = an[c];
                 }
             }
         }

@@ -4,7 +4,7 @@ args="$1"; shift
 for rep in 1 2; do
 for v in "$@"; do
   if [ "$v" = "base" ]; then lib=""; else lib="$PWD/build/variants/libbhgeo_$v.so"; fi
-  BHGEO_LIB=$lib timeout 300 python bench.py --cpu-seconds 0 --emulate-shards= $args 2>&1 | tail -1 | python3 -c "
+  BHGEO_LIB=$lib timeout 300 python bench.py --lean $args 2>&1 | tail -1 | python3 -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read())

@@ -9,16 +9,16 @@ mkdir -p $O
 timeout 600 python3 $R/bench.py "$@" 2>/dev/null | tail -1 > $O/prof_${name}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_$name /tmp/pf_$name /tmp/pw_$name
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-seconds 0 "$@" > $O/prof_${name}_rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 $R/bench.py --steps 20 --warmup 3 --lean "$@" > $O/prof_${name}_rocprof.log 2>&1
 for f in $(find /tmp/kt_$name -name "*kernel_stats.csv"); do cp $f $O/prof_${name}_kernel_stats.csv; done
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --cpu-seconds 0 "$@" >> $O/prof_${name}_rocprof.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --cpu-seconds 0 "$@" >> $O/prof_${name}_rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean "$@" >> $O/prof_${name}_rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean "$@" >> $O/prof_${name}_rocprof.log 2>&1
 for f in $(find /tmp/pf_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_pmc_fetch.csv; grep "trace_" $f >> $O/prof_${name}_pmc_fetch.csv; done
 for f in $(find /tmp/pw_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_pmc_write.csv; grep "trace_" $f >> $O/prof_${name}_pmc_write.csv; done
 python3 $R/scripts/summarize_pmc.py $O/prof_${name}_pmc_fetch.csv $O/prof_${name}_pmc_write.csv $O/prof_${name}_pmc_summary.json trace_ > /dev/null
 for ctr in VALUBusy VALUUtilization SQ_INSTS_VALU; do
   rm -rf /tmp/dv_$name
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/dv_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --cpu-seconds 0 "$@" >> $O/prof_${name}_rocprof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/dv_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean "$@" >> $O/prof_${name}_rocprof.log 2>&1
   for f in $(find /tmp/dv_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_$ctr.csv; grep "trace_" $f >> $O/prof_${name}_$ctr.csv; done
 done
 python3 - <<PY
