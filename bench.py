@@ -70,6 +70,14 @@ def parse():
     ap.add_argument("--full-records", action="store_true",
                     help="frame workload: have the trace write whole end states (48 B/ray) instead of the exit directions a sky frame reads")
     ap.add_argument("--lpt", type=int, default=1, help="1: visit tiles in order of decreasing expected cost")
+    ap.add_argument("--visit", choices=["auto", "cost", "row"], default="auto",
+                    help="order in which a rank visits its tiles: by decreasing cost (shortens the wave-drain tail: what a "
+                         "1/8 shard's 0.2-ms kernel needs), row-major (1 %% faster over a whole frame on one GPU: the cheap "
+                         "far-field batches, which claim work every few iterations, stay interleaved with the long rays); "
+                         "auto = row on one GPU, cost when the frame is sharded")
+    ap.add_argument("--order", choices=["measured", "model", "none"], default="model",
+                    help="tile order / dealing: by the attempted steps of one untimed calibration trace of the same frame "
+                         "(dist.measured_tile_cost), by the shadow-edge model (plain frame only), or row-major")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline wall time (0 = skip)")
     ap.add_argument("--emulate-shards", type=str, default="2,4,8",
                     help="N = 1, frame workload: also time rank 0's shard of a world-N dealing of the SAME fixed frame (no "
@@ -229,32 +237,50 @@ def main():
             ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
             return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
 
-        # (only the plain frame: with a disk or the orbiting sphere this cost model is wrong and the order measured 1.5 % slower)
-        tcost = tile_cost if (a.lpt and a.workload == "frame") else None
-        pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
+        tile_cost.visit = a.visit if a.visit != "auto" else ("row" if world == 1 else "cost")
+        # (the model only for the plain frame: with a disk or the orbiting sphere it is wrong and the order measured 1.5 % slower)
+        tcost = tile_cost if (a.lpt and a.order != "none" and a.workload == "frame") else None
         jitter = python_random_stream(42.0, 2 * S * W * H)
-        frames = []   # the DeviceFrames one step passes over
-        batch = None
-        if a.workload == "disk":
-            # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination),
-            # traced by ONE library call with per-ray origins (FrameBatch); shaded frame by frame
-            cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0))
-                    for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
-            batch = FrameBatch(ctx, cams, W, H, S, pixels=pixels, jitter=jitter, fov_x=0.9, fov_y=0.9, sampling_seed=42.0)
-            frames = batch.frames
-            disk_tex = synthetic_sky(1024, 128, seed=3)
+
+        def build_frames(pixels):
+            frames, batch = [], None   # the DeviceFrames one step passes over
+            if a.workload == "disk":
+                # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination),
+                # traced by ONE library call with per-ray origins (FrameBatch); shaded frame by frame
+                cams = [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0))
+                        for i in np.radians([85.0, 80.0, 60.0, 30.0, 5.0])]
+                batch = FrameBatch(ctx, cams, W, H, S, pixels=pixels, jitter=jitter, fov_x=0.9, fov_y=0.9, sampling_seed=42.0)
+                frames = batch.frames
+                disk_tex = synthetic_sky(1024, 128, seed=3)
+                for f in frames:
+                    f.set_disk(DISK[0], DISK[1], disk_tex)
+            else:
+                # a sky frame reads only the exit directions of its rays (background_hit, :366-378): the trace writes those
+                # alone (bhg_trace_dir_device) unless --full-records asks for whole end states
+                frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
+                                          pixels=pixels, jitter=jitter,
+                                          directions_only=(a.workload == "frame" and not a.full_records)))
             for f in frames:
-                f.set_disk(DISK[0], DISK[1], disk_tex)
-        else:
-            # a sky frame reads only the exit directions of its rays (background_hit, :366-378): the trace writes those
-            # alone (bhg_trace_dir_device) unless --full-records asks for whole end states
-            frames.append(DeviceFrame(ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=cam,
-                                      pixels=pixels, jitter=jitter,
-                                      directions_only=(a.workload == "frame" and not a.full_records)))
+                f.set_sky(sky)
+                f.generate_rays()
+            return frames, batch
+
+        pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
+        frames, batch = build_frames(pixels)
+        if a.lpt and a.order == "measured":
+            # One untimed calibration trace of the frame prices every tile by the attempted steps of its rays; the tiles
+            # are then dealt to the ranks and visited longest-first by THAT (the renderer traces the same pixels sample
+            # after sample and frame after frame, :242-250: the last pass prices the next).  Same rays, another order.
+            if a.workload == "orbit":
+                frames[0].set_objects(*orbit_scene(0))
+            (batch or frames[0]).trace(params)
+            cost = sum(f.pixel_cost() for f in frames).cpu().numpy()
+            tcost = bdist.measured_tile_cost(W, H, a.tile, pixels, cost)
+            tcost.visit = tile_cost.visit
+            del frames, batch
+            pixels = bdist.rank_pixels(W, H, a.tile, rank, world, tile_cost=tcost)
+            frames, batch = build_frames(pixels)
         del jitter
-        for f in frames:
-            f.set_sky(sky)
-            f.generate_rays()
         fr = frames[0]
         n = sum(f.n for f in frames)
 
@@ -371,7 +397,7 @@ def main():
         if lanes is not None:
             ctx2.close()
         return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
-                    steps_all=float(tot[1].item()), launch=ctx.last_launch(), fr=fr)
+                    steps_all=float(tot[1].item()), launch=ctx.last_launch(), fr=fr, tcost=tcost)
 
     def time_frame(fr_, steps, warmup, overlap=False):
         """K timed steps of trace + shade (float RGBA in frame order) of ONE DeviceFrame on this GPU, no collective:
@@ -427,6 +453,7 @@ def main():
             strong["two_frames_in_flight"] = {"value": s2["rays_all"] / (s2["dt"] / a.steps) / 1e6, "unit": "Mrays/s",
                                               "ms_per_step": s2["dt"] / a.steps * 1e3}
             del s2
+    tile_cost_visit = a.visit if a.visit != "auto" else ("row" if world == 1 else "cost")
     W, H, S, n, ray_steps, dt, call_ms, k_ms = m["W"], m["H"], m["S"], m["n"], m["ray_steps"], m["dt"], m["call_ms"], m["k_ms"]
     rays_all, steps_all, fr = m["rays_all"], m["steps_all"], m["fr"]
 
@@ -467,7 +494,9 @@ def main():
                 "regime": a.regime, "integrator": "DP5(4) scipy-RK45 controller" if method == "dp54" else "RK4 h=0.1",
                 "rtol": 1e-3, "atol": 1e-6, "max_step": (0.1 if a.regime == "fine" else "inf"),
                 "rhs_form": a.rhs, "rays_per_gpu": n, "attempted_steps_per_ray": ray_steps / n,
-                "tile": a.tile, "trace_output": "exit directions + flags + step counts (25 + 8 B/ray)" if getattr(fr, "_dir_traced", False) else "end states + flags + step counts (49 + 8 B/ray)",
+                "tile": a.tile, "tile_order": ("longest first by the attempted steps of an untimed calibration trace" if a.order == "measured" else
+                                               ("dealt by the shadow-edge model, visited " + ("row-major" if tile_cost_visit == "row" else "longest first")) if (a.order == "model" and a.workload == "frame") else "row-major") if a.lpt else "row-major",
+                "trace_output": "exit directions + flags + step counts (25 + 8 B/ray)" if getattr(fr, "_dir_traced", False) else "end states + flags + step counts (49 + 8 B/ray)",
                 "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0 + root-side assembly kernel" if collective else "in frame order"),
                 "collective": ("rccl gather, %d rank(s)%s" % (world, " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if collective else "none (single rank)",
                 "launch": m["launch"],
@@ -524,8 +553,9 @@ def main():
             def tile_cost1(cx, cy):
                 ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
                 return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
+            tile_cost1.visit = a.visit if a.visit != "auto" else "cost"
             for N in [int(v) for v in a.emulate_shards.split(",") if v.strip()]:
-                pix = bdist.rank_pixels(W, H, a.tile, 0, N, tile_cost=tile_cost1 if a.lpt else None)
+                pix = bdist.rank_pixels(W, H, a.tile, 0, N, tile_cost=(m["tcost"] if a.order == "measured" else tile_cost1) if (a.lpt and a.order != "none") else None)
                 frs = DeviceFrame(ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=cam, pixels=pix,
                                   jitter=jit, directions_only=fr.directions_only)
                 frs.set_sky(sky)

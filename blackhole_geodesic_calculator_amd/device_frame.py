@@ -115,6 +115,11 @@ class DeviceFrame:
         if self.d_obj is None:
             self.d_obj = torch.empty(self.n, dtype=torch.int8, device=self.dev)
 
+    def pixel_cost(self):
+        """Attempted steps of the last trace summed over the samples of each pixel ([P], order of `pixels`): the
+        measured cost dist.measured_tile_cost() orders and deals the tiles by."""
+        return self.d_steps.view(self.S, self.P).to(torch.int64).sum(0)
+
     def generate_rays(self):
         self.ctx.raygen_device(self.W, self.H, self.S, self.fov_x, self.fov_y, self.d_jitter.data_ptr(),
                                self.d_k0.data_ptr(), self.P,

@@ -44,7 +44,7 @@ def tile_owner(width: int, height: int, tile: int, world: int, tile_cost=None) -
 def rank_tiles(width: int, height: int, tile: int, rank: int, world: int, tile_cost=None) -> np.ndarray:
     """Tile ids (row-major over the tile grid) owned by `rank`: ascending, or -- with a cost -- by decreasing cost."""
     mine = np.nonzero(tile_owner(width, height, tile, world, tile_cost) == int(rank))[0].astype(np.int64)
-    if tile_cost is not None:
+    if tile_cost is not None and getattr(tile_cost, "visit", "cost") == "cost":
         mine = mine[np.argsort(-_tile_costs(width, height, tile, tile_cost)[mine], kind="stable")]
     return mine
 
@@ -65,6 +65,35 @@ def rank_pixels(width: int, height: int, tile: int, rank: int, world: int, tile_
         xs = np.arange(tx_ * tile, min((tx_ + 1) * tile, W))
         out.append((ys[:, None] * W + xs[None, :]).reshape(-1))
     return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
+def measured_tile_cost(width: int, height: int, tile: int, pixels, cost_per_pixel, group=None):
+    """A tile_cost made of MEASURED work: cost_per_pixel[p] is what pixel pixels[p] cost the last time it was traced
+    (its rays' attempted steps summed over samples -- DeviceFrame.pixel_cost(); the reference renders the same
+    pixels `samples` times per frame and the same view frame after frame, :242-250, so the last pass prices the next).
+    Returns tile_cost(cx, cy) for tile_owner / rank_pixels / FrameGatherer, with the per-tile sums in `.table`
+    (row-major over the tile grid).  With torch.distributed initialised over more than one rank every rank passes ITS
+    pixels and the tables are summed over the ranks (one small all-reduce, outside any timed region), so that all ranks
+    hold the same cost map: the tiles can then be re-dealt by measured cost, which is what balances the shards."""
+    tx, ty = tile_grid(width, height, tile)
+    px = np.asarray(pixels, dtype=np.int64)
+    t = (px // int(width) // tile) * tx + (px % int(width)) // tile
+    table = np.bincount(t, weights=np.asarray(cost_per_pixel, dtype=np.float64), minlength=tx * ty).astype(np.float64)
+    try:
+        import torch
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            tt = torch.from_numpy(table).to(dev)
+            dist.all_reduce(tt, group=group)
+            table = tt.cpu().numpy()
+    except ImportError:
+        pass
+
+    def tile_cost(cx, cy):
+        return table[int(cy // tile) * tx + int(cx // tile)]
+    tile_cost.table = table
+    return tile_cost
 
 
 def max_pixels_per_rank(width: int, height: int, tile: int, world: int, tile_cost=None) -> int:

@@ -125,6 +125,60 @@ dist.destroy_process_group()
 """
 
 
+_WORKER4 = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["BHG_ROOT"])
+from blackhole_geodesic_calculator_amd import dist as bd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H, T = 128, 96, 16
+true_cost = lambda p: 1.0 + 9.0 * np.exp(-((p % W - 70.0) ** 2 + (p // W - 40.0) ** 2) / 900.0)   # work per pixel
+px = bd.rank_pixels(W, H, T, rank, world)                     # first pass: plain dealing, every rank prices ITS pixels
+tc = bd.measured_tile_cost(W, H, T, px, true_cost(px))        # ... and the tables are summed over the ranks
+ids = np.arange(W * H)
+tx = (W + T - 1) // T
+want = np.bincount((ids // W // T) * tx + (ids % W) // T, weights=true_cost(ids))
+assert np.allclose(tc.table, want), (tc.table, want)          # the whole frame's cost map, on every rank
+px2 = bd.rank_pixels(W, H, T, rank, world, tile_cost=tc)      # second pass: dealt and visited by measured cost
+mine = true_cost(px2).sum()
+tot = torch.tensor([mine], dtype=torch.float64)
+dist.all_reduce(tot)
+assert abs(mine / tot.item() - 1.0 / world) < 0.08, mine / tot.item()      # balanced to a tile
+first, last = true_cost(px2[: T * T]).sum(), true_cost(px2[-T * T:]).sum()
+assert first >= last                                           # longest first
+g = bd.FrameGatherer(W, H, T, channels=1, dtype=torch.float64, device="cpu", tile_cost=tc)
+g.submit(0, torch.tensor(px2[:, None], dtype=torch.float64))
+g.drain()
+if rank == 0:
+    assert np.array_equal(g.image().numpy().reshape(-1), ids)
+    print("MEASURED_COST_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_measured_tile_cost_world2_gloo(tmp_path):
+    """A calibration pass prices the tiles (summed over the ranks), the next pass is dealt and ordered by it."""
+    _run_world2(tmp_path, _WORKER4, "MEASURED_COST_OK")
+
+
+def test_measured_tile_cost_and_visit_order_single_process():
+    from blackhole_geodesic_calculator_amd import dist as bd
+    W, H, T = 96, 64, 32
+    px = bd.rank_pixels(W, H, T, 0, 1)
+    cost = (px % 7 + 1).astype(np.float64)
+    tc = bd.measured_tile_cost(W, H, T, px, cost)
+    assert tc.table.shape == (6,) and np.isclose(tc.table.sum(), cost.sum())
+    assert tc(16.0, 16.0) == tc.table[0] and tc(80.0, 48.0) == tc.table[5]
+    order = bd.rank_tiles(W, H, T, 0, 1, tile_cost=tc)
+    assert np.all(np.diff(tc.table[order]) <= 0)               # visited longest-first ...
+    tc.visit = "row"                                           # ... or dealt by cost but visited row-major
+    assert np.array_equal(bd.rank_tiles(W, H, T, 0, 1, tile_cost=tc), np.arange(6))
+    own_cost = bd.tile_owner(W, H, T, 2, tile_cost=tc)
+    tc.visit = "cost"
+    assert np.array_equal(own_cost, bd.tile_owner(W, H, T, 2, tile_cost=tc))    # the dealing does not depend on it
+
+
 def _run_world2(tmp_path, body, token):
     script = tmp_path / "worker.py"
     script.write_text(body)
