@@ -384,12 +384,9 @@ def main():
             tr.append(ctx.last_pass_ms())
         ctx.set_profiling(False)
         torch.cuda.synchronize()
-        if a.rhs == "kerr":
-            # the finalize launch follows the library's last event: price it as part of the call, not of the kernel
-            share = float(np.median([t["trace"] for t in tr])) / call_ms if call_ms == call_ms else float("nan")
-            share = min(share, 1.0)
-        else:
-            share = float(np.median([t["trace"] / (t["prepare"] + t["trace"]) for t in tr]))
+        # (Kerr: prepare | trace | finalize; the Schwarzschild forms report 0 for the passes they do not have.  A SHARE of
+        # the profiled calls, not their absolute times: those calls are synchronous, the GPU idles between them)
+        share = float(np.median([t["trace"] / (t["prepare"] + t["trace"] + t["post"]) for t in tr]))
         k_ms = call_ms * share
         tot = torch.tensor([n, ray_steps], dtype=torch.float64, device="cuda")
         if world > 1:

@@ -443,10 +443,11 @@ class Context:
         _check(load().bhg_set_profiling(self._h, 1 if enable else 0))
 
     def last_pass_ms(self):
-        """{prepare, trace, resolve} milliseconds of the last profiled trace call (waits for it)."""
+        """{prepare, trace, post} milliseconds of the last profiled trace call (waits for it); post = Kerr's finalize
+        pass, 0 otherwise ("resolve" is the slot's round-1 name, kept as an alias)."""
         out = (C.c_float * 3)()
         _check(load().bhg_last_pass_ms(self._h, out))
-        return {"prepare": out[0], "trace": out[1], "resolve": out[2]}
+        return {"prepare": out[0], "trace": out[1], "post": out[2], "resolve": out[2]}
 
     def synchronize(self):
         _check(load().bhg_synchronize(self._h))

@@ -207,7 +207,8 @@ struct bhg_context {
     // optional per-pass timing (bhg_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // around prepare | trace
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around prepare | trace | (Kerr) finalize
+    bool ev_post = false;                                     // the last profiled call had a finalize pass
 };
 
 namespace {
@@ -399,7 +400,7 @@ int bhg_set_profiling(bhg_context *c, int enable)
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     ENTER_DEVICE(c->device);
     if (enable && !c->ev[0])
-        for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     c->profiling = enable != 0;
     c->ev_valid = false;
     return BHG_OK;
@@ -410,9 +411,12 @@ int bhg_last_pass_ms(bhg_context *c, float out_ms[3])
     if (!c || !out_ms) return fail(BHG_E_INVALID, "bad argument");
     if (!c->ev_valid) return fail(BHG_E_INVALID, "no profiled trace call yet (bhg_set_profiling)");
     ENTER_DEVICE(c->device);
-    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    HIP_TRY(hipEventSynchronize(c->ev[c->ev_post ? 3 : 2]));
     for (int i = 0; i < 2; i++) HIP_TRY(hipEventElapsedTime(&out_ms[i], c->ev[i], c->ev[i + 1]));
-    out_ms[2] = 0.0f;  // events are resolved inside the trace kernel: there is no separate pass any more
+    // third slot: the pass AFTER the trace kernel -- Kerr's Boyer-Lindquist -> Cartesian finalize (0 for the
+    // Schwarzschild forms: events are resolved inside the trace kernel, there is no pass after it)
+    out_ms[2] = 0.0f;
+    if (c->ev_post) HIP_TRY(hipEventElapsedTime(&out_ms[2], c->ev[2], c->ev[3]));
     return BHG_OK;
 }
 
@@ -585,9 +589,14 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
     c->ev_valid = c->profiling;
     c->last_launch[3] = 1;
+    c->ev_post = false;
     if (p->rhs_form == BHG_RHS_KERR_BL) {
         HIP_TRY(bhg::launch_kerr_finalize(a, s));
         if (d_end_dir) HIP_TRY(bhg::launch_split_end(d_end, n, nullptr, d_end_dir, s));
+        if (c->profiling) {
+            HIP_TRY(hipEventRecord(c->ev[3], s));
+            c->ev_post = true;
+        }
     }
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;

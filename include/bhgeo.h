@@ -302,8 +302,9 @@ void *bhg_context_stream(bhg_context *ctx);
  * forms do it inside TRACE and report 0 here) and TRACE (the integrate loop including the root search for
  * rays that end on an event; the dominant kernel).  With profiling enabled the library records HIP
  * events around each pass on that stream; bhg_last_pass_ms() waits for the last call's events and
- * returns {prepare, trace, 0} in milliseconds (the third slot was a separate root-search pass up to
- * ABI 1.x builds of round 1; it stays in the signature and reads 0). */
+ * returns {prepare, trace, post} in milliseconds: post is the pass after the trace kernel -- the
+ * Boyer-Lindquist -> Cartesian finalize of BHG_RHS_KERR_BL, 0 for the Schwarzschild forms (up to the
+ * ABI 1.x builds of round 1 the slot was a separate root-search pass). */
 int bhg_set_profiling(bhg_context *ctx, int enable);
 int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
 

@@ -180,6 +180,29 @@ def test_work_order_hint_never_changes_results(ctx):
             assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_profiled_passes_and_pixel_cost(ctx):
+    """bhg_set_profiling / bhg_last_pass_ms: {prepare, trace, post} -- Kerr has all three passes, the Schwarzschild forms
+    only the trace kernel; DeviceFrame.pixel_cost() = the steps of a pixel's rays summed over its samples."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    fr = DeviceFrame(ctx, 64, 48, 3, fov_x=0.6, fov_y=0.6)
+    fr.generate_rays()
+    ctx.set_profiling(True)
+    try:
+        fr.trace(_params(r_s=1.0, lambda_end=50.0))
+        t = ctx.last_pass_ms()
+        assert t["trace"] > 0.0 and t["prepare"] >= 0.0 and t["post"] == 0.0 and t["prepare"] < t["trace"]
+        cost = fr.pixel_cost().cpu().numpy()
+        st = fr.d_steps.cpu().numpy().astype(np.int64)
+        assert cost.shape == (64 * 48,) and np.array_equal(cost, st.reshape(3, -1).sum(0)) and cost.min() > 0
+        fr.trace(_params(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45))
+        t = ctx.last_pass_ms()
+        assert t["trace"] > 0.0 and t["prepare"] > 0.0 and t["post"] > 0.0
+    finally:
+        ctx.set_profiling(False)
+    torch.cuda.synchronize()
+
+
 def test_frame_batch_equals_single_frames(ctx):
     """Several cameras in ONE trace call (per-ray origins) give bit-identical rays, end states and pixels."""
     import torch
