@@ -18,6 +18,13 @@ elif what == "orbit":
 elif what == "exit":
     fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
     p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
+elif what == "framesorted":
+    # the plain frame with its tiles visited longest-first by the shadow-edge model (bench.py --visit cost)
+    from blackhole_geodesic_calculator_amd import dist as bd
+    def tile_cost(cx, cy):
+        return -abs(np.hypot(0.6 * (cx - 512) / 1024, 0.6 * (cy - 512) / 1024) - 2.598 / 30.0)
+    fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6, pixels=bd.rank_pixels(1024, 1024, 32, 0, 1, tile_cost=tile_cost))
+    p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
 else:
     fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
     p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
