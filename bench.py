@@ -44,6 +44,9 @@ BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accept
 BYTES_PER_RAY_DIR = 24 + 24 + 1 + 4 + 4  # direction-only traces (sky frames): the direction half of the end state
 
 
+EV_EVERY = 4   # HIP event pairs around the trace call of every 4th timed step (see measure.step)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,20 +205,6 @@ def main():
         ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
                                       stream=torch.cuda.current_stream().cuda_stream)
 
-    def twin_of(fr_, ctx2):
-        """A second DeviceFrame over the SAME rays (shared d_k0) with result buffers of its own, on another library
-        context (its own work counters): consecutive frames of an animation are independent, so frame i + 1 can be
-        traced on a second stream while frame i's last waves drain."""
-        n_ = fr_.n
-        buf = (fr_.d_k0, None if fr_.directions_only else torch.empty((n_, 6), dtype=torch.float64, device="cuda"),
-               torch.empty(n_, dtype=torch.uint8, device="cuda"), torch.empty(n_, dtype=torch.int32, device="cuda"),
-               torch.empty(n_, dtype=torch.int32, device="cuda"))
-        f2 = DeviceFrame(ctx2, fr_.W, fr_.H, fr_.S, fov_x=fr_.fov_x, fov_y=fr_.fov_y, origin=fr_.origin,
-                         pixels=None if fr_.d_pixels is None else fr_.d_pixels.cpu().numpy(), jitter=np.zeros(2), buffers=buf,
-                         directions_only=fr_.directions_only)
-        f2.d_sky, f2.sky_wh = fr_.d_sky, fr_.sky_wh
-        return f2
-
     def measure(nx, ny, ramp, overlap=False):
         """One timed region over a frame of (width * nx) x (height * ny) pixels sharded over the ranks.
         Returns the figures of this rank (dt already the maximum over ranks).  overlap (frame workload): two frames in
@@ -294,9 +283,12 @@ def main():
         lanes = None
         if overlap and a.workload == "frame":
             ctx2 = _ffi.Context(local_rank)
-            lanes = [(fr, torch.cuda.Stream()), (twin_of(fr, ctx2), torch.cuda.Stream())]
+            lanes = [(fr, torch.cuda.Stream()), (twin_of(fr, ctx2), torch.cuda.Stream(priority=-1))]   # (see time_frame)
 
         def step(i, timed):
+            # HIP events around the trace call of every EV_EVERY-th timed step: an event pair costs 7-9 us of stream
+            # time (0.6 % of a config-2 step, 4 % of a 1/8 shard's), so not around every step
+            timed = timed and i % EV_EVERY == 0
             if lanes is not None:
                 f, st = lanes[i & 1]
                 with torch.cuda.stream(st):
@@ -372,7 +364,8 @@ def main():
 
         ray_steps = sum(int(f.d_steps.to(torch.int64).sum().item()) for f in frames)
         # per step: the trace calls of all its frames (HIP events on the stream the library launches on)
-        call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(a.steps, 1) if kernel_ms else float("nan")
+        n_sampled = len(range(0, a.steps, EV_EVERY))
+        call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(n_sampled, 1) if kernel_ms else float("nan")
         # the dominant kernel alone: one launch per call finishes every ray (events are located and resumed rays
         # carry on inside trace_*_kernel); Kerr adds a prepare and a finalize launch.  A few extra profiled calls
         # after the timed region (HIP events recorded by the library around prepare | trace on this same stream)
@@ -395,41 +388,6 @@ def main():
             ctx2.close()
         return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                     steps_all=float(tot[1].item()), launch=ctx.last_launch(), fr=fr, tcost=tcost)
-
-    def time_frame(fr_, steps, warmup, overlap=False):
-        """K timed steps of trace + shade (float RGBA in frame order) of ONE DeviceFrame on this GPU, no collective:
-        (ms per step by the wall clock around a synchronised region, trace-call ms by HIP events, attempted ray-steps).
-        overlap: two frames in flight, alternating between two streams / library contexts (the call times overlap then)."""
-        ctx2 = _ffi.Context(local_rank) if overlap else None
-        lanes_ = [(fr_, ts)] if not overlap else [(fr_, torch.cuda.Stream()), (twin_of(fr_, ctx2), torch.cuda.Stream())]
-        imgs = [torch.zeros((fr_.W * fr_.H, 4), dtype=torch.float32, device="cuda") for _ in lanes_]
-        evs = []
-
-        def run(k, timed):
-            for i in range(k):
-                f, st = lanes_[i % len(lanes_)]
-                with torch.cuda.stream(st):
-                    if timed:
-                        e0 = torch.cuda.Event(enable_timing=True)
-                        e1 = torch.cuda.Event(enable_timing=True)
-                        e0.record(st)
-                        f.trace(params)
-                        e1.record(st)
-                        evs.append((e0, e1))
-                    else:
-                        f.trace(params)
-                    f.shade_f32(imgs[i % len(lanes_)], fr_.d_pixels)
-        torch.cuda.synchronize()
-        run(warmup, False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(steps, True)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out_ = dt / steps * 1e3, float(np.mean([x.elapsed_time(y) for x, y in evs])), int(fr_.d_steps.to(torch.int64).sum().item())
-        if ctx2 is not None:
-            ctx2.close()
-        return out_
 
     nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
     m = measure(nx, ny, a.ramp_seconds)
@@ -531,7 +489,7 @@ def main():
                               pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=False)
             frf.d_k0 = fr.d_k0
             frf.set_sky(sky)
-            ms_f, call_f, steps_f = time_frame(frf, a.steps, a.warmup)
+            ms_f, call_f, steps_f = time_frame(frf, params, a.steps, a.warmup, device=local_rank)
             out["full_records"] = {"value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
                                    "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                    "algorithmic_bytes_per_ray": BYTES_PER_RAY,
@@ -543,8 +501,8 @@ def main():
             # without the collective; efficiency = T_1 / (N T_N).  What it leaves out: the gather (16 B/pixel, ~0.1 ms per
             # peer, overlapped) and the root's assembly kernel.
             jit = python_random_stream(42.0, 2 * S * W * H)
-            t1_ms, t1_call, _ = time_frame(fr, a.steps, a.warmup)
-            t1o_ms, _, _ = time_frame(fr, a.steps, a.warmup, overlap=True)
+            t1_ms, t1_call, _ = time_frame(fr, params, a.steps, a.warmup, device=local_rank)
+            t1o_ms, _, _ = time_frame(fr, params, a.steps, a.warmup, overlap=True, device=local_rank)
             pred = {"T1_ms_per_step": t1_ms, "T1_trace_call_ms": t1_call, "T1_ms_per_step_two_in_flight": t1o_ms, "shards": {}}
 
             def tile_cost1(cx, cy):
@@ -557,8 +515,8 @@ def main():
                                   jitter=jit, directions_only=fr.directions_only)
                 frs.set_sky(sky)
                 frs.generate_rays()
-                ms_n, call_n, steps_n = time_frame(frs, a.steps, a.warmup)
-                mso_n, _, _ = time_frame(frs, a.steps, a.warmup, overlap=True)
+                ms_n, call_n, steps_n = time_frame(frs, params, a.steps, a.warmup, device=local_rank)
+                mso_n, _, _ = time_frame(frs, params, a.steps, a.warmup, overlap=True, device=local_rank)
                 pred["shards"][str(N)] = {"rays": frs.n, "ms_per_step": ms_n, "trace_call_ms": call_n,
                                           "attempted_steps_per_ray": steps_n / frs.n,
                                           "efficiency": t1_ms / (N * ms_n), "efficiency_trace_call": t1_call / (N * call_n),
@@ -593,6 +551,64 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def twin_of(fr_, ctx2):
+    """A second DeviceFrame over the SAME rays (shared d_k0) with result buffers of its own, on another library
+    context (its own work counters): consecutive frames of an animation are independent, so frame i + 1 can be
+    traced on a second stream while frame i's last waves drain."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    n_ = fr_.n
+    buf = (fr_.d_k0, None if fr_.directions_only else torch.empty((n_, 6), dtype=torch.float64, device="cuda"),
+           torch.empty(n_, dtype=torch.uint8, device="cuda"), torch.empty(n_, dtype=torch.int32, device="cuda"),
+           torch.empty(n_, dtype=torch.int32, device="cuda"))
+    f2 = DeviceFrame(ctx2, fr_.W, fr_.H, fr_.S, fov_x=fr_.fov_x, fov_y=fr_.fov_y, origin=fr_.origin,
+                     pixels=None if fr_.d_pixels is None else fr_.d_pixels.cpu().numpy(), jitter=np.zeros(2), buffers=buf,
+                     directions_only=fr_.directions_only)
+    f2.d_sky, f2.sky_wh = fr_.d_sky, fr_.sky_wh
+    return f2
+
+
+def time_frame(fr_, params, steps, warmup, overlap=False, device=0):
+    """K timed steps of trace + shade (float RGBA in frame order) of ONE DeviceFrame on this GPU, no collective:
+    (ms per step by the wall clock around a synchronised region, trace-call ms by HIP events, attempted ray-steps).
+    overlap: two frames in flight, alternating between two streams / library contexts (the call times overlap then)."""
+    import torch
+    from blackhole_geodesic_calculator_amd import _ffi
+    ctx2 = _ffi.Context(device) if overlap else None
+    # (two streams of the SAME priority share one hardware queue on this ROCm build -- rocprofv3 shows one queue id and
+    # strictly serial kernels, and the pair measures exactly like one stream; a stream of another priority gets a queue
+    # of its own, and only then do the second frame's first waves start while the first frame's last ones drain)
+    lanes_ = [(fr_, torch.cuda.current_stream())] if not overlap else [(fr_, torch.cuda.Stream()), (twin_of(fr_, ctx2), torch.cuda.Stream(priority=-1))]
+    imgs = [torch.zeros((fr_.W * fr_.H, 4), dtype=torch.float32, device="cuda") for _ in lanes_]
+    evs = []
+
+    def run(k, timed):
+        for i in range(k):
+            f, st = lanes_[i % len(lanes_)]
+            with torch.cuda.stream(st):
+                if timed and i % EV_EVERY == 0:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    f.trace(params)
+                    e1.record(st)
+                    evs.append((e0, e1))
+                else:
+                    f.trace(params)
+                f.shade_f32(imgs[i % len(lanes_)], fr_.d_pixels)
+    torch.cuda.synchronize()
+    run(warmup, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps, True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out_ = dt / steps * 1e3, float(np.mean([x.elapsed_time(y) for x, y in evs])), int(fr_.d_steps.to(torch.int64).sum().item())
+    if ctx2 is not None:
+        ctx2.close()
+    return out_
+
+
 def pipelined_figure(ctx, fr, params, a, device):
     """Consecutive frames of an animation are independent: two frames in flight on two streams (two library
     contexts, each with its own work counters and workspace) let the next frame's waves start while the previous
@@ -610,7 +626,7 @@ def pipelined_figure(ctx, fr, params, a, device):
                       directions_only=fr.directions_only)
     fr2.d_sky, fr2.sky_wh = fr.d_sky, fr.sky_wh
     frames = (fr, fr2)
-    streams = (torch.cuda.Stream(), torch.cuda.Stream())
+    streams = (torch.cuda.Stream(), torch.cuda.Stream(priority=-1))   # (different priorities = different hardware queues, see time_frame)
     imgs = [torch.zeros((fr.W * fr.H, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
 
     def run(k):

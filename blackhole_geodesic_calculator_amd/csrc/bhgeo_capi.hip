@@ -182,7 +182,12 @@ struct DeviceGuard {
 struct bhg_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    unsigned long long *counter = nullptr;  // work counter (device)
+    // work counters (device): two sets of 8 slice counters, one 256-byte line each.  Consecutive launches alternate
+    // between the sets; a launch zeroes the set the next one will use (trace kernels, block 0), so no memset launch
+    // per call.  counters_clean = both sets are known to be in that state (false after a failed enqueue)
+    unsigned long long *counter = nullptr;
+    int counter_set = 0;
+    bool counters_clean = false;
     int num_cus = 0;
     char name[256] = {0};
     // device buffers of the host-buffer entry points, grown on demand
@@ -343,7 +348,7 @@ int bhg_create(int device, bhg_context **out)
         delete c;
         return fail_hip(e, "hipStreamCreate");
     }
-    e = hipMalloc((void **)&c->counter, 8 * 256);
+    e = hipMalloc((void **)&c->counter, 2 * 8 * 256);
     if (e != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
@@ -504,7 +509,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.flags = d_flags ? d_flags : w_flags;
     a.n_steps = d_n_steps ? d_n_steps : w_steps;
     a.n_accepted = d_n_accepted ? d_n_accepted : w_acc;
-    a.counter = c->counter;
+    a.counter = c->counter + (size_t)c->counter_set * (8 * 256 / sizeof(unsigned long long));
+    a.counter_next = c->counter + (size_t)(c->counter_set ^ 1) * (8 * 256 / sizeof(unsigned long long));
     a.n = n;
     if (!d_x0) {
         a.x0s[0] = x0_shared[0];
@@ -585,8 +591,11 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
 #endif
     // ONE persistent launch finishes every ray: events are resolved and rays resumed inside the trace kernel, so
     // the call only enqueues (Kerr: prepare, trace, finalize) and returns
-    HIP_TRY(hipMemsetAsync(c->counter, 0, 8 * 256, s));  // 8 slice counters, one 256-byte line each
+    if (!c->counters_clean) HIP_TRY(hipMemsetAsync(c->counter, 0, 2 * 8 * 256, s));   // first call, or after a failed enqueue
+    c->counters_clean = false;
     HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
+    c->counter_set ^= 1;      // (the launch is in the stream: the next call of this context counts on the set it zeroes)
+    c->counters_clean = true;
     c->ev_valid = c->profiling;
     c->last_launch[3] = 1;
     c->ev_post = false;
@@ -1179,7 +1188,8 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.flags = (uint8_t *)(o + off_flags);
     a.n_steps = (uint32_t *)(o + off_steps);
     a.n_accepted = (uint32_t *)(o + off_acc);
-    a.counter = c->counter;
+    a.counter = c->counter;        // (the trajectory kernel hands out no batches)
+    a.counter_next = nullptr;
     a.n = n;
     if (!d_x0) {
         a.x0s[0] = x0[0];

@@ -52,7 +52,8 @@ struct TraceArgs {
     int32_t from_records;        // rays start from the records the prepare pass wrote (Kerr)
     const double *k0;            // [n][3]
     const double *x0;            // [n][3] or nullptr -> x0s
-    unsigned long long *counter; // 8 slice counters (256 B apart), zeroed before launch
+    unsigned long long *counter; // 8 slice counters (256 B apart), zero at launch
+    unsigned long long *counter_next; // the set the NEXT launch of this context will use: this launch zeroes it
     uint64_t n;                  // rays in the call
     double x0s[3];
     int32_t inline_prepare;      // set by the launcher: no prepare launch, the trace waves work the start records out (Schwarzschild forms)

@@ -2105,6 +2105,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
 #endif
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
+    // Work counters come in two sets used by alternate launches of a context: this launch counts on A.counter (zero
+    // at launch) and zeroes the other set for the launch after it -- a 5-us memset launch less per call.
+    if (blockIdx.x == 0 && lane < (uint32_t)NSLICE && A.counter_next) A.counter_next[lane * SLICE_STRIDE] = 0ull;
 
     for (;;) {
         if (__ballot(!L.active)) {
@@ -2296,6 +2299,9 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
     wave_lds_sync();
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
+    // Work counters come in two sets used by alternate launches of a context: this launch counts on A.counter (zero
+    // at launch) and zeroes the other set for the launch after it -- a 5-us memset launch less per call.
+    if (blockIdx.x == 0 && lane < (uint32_t)NSLICE && A.counter_next) A.counter_next[lane * SLICE_STRIDE] = 0ull;
 
     for (;;) {
         if (__ballot(!L.active) && service<RHS, false, EVT>(A, Q, W, L, lane)) break;
