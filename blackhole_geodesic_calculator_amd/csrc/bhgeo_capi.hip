@@ -551,7 +551,10 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.n_spheres = n_spheres;
     for (int j = 0; j < n_spheres; j++)
         for (int q = 0; q < 4; q++) a.spheres[j][q] = spheres[4 * j + q];
-    const int evt = n_spheres > 0 ? 7 : ((has_exit ? 1 : 0) | (p->disk_r_out > 0.0 ? 2 : 0));
+    // kernel variant: bit 0 exit sphere, bit 1 disk, bit 2 objects.  With objects: 5 = exit sphere and no disk (the
+    // orbiting-sphere frames), otherwise 7, which tests for the exit sphere and the disk at run time
+    const int evt = n_spheres > 0 ? ((has_exit && !(p->disk_r_out > 0.0)) ? 5 : 7)
+                                  : ((has_exit ? 1 : 0) | (p->disk_r_out > 0.0 ? 2 : 0));
 
     // resident waves per CU of the trace kernel variant: asked of the runtime once per variant and context
     const int vkey = ((p->method & 1) * 3 + (p->rhs_form % 3)) * 8 + evt;

@@ -2794,6 +2794,7 @@ static hipError_t launch_rhs(const TraceArgs &a, int method, int evt, int grid, 
     case 1: return launch_variant<RHS, 1>(a, method, grid, s, ev);
     case 2: return launch_variant<RHS, 2>(a, method, grid, s, ev);
     case 3: return launch_variant<RHS, 3>(a, method, grid, s, ev);
+    case 5: return launch_variant<RHS, 5>(a, method, grid, s, ev);   // exit sphere + objects, no disk (config 4)
     default: return launch_variant<RHS, 7>(a, method, grid, s, ev);
     }
 }
@@ -2806,6 +2807,7 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
     case 1: return occupancy_variant<RHS, 1>(method, blocks_per_cu);
     case 2: return occupancy_variant<RHS, 2>(method, blocks_per_cu);
     case 3: return occupancy_variant<RHS, 3>(method, blocks_per_cu);
+    case 5: return occupancy_variant<RHS, 5>(method, blocks_per_cu);
     default: return occupancy_variant<RHS, 7>(method, blocks_per_cu);
     }
 }
