@@ -778,14 +778,28 @@ __device__ __forceinline__ bool disk_crossing_may_hit_sharp(const TraceArgs &A, 
     return !((lo > 0.0 && R2 < lo * lo) || R2 > hi * hi);       // NaN anywhere: may hit
 }
 
+// The step loop's version of that test: a SUPERSET of sphere_candidate() in straight-line code (the event drain applies
+// the exact test to whatever is parked, and a step it then finds empty carries on -- so a false positive costs a little
+// time and a false negative would cost a hit).  One set of differences for both ends (d1 = d0 - 2 b + c instead of a
+// second distance), no divergent branches, and a relative slack of 1e-9 on the two comparisons that rounding could
+// turn the other way.  23 instead of 30 instructions per sphere and step, in every step of an object frame.
+__device__ __forceinline__ bool sphere_maybe(const double sp[4], const double x0[3], const double x1[3])
+{
+    const double rho2 = sp[3] * sp[3], rho2s = rho2 * (1.0 + 1e-9);
+    const double a0[3] = {x0[0] - sp[0], x0[1] - sp[1], x0[2] - sp[2]};
+    const double ch[3] = {x1[0] - x0[0], x1[1] - x0[1], x1[2] - x0[2]};
+    const double d0 = __builtin_fma(a0[2], a0[2], __builtin_fma(a0[1], a0[1], a0[0] * a0[0]));
+    const double cc = __builtin_fma(ch[2], ch[2], __builtin_fma(ch[1], ch[1], ch[0] * ch[0]));
+    const double bb = -__builtin_fma(a0[2], ch[2], __builtin_fma(a0[1], ch[1], a0[0] * ch[0]));
+    const double d1 = __builtin_fma(-2.0, bb, d0) + cc;
+    const bool through = bb > 0.0 && bb < cc && (d0 - rho2s) * cc < bb * bb;
+    return d0 > rho2 && (d1 <= rho2s || through);
+}
+
 __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const double x0[3], const double x1[3])
 {
     bool any = false;
-    for (int j = 0; j < A.n_spheres; j++) {
-        double bb, cc;
-        bool inside;
-        any |= sphere_candidate(A.spheres[j], x0, x1, bb, cc, inside);
-    }
+    for (int j = 0; j < A.n_spheres; j++) any |= sphere_maybe(A.spheres[j], x0, x1);
     return any;
 }
 // ray records in A.ws are A.ws_stride doubles apart: {a(3), w3, w4, w5} (+ {E, L} for Kerr, stride 8)  // template bitmask: which optional events are compiled in
