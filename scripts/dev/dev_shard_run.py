@@ -50,4 +50,4 @@ if len(sys.argv) > 3 and "bench" in sys.argv[3]:
     sys.exit(0)
 run(300); torch.cuda.synchronize()
 t = time.perf_counter(); run(K); t_host = (time.perf_counter() - t) / K; torch.cuda.synchronize(); dt = (time.perf_counter() - t) / K
-print("shard 1/%d: %d rays, %.4f ms per frame, host enqueue %.4f ms per frame (%s)" % (N, frs[0].n, dt * 1e3, t_host * 1e3, ("two in flight" if two else "sequential") + (", event pair per trace" if with_events else "")))
+print("shard 1/%d: %d rays, %.4f ms per frame, host enqueue %.4f ms per frame (%s)" % (N, frs[0].n, dt * 1e3, t_host * 1e3, (("two in flight, second stream at another priority" if "prio" in sys.argv[3] else "two in flight, two plain streams") if two else "sequential") + (", event pair per trace" if with_events else "")))

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for N in 1 2 4 8; do
   rm -rf /tmp/sh_$N
   (cd $R && timeout 300 python3 scripts/dev/dev_shard_run.py $N 200 | tail -1) > $O/prof_shard${N}_timing.txt
-  (cd $R && timeout 300 python3 scripts/dev/dev_shard_run.py $N 200 two | tail -1) >> $O/prof_shard${N}_timing.txt
+  (cd $R && timeout 300 python3 scripts/dev/dev_shard_run.py $N 200 twoprio | tail -1) >> $O/prof_shard${N}_timing.txt
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sh_$N -- python3 $R/scripts/dev/dev_shard_run.py $N 200 > $O/prof_shard${N}_rocprof.log 2>&1
   for f in $(find /tmp/sh_$N -name "*kernel_stats.csv"); do cp $f $O/prof_shard${N}_kernel_stats.csv; done
   cat $O/prof_shard${N}_timing.txt

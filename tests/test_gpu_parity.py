@@ -217,6 +217,37 @@ def test_empty_input(ctx):
     assert end.shape == (0, 6) and flags.shape == (0,) and steps.shape == (0,)
 
 
+def test_consecutive_calls_of_every_shape_on_one_context(oracle):
+    """The work counters come in two sets used by alternate launches, each launch zeroing the set of the next: a context
+    must give the same answers whatever it ran before -- sizes from one ray to many batches, empty calls in between,
+    event variants, both steppers, Kerr, and the host-buffer chunk pipeline (several launches per call)."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    c = _ffi.Context(0)
+    try:
+        cases = []
+        for i, n in enumerate((1, 64, 65, 4097, 20000)):
+            k = frame_rays(n, seed=100 + i)
+            cases.append((k, _params(r_s=1.0, lambda_end=50.0)))
+            cases.append((k, _params(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)))
+            cases.append((k, _params(r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.1)))
+            cases.append((k, _params(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.3)))
+        first = [c.trace(k, CAM, p) for k, p in cases]
+        rng = np.random.default_rng(5)
+        for it in range(3):
+            for j in rng.permutation(len(cases)):
+                if j % 5 == 0:
+                    c.trace(np.zeros((0, 3)), CAM, cases[j][1])       # an empty call launches nothing, flips nothing
+                got = c.trace(cases[j][0], CAM, cases[j][1])
+                for a, b in zip(first[j], got):
+                    assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True), (it, j)
+        k, p = cases[1]
+        end, flags, steps, _ = first[1]
+        o = oracle.trace(k, CAM, r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)
+        assert np.array_equal(flags, o["flags"]) and np.array_equal(steps, o["n_attempted"])
+    finally:
+        c.close()
+
+
 def test_start_inside_mixed_with_normal_rays(ctx, oracle):
     n = 500
     k = frame_rays(n, seed=23)
