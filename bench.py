@@ -489,7 +489,7 @@ def main():
                               pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=False)
             frf.d_k0 = fr.d_k0
             frf.set_sky(sky)
-            ms_f, call_f, steps_f = time_frame(frf, params, a.steps, a.warmup, device=local_rank)
+            ms_f, call_f, steps_f = time_frame(frf, params, a.steps, a.warmup, device=local_rank, ramp=a.ramp_seconds)
             out["full_records"] = {"value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
                                    "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                                    "algorithmic_bytes_per_ray": BYTES_PER_RAY,
@@ -501,8 +501,8 @@ def main():
             # without the collective; efficiency = T_1 / (N T_N).  What it leaves out: the gather (16 B/pixel, ~0.1 ms per
             # peer, overlapped) and the root's assembly kernel.
             jit = python_random_stream(42.0, 2 * S * W * H)
-            t1_ms, t1_call, _ = time_frame(fr, params, a.steps, a.warmup, device=local_rank)
-            t1o_ms, _, _ = time_frame(fr, params, a.steps, a.warmup, overlap=True, device=local_rank)
+            t1_ms, t1_call, _ = time_frame(fr, params, a.steps, a.warmup, device=local_rank, ramp=a.ramp_seconds)
+            t1o_ms, _, _ = time_frame(fr, params, a.steps, a.warmup, overlap=True, device=local_rank, ramp=a.ramp_seconds)
             pred = {"T1_ms_per_step": t1_ms, "T1_trace_call_ms": t1_call, "T1_ms_per_step_two_in_flight": t1o_ms, "shards": {}}
 
             def tile_cost1(cx, cy):
@@ -515,8 +515,8 @@ def main():
                                   jitter=jit, directions_only=fr.directions_only)
                 frs.set_sky(sky)
                 frs.generate_rays()
-                ms_n, call_n, steps_n = time_frame(frs, params, a.steps, a.warmup, device=local_rank)
-                mso_n, _, _ = time_frame(frs, params, a.steps, a.warmup, overlap=True, device=local_rank)
+                ms_n, call_n, steps_n = time_frame(frs, params, a.steps, a.warmup, device=local_rank, ramp=a.ramp_seconds)
+                mso_n, _, _ = time_frame(frs, params, a.steps, a.warmup, overlap=True, device=local_rank, ramp=a.ramp_seconds)
                 pred["shards"][str(N)] = {"rays": frs.n, "ms_per_step": ms_n, "trace_call_ms": call_n,
                                           "attempted_steps_per_ray": steps_n / frs.n,
                                           "efficiency": t1_ms / (N * ms_n), "efficiency_trace_call": t1_call / (N * call_n),
@@ -568,7 +568,18 @@ def twin_of(fr_, ctx2):
     return f2
 
 
-def time_frame(fr_, params, steps, warmup, overlap=False, device=0):
+def ramp_clocks(run, seconds):
+    """Untimed frames until `seconds` of wall time have passed: the GPU's clocks take tens of milliseconds of load to
+    settle, and every secondary figure of the line starts after host-side work during which the GPU sat idle (a
+    K = 20 / W = 3 run read 5-10 % low without this)."""
+    import torch
+    t = time.perf_counter()
+    while seconds > 0 and time.perf_counter() - t < seconds:
+        run(4)
+        torch.cuda.synchronize()
+
+
+def time_frame(fr_, params, steps, warmup, overlap=False, device=0, ramp=0.25):
     """K timed steps of trace + shade (float RGBA in frame order) of ONE DeviceFrame on this GPU, no collective:
     (ms per step by the wall clock around a synchronised region, trace-call ms by HIP events, attempted ray-steps).
     overlap: two frames in flight, alternating between two streams / library contexts (the call times overlap then)."""
@@ -597,6 +608,7 @@ def time_frame(fr_, params, steps, warmup, overlap=False, device=0):
                     f.trace(params)
                 f.shade_f32(imgs[i % len(lanes_)], fr_.d_pixels)
     torch.cuda.synchronize()
+    ramp_clocks(lambda k: run(k, False), ramp)
     run(warmup, False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -635,6 +647,7 @@ def pipelined_figure(ctx, fr, params, a, device):
                 frames[i & 1].trace(params)
                 frames[i & 1].shade_f32(imgs[i & 1], fr.d_pixels)
     torch.cuda.synchronize()
+    ramp_clocks(run, a.ramp_seconds)
     run(a.warmup)
     torch.cuda.synchronize()
     t = time.perf_counter()
