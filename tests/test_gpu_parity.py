@@ -88,8 +88,15 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, **kw):
             tol = tol + np.where(hit, 1e-11 / np.maximum(steep, 1e-12), 0.0)
         over = d[fin] > tol[fin]
         # how much work the sensitivity-scaled part of the bound does: rays further than the absolute floor from the oracle
-        LAST_COMPARE.update(rays=int(fin.sum()), beyond_floor=int((d[fin] > TOL_END).sum()), beyond_bound=int(over.sum()),
-                            worst=float(d[fin].max(initial=0.0)))
+        # (rays cut off by the step budget end at a lambda that is the SUM of their step sizes: with tolerances near
+        # rounding level the error estimate -- a difference of nearly equal stage values -- is noise at 1e-8 relative,
+        # the step sizes follow it, and the state at the cut-off moves by k * d(lambda); rays that run to lambda_end or to
+        # an event end at a pinned place.  The record keeps the two apart.)
+        cut = (o["flags"] & np.uint8(16 | 32)) != 0
+        pinned = fin & ~cut
+        LAST_COMPARE.update(rays=int(fin.sum()), beyond_floor=int((d[pinned] > TOL_END).sum()), beyond_bound=int(over.sum()),
+                            worst=float(d[pinned].max(initial=0.0)), cut_off=int((fin & cut).sum()),
+                            worst_cut_off=float(d[fin & cut].max(initial=0.0)))
         # `outliers`: S_i is an estimate from three perturbations, not a bound; the fuzz test lets a
         # fraction of rays exceed it, but never by more than a factor 1e3
         assert over.mean() <= outliers and np.all(d[fin] <= 1e3 * tol[fin]), \
@@ -439,7 +446,9 @@ def test_randomised_configurations(ctx, oracle, seed, record_property):
         record_property(key, val)
     print(f"fuzz draw {seed}: {LAST_COMPARE}")
     # (measured, round 3, 16 draws: 14 draws with no such ray, one with 1 of 564, one -- rtol 1e-7 next to the photon
-    # sphere -- with 53 of 919, worst 1.0e-8; none beyond the scaled bound)
+    # sphere -- with 53 of 919, worst 1.0e-8; none beyond the scaled bound.  300 draws, BHG_FUZZ=300: the same picture
+    # for rays that end at lambda_end or on an event; rays cut off by max_steps differ by up to 5.5e-6 -- their end
+    # lambda is not pinned, see _compare -- and are recorded apart.)
     assert LAST_COMPARE["beyond_floor"] <= max(3, 0.10 * LAST_COMPARE["rays"]) and LAST_COMPARE["worst"] < 1e-6, LAST_COMPARE
 
 
