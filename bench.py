@@ -525,7 +525,8 @@ def main():
             del jit
             pred["what"] = ("rank 0's shard of a world-N dealing of the fixed %dx%d x%d frame, trace + shade on this one GPU, no "
                             "collective; efficiency = T1 / (N T_N); two_in_flight: consecutive frames alternate between two "
-                            "streams / library contexts, so a frame's first waves start while the previous frame's last ones drain "
+                            "streams / library contexts -- the second stream at another priority, i.e. on a hardware queue of its "
+                            "own -- so a frame's first waves start while the previous frame's last ones drain "
                             "(both T1 and T_N measured that way)" % (W, H, S))
             out["strong_predicted"] = pred
         if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
@@ -657,7 +658,8 @@ def pipelined_figure(ctx, fr, params, a, device):
     same = bool(torch.equal(imgs[0], imgs[1]))
     ctx2.close()
     return {"value": n / (dt / a.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": dt / a.steps * 1e3, "frames_identical": same,
-            "what": f"{a.steps} frames alternating between two streams / library contexts (trace + shade each), no synchronisation in between"}
+            "what": f"{a.steps} frames alternating between two streams of different priority (two hardware queues) / two library "
+                    f"contexts (trace + shade each), no synchronisation in between"}
 
 
 def host_buffer_figures(ctx, fr, cam, params, n):
