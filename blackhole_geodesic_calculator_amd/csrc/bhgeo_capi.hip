@@ -603,8 +603,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     c->last_launch[3] = 1;
     c->ev_post = false;
     if (p->rhs_form == BHG_RHS_KERR_BL) {
-        HIP_TRY(bhg::launch_kerr_finalize(a, s));
-        if (d_end_dir) HIP_TRY(bhg::launch_split_end(d_end, n, nullptr, d_end_dir, s));
+        // (direction-only calls: the finalize pass writes the Cartesian exit directions straight into d_end_dir)
+        HIP_TRY(bhg::launch_kerr_finalize(a, d_end_dir, s));
         if (c->profiling) {
             HIP_TRY(hipEventRecord(c->ev[3], s));
             c->ev_post = true;

@@ -111,7 +111,7 @@ hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t 
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
 // Kerr: after the last pass of a call, Boyer-Lindquist end states -> Cartesian
-hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s);
+hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t s);
 // the Kerr instantiations live in their own translation unit (geodesic_kernels_kerr.hip: same source, built with
 // machine LICM on, which suits the big Kerr kernels; the Schwarzschild unit is built with it off)
 hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev);

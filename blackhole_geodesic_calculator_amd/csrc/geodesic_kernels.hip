@@ -2504,21 +2504,41 @@ hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, doubl
 
 // Kerr only: the passes above work in Boyer-Lindquist coordinates; turn every final state back into
 // the Cartesian frame the boundary speaks (rays that started inside were stored Cartesian already).
-__global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A)
+// dir_out (direction-only calls: a sky frame reads nothing else): the Cartesian exit directions go there, 24 bytes per
+// ray, and the records in A.end -- a workspace of the library then -- stay as they are: one pass of 72 bytes per ray
+// instead of this pass in place (96) plus a pass that splits the directions off (72).
+__global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A, double *dir_out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
-    if (A.flags[i] & BHG_FLAG_START_INSIDE_) return;
     double *e = A.end + i * 6;
+    if (A.flags[i] & BHG_FLAG_START_INSIDE_) {
+        if (dir_out) {
+            dir_out[i * 3 + 0] = e[3];
+            dir_out[i * 3 + 1] = e[4];
+            dir_out[i * 3 + 2] = e[5];
+        }
+        return;
+    }
     const double r = e[0], th = e[1], ph = e[2], u0 = e[3], u1 = e[4], u2 = e[5], a = A.spin;
     const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
-    e[0] = R * st * cp;
-    e[1] = R * st * sp;
-    e[2] = r * ct;
-    e[3] = (r / R * st * cp) * u0 + (R * ct * cp) * u1 + (-R * st * sp) * u2;
-    e[4] = (r / R * st * sp) * u0 + (R * ct * sp) * u1 + (R * st * cp) * u2;
-    e[5] = ct * u0 + (-r * st) * u1 + 0.0 * u2;
-    const bool bad = !(isfinite(e[0]) && isfinite(e[1]) && isfinite(e[2]) && isfinite(e[3]) && isfinite(e[4]) && isfinite(e[5]));
+    const double c0 = R * st * cp, c1 = R * st * sp, c2 = r * ct;
+    const double c3 = (r / R * st * cp) * u0 + (R * ct * cp) * u1 + (-R * st * sp) * u2;
+    const double c4 = (r / R * st * sp) * u0 + (R * ct * sp) * u1 + (R * st * cp) * u2;
+    const double c5 = ct * u0 + (-r * st) * u1 + 0.0 * u2;
+    if (dir_out) {
+        dir_out[i * 3 + 0] = c3;
+        dir_out[i * 3 + 1] = c4;
+        dir_out[i * 3 + 2] = c5;
+    } else {
+        e[0] = c0;
+        e[1] = c1;
+        e[2] = c2;
+        e[3] = c3;
+        e[4] = c4;
+        e[5] = c5;
+    }
+    const bool bad = !(isfinite(c0) && isfinite(c1) && isfinite(c2) && isfinite(c3) && isfinite(c4) && isfinite(c5));
     if (bad) A.flags[i] |= (uint8_t)BHG_FLAG_NAN_;
 }
 
@@ -2694,7 +2714,7 @@ hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
     hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
     hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
-    hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a, (double *)nullptr);
     return hipGetLastError();
 }
 #else
@@ -2764,10 +2784,10 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
 
 #ifdef BHG_TU_KERR
 // Kerr: once ALL passes of a call are done, turn the Boyer-Lindquist end states into Cartesian ones
-hipError_t launch_kerr_finalize(const TraceArgs &a, hipStream_t s)
+hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t s)
 {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, dir_out);
     return hipGetLastError();
 }
 #endif
