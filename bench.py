@@ -453,7 +453,8 @@ def main():
                                                ("dealt by the shadow-edge model, visited " + ("row-major" if tile_cost_visit == "row" else "longest first")) if (a.order == "model" and a.workload == "frame") else "row-major") if a.lpt else "row-major",
                 "trace_output": "exit directions + flags + step counts (25 + 8 B/ray)" if getattr(fr, "_dir_traced", False) else "end states + flags + step counts (49 + 8 B/ray)",
                 "frame_end": "device shade + per-pixel sample mean, written as float RGBA " + ("into the gather slab + 1 async RCCL gather to rank 0 + root-side assembly kernel" if collective else "in frame order"),
-                "collective": ("rccl gather, %d rank(s)%s" % (world, " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if collective else "none (single rank)",
+                "collective": ("%s gather, %d rank(s)%s" % ("rccl" if backend == "nccl" else backend + " (development aid, ranks sharing a GPU)", world,
+                                                           " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if collective else "none (single rank)",
                 "launch": m["launch"],
             },
             "roofline": {
