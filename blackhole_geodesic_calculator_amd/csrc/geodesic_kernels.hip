@@ -21,15 +21,18 @@
 //     SIMD so that the event drain next to it does not spill).  For the Schwarzschild forms the waves also work out
 //     each batch's start records -- f0, r0, scipy's initial step -- while they fill their queue; Kerr runs a PREPARE
 //     pass first (Cartesian -> Boyer-Lindquist, E, L) and a finalize pass last;
-//   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord touches an object
-//     sphere, parks the step's start state in its own output slots, puts its ray on the wave's parked-event list and
-//     refills at once, so the root search never runs one lane wide.  When the ray queue is empty and 64 steps are
-//     parked the wave DRAINS them converged: recompute the step (bit-identical stages), quartic dense output, Brent
-//     roots, earliest terminal root wins; a step that holds no terminal event after all puts its ray on the wave's
-//     resume list, from which the queue is refilled before any new batch is claimed.  Park and resume records are
-//     written and read back by the same wavefront: no second pass, no host round trip;
+//   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord may touch an object
+//     sphere, does not take the step: it keeps the step's START state, and at its next service() that record goes into
+//     the wave's LDS slot pool (WaveLds: queue entries, parked steps and free slots share it) and the lane pops the
+//     next ray -- nothing of an event leaves the CU, and the root search never runs one lane wide.  Parked steps sit
+//     on two lists: one candidate event of a monotone kind (exit sphere, disk plane) -> drain_short, a certified
+//     Newton search on the dense-output polynomial; anything else (horizon, several candidates, object spheres) ->
+//     drain_long, Brent as scipy's brentq does it.  A list is drained 64 wide as soon as it holds 64 steps: recompute
+//     the step (bit-identical stages), dense output, root, earliest terminal root wins; a step that holds no terminal
+//     event after all goes back into the ray queue and carries on.  One launch, no second pass, no host round trip;
 //   * work is handed out in 64-ray batches from eight sliced device counters (a wave starts on the slice of its
-//     XCD and steals from the others), each batch claimed when the queue has run out;
+//     XCD and steals from the others), each batch claimed when the queue has run out; the counters come in two sets
+//     used by alternate launches, each launch zeroing the set of the next;
 //   * fp64 VALU only -- v_fma_f64 chains, v_rcp_f64 / v_rsq_f64 seeds + Newton, fp32
 //     v_log/v_exp seed + one cubic Newton step for err^(-1/5).  No MFMA: the path is an
 //     element-wise ODE, not a contraction.
