@@ -15,6 +15,11 @@ timed region then shards ONE fixed 1024x1024x5 frame over the N ranks (BASELINE.
 scaling) and is reported in the same line as "strong": {...}.  BHGEO_FORCE_COLLECTIVE=1 makes a single-GPU run
 take the N > 1 code path (RCCL process group of one rank, the real asynchronous gather, root-side assembly).
 
+roofline.traffic and roofline.valu_insts_per_64_ray_steps are measured in the run itself on one GPU: before this process
+touches the GPU it starts three rocprofv3 --pmc child runs of the same command (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU in
+separate passes, 3 steps each; live_pmc()); if that fails (or with --live-pmc 0, --lean, --cpu-seconds 0, N > 1) the line
+carries the committed profiles/rNN_pmc_summary*.json instead -- roofline.traffic_source says which.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -86,6 +91,10 @@ def parse():
                     help="N = 1, frame workload: also time rank 0's shard of a world-N dealing of the SAME fixed frame (no "
                          "collective) for each N listed and report the predicted strong-scaling efficiency T1 / (N T_N) in "
                          "a strong_predicted block; '' = off")
+    ap.add_argument("--live-pmc", type=int, default=1,
+                    help="1 (default, single GPU, not --lean): measure roofline.traffic and the VALU instruction count NOW, with "
+                         "three rocprofv3 --pmc child runs of this same command (3 steps each) started before this process "
+                         "touches the GPU; on any failure -- or 0 -- the line replays the committed profiles/ summary")
     ap.add_argument("--lean", action="store_true",
                     help="profiling runs: the headline's timed region and nothing after it (no full_records, shard emulation, "
                          "pipelined / host-buffer figures, CPU baseline), so that a profiler's per-kernel averages are the headline's")
@@ -141,10 +150,64 @@ def self_launch(n_gpus):
     raise SystemExit(rc)
 
 
+def live_pmc(a):
+    """HBM bytes and wave-level VALU instructions per launch of the trace kernel, measured in THIS run: three rocprofv3
+    child runs of this same command (--lean, 3 timed steps), one counter each -- FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU in
+    separate passes, as MI355X_MICROARCH.md prescribes; units KiB, FETCH_SIZE doubled on gfx950 (scripts/summarize_pmc.py
+    applies the same corrections to the committed profiles).  Children of a parent that has not touched the GPU yet.
+    Returns (hbm_bytes_per_launch, valu_insts_per_launch, source) or None: any failure means the committed summary is
+    replayed instead."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--lean", "--live-pmc", "0", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0",
+             "--cpu-seconds", "0", "--regime", a.regime, "--rhs", a.rhs, "--workload", a.workload, "--tile", str(a.tile),
+             "--order", a.order, "--visit", a.visit, "--lpt", str(a.lpt)]
+    for flag, val in (("--width", a.width), ("--height", a.height), ("--samples", a.samples)):
+        if val is not None:
+            child += [flag, str(val)]
+    if a.full_records:
+        child.append("--full-records")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bhg_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") == ctr and "trace_" in row.get("Kernel_Name", ""):
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            out[ctr] = (sum(vals) / len(vals), len(vals))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    hbm = 2.0 * out["FETCH_SIZE"][0] * 1024.0 + out["WRITE_SIZE"][0] * 1024.0
+    src = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU, three child runs of this command before the "
+           "timed region (means over %d / %d / %d trace launches; KiB, FETCH_SIZE x2 on gfx950)"
+           % (out["FETCH_SIZE"][1], out["WRITE_SIZE"][1], out["SQ_INSTS_VALU"][1]))
+    return hbm, out["SQ_INSTS_VALU"][0], src
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a.gpus)     # (before anything touches the GPU)
+    live = None
+    if a.live_pmc and not a.lean and a.cpu_seconds > 0 and a.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        live = live_pmc(a)      # (child processes; this one has not touched the GPU yet)
     import torch
     import torch.distributed as dist
 
@@ -417,6 +480,8 @@ def main():
         ms_per_step = dt / a.steps * 1e3
         achieved_tf = ray_steps * F / (k_ms * 1e-3) / 1e12
         traffic, traffic_source, valu_insts = pmc_traffic(a, method)
+        if live is not None:
+            traffic, valu_insts, traffic_source = live
         bytes_per_ray = BYTES_PER_RAY_DIR if getattr(fr, "_dir_traced", False) else BYTES_PER_RAY
         out = {
             "metric": "Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 " + ("Kerr" if a.rhs == "kerr" else "Schwarzschild") + " frame per GPU"

@@ -131,3 +131,23 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     assert line["full_records"]["value"] > 0 and line["full_records"]["algorithmic_bytes_per_ray"] == 81
     sh = line["strong_predicted"]["shards"]["2"]
     assert sh["rays"] * 2 == 256 * 256 * 2 and 0.2 < sh["efficiency"] < 1.5 and sh["ms_per_step_two_in_flight"] > 0
+
+
+def test_bench_measures_traffic_live_with_rocprofv3_child_runs():
+    """The default single-GPU line measures roofline.traffic and the VALU instruction count in its own run: three
+    rocprofv3 --pmc child runs of the same command, started before the parent touches the GPU."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "256", "--samples", "2", "--steps", "4",
+                          "--warmup", "2", "--ramp-seconds", "0", "--cpu-seconds", "0.2", "--emulate-shards", ""],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    r = line["roofline"]
+    assert r["traffic_source"].startswith("live: rocprofv3"), r["traffic_source"]
+    n = 256 * 256 * 2
+    assert 0.5 * n * 57 < r["traffic"] < 4.0 * n * 57            # HBM bytes per launch: around the algorithmic 57 B/ray
+    assert 400 < r["valu_insts_per_64_ray_steps"] < 1200
+    assert line["cpu_baseline"]["value"] > 0
