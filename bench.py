@@ -164,6 +164,10 @@ def live_pmc(a):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # (already under a profiler -- its preloaded library has initialised the GPU in this process and would ride along
+    # into the children: leave it to that run)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ):
+        return None
     child = [sys.executable, os.path.abspath(__file__), "--lean", "--live-pmc", "0", "--steps", "3", "--warmup", "1", "--ramp-seconds", "0",
              "--cpu-seconds", "0", "--regime", a.regime, "--rhs", a.rhs, "--workload", a.workload, "--tile", str(a.tile),
              "--order", a.order, "--visit", a.visit, "--lpt", str(a.lpt)]
