@@ -147,3 +147,24 @@ def test_bench_self_launch_relays_a_failing_launch(tmp_path):
         pytest.skip("a GPU is present: the launch succeeds (covered by tests/test_gpu_rccl.py)")
     assert out.returncode != 0
     assert "torch.distributed" in out.stderr or "Traceback" in out.stderr or "Error" in out.stderr
+
+
+def test_bench_live_pmc_declines_cleanly(monkeypatch):
+    """bench.live_pmc(): no rocprofv3 on PATH, or the run already under a profiler -> None (the line then carries the
+    committed profiles/ summary and says so in roofline.traffic_source); never an exception."""
+    import importlib
+    import shutil
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    a = types.SimpleNamespace(regime="adaptive", rhs="christoffel", workload="frame", tile=32, order="model", visit="auto", lpt=1,
+                              width=None, height=None, samples=None, full_records=False)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.live_pmc(a) is None
+    monkeypatch.setattr(shutil, "which", lambda name: "/usr/bin/true")
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    assert bench.live_pmc(a) is None
+    # and the replay it falls back to finds this round's summary for the default workload
+    a2 = types.SimpleNamespace(regime="adaptive", rhs="christoffel", workload="frame", width=1024, height=1024, samples=5)
+    traffic, source, valu = bench.pmc_traffic(a2, "dp54")
+    assert source.startswith("profiles/r") and 2.5e8 < traffic < 4.5e8 and 5e8 < valu < 8e8
