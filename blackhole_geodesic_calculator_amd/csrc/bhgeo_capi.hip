@@ -62,6 +62,11 @@ int fail_hip(hipError_t e, const char *what)
 
 }  // namespace
 
+namespace bhg {
+// for the other translation units of the library (bhgeo_frame.hip): set the thread-local message of bhg_last_error()
+int set_error(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace bhg
+
 namespace {
 
 // Worker threads for the host side of the host-buffer entry points: a 100-MB-class memcpy between a caller's

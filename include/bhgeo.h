@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 5
+#define BHG_ABI_VERSION 6
 
 /* return codes */
 #define BHG_OK 0
@@ -282,6 +282,75 @@ int bhg_shade_dir_device(bhg_context *ctx, const double *d_end_dir, const uint8_
  * pixels of the frame (d_index: the frame's permutation, computed once by the host from the tile dealing). */
 int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const int64_t *d_index, size_t n_pixels,
                                   float *d_frame, void *stream);
+
+/* --- the whole frame, owned by the library: one process, one or several GPUs, no PyTorch ------------------------
+ * Replaces the body of the reference's frame loop as Blender calls it -- render() (RelativisticRenderEngine.py:50) ->
+ * render_scene() (:152-168) -> ray_trace() (:172-267) on ONE render thread of ONE process; the author's commented-out
+ * mp.Pool (:210-216) marks where the parallelism has to live.  A bhg_frame holds, per listed device, a context, that
+ * device's tiles of the image (tile x tile pixels, all samples of a pixel on one device), its camera rays (generated on
+ * the device from the MT19937 jitter stream, :185-230), result buffers and the scene's images; bhg_frame_render() runs
+ * rays -> trace -> shade + sample mean on every device at once (one host thread enqueues, the devices work
+ * concurrently), gathers the devices' float-RGBA slabs onto the FIRST listed device with ONE exchange per frame, puts
+ * them into frame order there and copies one [height][width][4] float array back -- what layer.rect takes (:163-164).
+ *
+ *   devices   device indices, n_devices >= 1.  An index may be repeated (e.g. {0, 0}): the frame is then sharded over
+ *             several contexts of ONE GPU and gathered by device-to-device copies -- the only way to run the N > 1 code
+ *             path on a one-GPU machine, and bit-for-bit the image N distinct GPUs give (every ray is its own ODE).
+ *   jitter    HOST array, the full-frame stream [samples][height][width][2] of random.random() draws after
+ *             random.seed(sampling_seed) (:189), or NULL = pixel centres.  Copied; not referenced after the call.
+ *   tile      tile edge in pixels (<= 0: 32).
+ *   gather    BHG_FRAME_GATHER_AUTO: RCCL in single-process mode (ncclCommInitAll, grouped ncclSend / ncclRecv on the
+ *             contexts' streams -- librccl.so is loaded at run time) when the listed devices are distinct and RCCL loads,
+ *             else device-to-device copies (hipMemcpyPeerAsync over xGMI; same-device copies for a repeated device);
+ *             _COPY / _RCCL force one (RCCL with a repeated device is BHG_E_INVALID; with ONE device it sends the
+ *             frame's slab to itself -- the whole gather path on a single GPU, for tests).
+ * Tiles are dealt cyclically ((tile_x + tile_y) mod n_devices) until bhg_frame_rebalance() re-deals them by the
+ * MEASURED cost of the last render (attempted steps per tile, longest-processing-time-first across devices, each
+ * device visiting its tiles longest first): the engine renders the same view sample after sample and frame after
+ * frame (:242-250), so the last pass prices the next.  Results never depend on the dealing.
+ * Threading: like a context -- one call at a time per frame. */
+#define BHG_FRAME_GATHER_AUTO 0
+#define BHG_FRAME_GATHER_COPY 1
+#define BHG_FRAME_GATHER_RCCL 2
+typedef struct bhg_frame bhg_frame;
+/* The scene of a frame; everything lives on the HOST and is copied by bhg_frame_set_scene (images are uploaded to
+ * every device on the next render).  Members as in bhg_scene.  sky = NULL keeps the current sky image (the first call
+ * must bring one); disk_tex = NULL keeps the current disk texture (white if there never was one). */
+typedef struct bhg_frame_scene {
+    const float *sky;        /* [sky_h][sky_w][4] RGBA float32, equirectangular, rows bottom-up (v = -1 is row 0) */
+    int32_t sky_w, sky_h;
+    const float *disk_tex;   /* [disk_h][disk_w][4] */
+    int32_t disk_w, disk_h;
+    double disk_r_in, disk_r_out;                                /* 0, 0 = no disk; must equal the trace parameters' */
+    double disk_phase, disk_mean, disk_stddev, disk_intensity;
+    int32_t n_spheres, n_lamps;                                  /* <= BHG_MAX_SPHERES, <= 4 */
+    double spheres[BHG_MAX_SPHERES][4];                          /* BH-centred {cx, cy, cz, radius} */
+    double sphere_rgb[BHG_MAX_SPHERES][3];
+    double lamps[4][4];                                          /* {x, y, z, intensity} */
+} bhg_frame_scene;
+int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera *cam, const double *jitter, int32_t tile,
+                     int32_t gather, bhg_frame **out);
+void bhg_frame_destroy(bhg_frame *frame);
+int bhg_frame_set_scene(bhg_frame *frame, const bhg_frame_scene *scene);
+/* One frame.  rgba_host [height][width][4] float (pageable or page-locked): blocking, the image is there on return.
+ * rgba_host = NULL: the render is only enqueued and the image stays on the first device (bhg_frame_device_image;
+ * bhg_frame_synchronize waits) -- an animation loop that consumes frames on the GPU, and what bench.py times.
+ * A sky-only scene is traced direction-only (bhg_trace_dir_device); with a disk or objects, whole end records. */
+int bhg_frame_render(bhg_frame *frame, const bhg_params *p, float *rgba_host);
+int bhg_frame_synchronize(bhg_frame *frame);
+const float *bhg_frame_device_image(bhg_frame *frame); /* device address (first listed device) of the last image */
+/* Re-deal the tiles by the measured cost of the last render (see above); the next render regenerates the rays. */
+int bhg_frame_rebalance(bhg_frame *frame);
+/* out = {rays, attempted steps, accepted steps, horizon rays} of the last render, summed over the devices (waits). */
+int bhg_frame_stats(bhg_frame *frame, uint64_t out[4]);
+/* out = {n_devices, gather mode in use (BHG_FRAME_GATHER_COPY / _RCCL), largest shard in pixels, smallest shard,
+ * tile, 1 if dealt by measured cost, renders so far, 1 if the last render traced directions only}. */
+int bhg_frame_info(const bhg_frame *frame, int64_t out[8]);
+/* Per-render timing: with profiling on, bhg_frame_last_ms gives the trace kernel's milliseconds per listed device
+ * (trace_ms [n_devices], HIP events on each context's stream) and the root's gather + assembly time (root_ms, may be
+ * NULL; 0 for a one-device frame). */
+int bhg_frame_set_profiling(bhg_frame *frame, int enable);
+int bhg_frame_last_ms(bhg_frame *frame, float *trace_ms, float *root_ms);
 
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term.  With rhs_form = BHG_RHS_KERR_BL the triples
