@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -46,7 +46,12 @@ EXPORTS = (
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
     "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free", "bhg_rays_create", "bhg_rays_count",
     "bhg_rays_destroy", "bhg_rays_trace", "bhg_trace_dir_device", "bhg_shade_dir_device",
+    "bhg_frame_create", "bhg_frame_destroy", "bhg_frame_set_scene", "bhg_frame_render", "bhg_frame_synchronize",
+    "bhg_frame_device_image", "bhg_frame_rebalance", "bhg_frame_stats", "bhg_frame_info", "bhg_frame_set_profiling",
+    "bhg_frame_last_ms", "bhg_deal_tiles",
 )
+
+GATHER_AUTO, GATHER_COPY, GATHER_RCCL = 0, 1, 2
 
 
 class Camera(C.Structure):
@@ -64,6 +69,21 @@ class Scene(C.Structure):
     _fields_ = [
         ("d_sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32),
         ("d_disk_tex", C.c_void_p), ("disk_w", C.c_int32), ("disk_h", C.c_int32),
+        ("disk_r_in", C.c_double), ("disk_r_out", C.c_double),
+        ("disk_phase", C.c_double), ("disk_mean", C.c_double), ("disk_stddev", C.c_double),
+        ("disk_intensity", C.c_double),
+        ("n_spheres", C.c_int32), ("n_lamps", C.c_int32),
+        ("spheres", (C.c_double * 4) * 8),
+        ("sphere_rgb", (C.c_double * 3) * 8),
+        ("lamps", (C.c_double * 4) * 4),
+    ]
+
+
+class FrameScene(C.Structure):
+    """struct bhg_frame_scene (include/bhgeo.h): the scene of a library-owned frame, everything on the host."""
+    _fields_ = [
+        ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32),
+        ("disk_tex", C.c_void_p), ("disk_w", C.c_int32), ("disk_h", C.c_int32),
         ("disk_r_in", C.c_double), ("disk_r_out", C.c_double),
         ("disk_phase", C.c_double), ("disk_mean", C.c_double), ("disk_stddev", C.c_double),
         ("disk_intensity", C.c_double),
@@ -233,6 +253,32 @@ def load():
     L.bhg_context_stream.argtypes = [C.c_void_p]
     L.bhg_last_launch.restype = C.c_int
     L.bhg_last_launch.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.bhg_frame_create.restype = C.c_int
+    L.bhg_frame_create.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(Camera), _dp, C.c_int32, C.c_int32,
+                                   C.POINTER(C.c_void_p)]
+    L.bhg_frame_destroy.restype = None
+    L.bhg_frame_destroy.argtypes = [C.c_void_p]
+    L.bhg_frame_set_scene.restype = C.c_int
+    L.bhg_frame_set_scene.argtypes = [C.c_void_p, C.POINTER(FrameScene)]
+    L.bhg_frame_render.restype = C.c_int
+    L.bhg_frame_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
+    L.bhg_frame_synchronize.restype = C.c_int
+    L.bhg_frame_synchronize.argtypes = [C.c_void_p]
+    L.bhg_frame_device_image.restype = C.c_void_p
+    L.bhg_frame_device_image.argtypes = [C.c_void_p]
+    L.bhg_frame_rebalance.restype = C.c_int
+    L.bhg_frame_rebalance.argtypes = [C.c_void_p]
+    L.bhg_frame_stats.restype = C.c_int
+    L.bhg_frame_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.bhg_frame_info.restype = C.c_int
+    L.bhg_frame_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.bhg_frame_set_profiling.restype = C.c_int
+    L.bhg_frame_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.bhg_frame_last_ms.restype = C.c_int
+    L.bhg_frame_last_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bhg_deal_tiles.restype = C.c_int
+    L.bhg_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
+                                 C.c_size_t, C.POINTER(C.c_size_t)]
     if L.bhg_version() != ABI_VERSION:
         raise ImportError(f"libbhgeo ABI {L.bhg_version()} != expected {ABI_VERSION}")
     _lib = L
@@ -394,6 +440,139 @@ class RaySet:
                                      int(first), n, ptr("end", _dp), ptr("end_loc", _dp), ptr("end_dir", _dp), ptr("flags", _u8p),
                                      ptr("n_steps", _u32p), ptr("n_accepted", _u32p), ptr("object_id", C.POINTER(C.c_int8))))
         return out
+
+
+def deal_tiles(width, height, tile, world, rank, tile_cost=None, visit_by_cost=True):
+    """bhg_deal_tiles: the pixel list of device `rank` of a library-owned frame (host logic, no GPU needed).
+    tile_cost: None or one figure per tile, row-major over the tile grid."""
+    n = C.c_size_t()
+    tc = None if tile_cost is None else np.ascontiguousarray(tile_cost, dtype=np.float64).reshape(-1)
+    args = (int(width), int(height), int(tile), int(world), None if tc is None else _np_dp(tc), 1 if visit_by_cost else 0, int(rank))
+    _check(load().bhg_deal_tiles(*args, None, 0, C.byref(n)))
+    px = np.empty(n.value, dtype=np.int64)
+    _check(load().bhg_deal_tiles(*args, px.ctypes.data_as(C.POINTER(C.c_int64)), px.size, C.byref(n)))
+    return px
+
+
+class Frame:
+    """bhg_frame: a whole frame owned by the library -- jitter stream -> rays -> geodesics -> shaded, sample-averaged
+    float RGBA pixels in frame order -- on one or several GPUs of this one process (include/bhgeo.h).  No torch.
+
+    devices: device indices; an index may be repeated ({0, 0}: several contexts of one GPU, the N > 1 code path on a
+    one-GPU machine).  jitter: the full-frame stream [S*H*W*2] of random.random() draws, or None = pixel centres.
+    origin is BH-centred; rot a 3x3 rotation matrix (None = identity)."""
+
+    def __init__(self, devices, width, height, samples, *, fov_x=1.0, fov_y=1.0, origin=(1e-4, 0.0, 30.0), rot=None,
+                 jitter=None, tile=32, gather=GATHER_AUTO):
+        cam = Camera()
+        cam.width, cam.height, cam.samples = int(width), int(height), int(samples)
+        cam.fov_x, cam.fov_y = float(fov_x), float(fov_y)
+        r = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        cam.rot[:] = [float(v) for v in r.reshape(9)]
+        cam.origin[:] = [float(v) for v in np.asarray(origin, dtype=np.float64).reshape(3)]
+        devs = [int(d) for d in (devices if hasattr(devices, "__len__") else [devices])]
+        jit = None if jitter is None else np.ascontiguousarray(jitter, dtype=np.float64).reshape(-1)
+        need = 2 * cam.samples * cam.width * cam.height
+        if jit is not None and len(jit) < need:
+            raise ValueError(f"jitter stream too short: {len(jit)} < {need}")
+        h = C.c_void_p()
+        _check(load().bhg_frame_create((C.c_int32 * len(devs))(*devs), len(devs), C.byref(cam),
+                                       None if jit is None else _np_dp(jit), int(tile), int(gather), C.byref(h)))
+        self._h = h
+        self.devices, self.W, self.H, self.S = devs, cam.width, cam.height, cam.samples
+        self._scene = FrameScene()
+        self._scene.disk_mean, self._scene.disk_stddev, self._scene.disk_intensity = 0.2, 0.3, 1.0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().bhg_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, sky=None, *, disk=None, disk_tex=None, disk_phase=0.0, disk_mean=0.2, disk_stddev=0.3,
+                  disk_intensity=1.0, spheres=None, sphere_rgb=None, lamps=None):
+        """sky [h, w, 4] float32 equirectangular (None: keep the current one); disk = (R_in, R_out) or None; disk_tex
+        [h, w, 4] float32 or None; spheres [[cx, cy, cz, radius]] BH-centred, sphere_rgb (default white), lamps
+        [[x, y, z, intensity]].  The whole scene is replaced by each call (images are kept when not given)."""
+        sc = FrameScene()
+        keep = []
+        if sky is not None:
+            a = np.ascontiguousarray(sky, dtype=np.float32)
+            assert a.ndim == 3 and a.shape[2] == 4
+            sc.sky, sc.sky_w, sc.sky_h = a.ctypes.data, a.shape[1], a.shape[0]
+            keep.append(a)
+        if disk_tex is not None:
+            t = np.ascontiguousarray(disk_tex, dtype=np.float32)
+            assert t.ndim == 3 and t.shape[2] == 4
+            sc.disk_tex, sc.disk_w, sc.disk_h = t.ctypes.data, t.shape[1], t.shape[0]
+            keep.append(t)
+        if disk is not None:
+            sc.disk_r_in, sc.disk_r_out = float(disk[0]), float(disk[1])
+        sc.disk_phase, sc.disk_mean, sc.disk_stddev, sc.disk_intensity = (float(disk_phase), float(disk_mean),
+                                                                            float(disk_stddev), float(disk_intensity))
+        sp = _spheres_array(spheres if spheres is not None else [])
+        rgb = np.ones((len(sp), 3)) if sphere_rgb is None else np.asarray(sphere_rgb, dtype=np.float64).reshape(-1, 3)
+        lm = np.zeros((0, 4)) if lamps is None else np.asarray(lamps, dtype=np.float64).reshape(-1, 4)
+        if len(sp) > MAX_SPHERES or len(lm) > 4 or len(rgb) != len(sp):
+            raise ValueError("at most 8 spheres (one colour each) and 4 lamps")
+        sc.n_spheres, sc.n_lamps = len(sp), len(lm)
+        for j in range(len(sp)):
+            for q in range(4):
+                sc.spheres[j][q] = float(sp[j, q])
+            for q in range(3):
+                sc.sphere_rgb[j][q] = float(rgb[j, q])
+        for j in range(len(lm)):
+            for q in range(4):
+                sc.lamps[j][q] = float(lm[j, q])
+        _check(load().bhg_frame_set_scene(self._h, C.byref(sc)))
+
+    def render(self, params: "Params", out=None, to_host=True):
+        """One frame: float32 [H, W, 4] (a new array, or `out`).  to_host=False: only enqueue; the image stays on the
+        first device (device_image(), synchronize())."""
+        if not to_host:
+            _check(load().bhg_frame_render(self._h, C.byref(params), None))
+            return None
+        if out is None:
+            out = np.empty((self.H, self.W, 4), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags["C_CONTIGUOUS"] and out.size == self.H * self.W * 4
+        _check(load().bhg_frame_render(self._h, C.byref(params), C.c_void_p(out.ctypes.data)))
+        return out
+
+    def synchronize(self):
+        _check(load().bhg_frame_synchronize(self._h))
+
+    def device_image(self) -> int:
+        return load().bhg_frame_device_image(self._h) or 0
+
+    def rebalance(self):
+        _check(load().bhg_frame_rebalance(self._h))
+
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        _check(load().bhg_frame_stats(self._h, out))
+        return {"rays": int(out[0]), "attempted_steps": int(out[1]), "accepted_steps": int(out[2]), "horizon_rays": int(out[3])}
+
+    def info(self):
+        out = (C.c_int64 * 8)()
+        _check(load().bhg_frame_info(self._h, out))
+        return {"n_devices": int(out[0]), "gather": {GATHER_COPY: "copy", GATHER_RCCL: "rccl"}.get(int(out[1]), str(out[1])),
+                "largest_shard_pixels": int(out[2]), "smallest_shard_pixels": int(out[3]), "tile": int(out[4]),
+                "dealt_by_measured_cost": bool(out[5]), "renders": int(out[6]), "directions_only": bool(out[7])}
+
+    def set_profiling(self, enable=True):
+        _check(load().bhg_frame_set_profiling(self._h, 1 if enable else 0))
+
+    def last_ms(self):
+        """(trace kernel ms per listed device, root gather + assembly ms) of the last profiled render."""
+        tr = (C.c_float * len(self.devices))()
+        root = C.c_float()
+        _check(load().bhg_frame_last_ms(self._h, tr, C.byref(root)))
+        return [float(v) for v in tr], float(root.value)
 
 
 class Context:

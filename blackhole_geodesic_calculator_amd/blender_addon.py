@@ -89,6 +89,7 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         self.mark_x_min = _unset(scene.mark_x_min, 0)
         self.mark_x_max = _unset(scene.mark_x_max, self.res_x)
         self.device_shading = float(getattr(scene, "device_shading", 0) or 0) != 0.0
+        self.render_devices = int(float(getattr(scene, "render_devices", 1) or 1))
 
         # one solver object per frame, as the reference builds it (:134)
         self.GeoInt = GeodesicIntegratorSchwarzschild(mass=self.mass, time_like=False, verbose=False)
@@ -230,29 +231,52 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
 
     def ray_trace_device(self, width, height, samples, buf, origin, rotation, spheres):
         """The generator protocol of ray_trace with everything between the jitter stream and the averaged pixels on
-        the GPU: ONE ray-generation launch, ONE trace launch for all samples, ONE shade + mean launch, ONE array back."""
-        from .device_frame import DeviceFrame
+        the GPU(s): a library-owned frame (bhg_frame_*, include/bhgeo.h; _ffi.Frame -- ctypes only, no PyTorch: Blender's
+        bundled Python has none).  Per listed device ONE ray-generation launch, ONE trace launch for all samples, ONE
+        shade + mean launch; one gather onto the first device; ONE float RGBA array back.  scene.render_devices = N
+        shards the image tiles over the first N GPUs of the machine (the reference's render thread is one thread of one
+        process, :152-168; its commented-out mp.Pool, :210-216, is where the author wanted the parallelism)."""
+        from . import _ffi
+        from .raygen import euler_xyz_matrix, python_random_stream
         sky = self._sky_pixels()
         if sky is None:
             sky = np.zeros((2, 2, 4), dtype=np.float32)     # no sky image: black, as background_hit returns (:369-370)
-        has_obj = len(spheres) > 0
-        fr = DeviceFrame(self.GeoInt.context, width, height, samples, fov_x=self.field_of_view_x,
-                         fov_y=self.field_of_view_y, sampling_seed=self.sampling_seed, origin=origin,
-                         rotation_euler=rotation, bh_loc=self.bh_loc, directions_only=not has_obj)
-        fr.set_sky(sky)
-        if has_obj:
-            sp = np.array(spheres, dtype=np.float64).reshape(-1, 4)
-            sp[:, 0:3] -= self.bh_loc                        # the solver and the shade kernel work BH-centred
-            lamps = [[*(np.array(list(l.location), dtype=np.float64) - self.bh_loc), self.LAMP_INTENSITY]
-                     for l in getattr(self, "lamps", [])][:4]
-            fr.set_objects(sp, np.ones((len(sp), 3)), lamps)
-        fr.generate_rays()
-        fr.trace(self.GeoInt.params(self.max_integration_step, self.int_depth_curve_end))
-        rgba = fr.shade().cpu().numpy()
-        buf[:, :, :] = rgba.reshape(height, width, 4)
-        self.last_device_frame = fr
+        n_dev = max(1, int(getattr(self, "render_devices", 1) or 1))
+        avail = _ffi.device_count()
+        if n_dev > avail:
+            warnings.warn(f"render_devices = {n_dev} but {avail} GPU(s) are visible: using {max(avail, 1)}", RuntimeWarning)
+            n_dev = max(avail, 1)
+        first = int(getattr(self.GeoInt.context, "device", 0))
+        devices = [(first + i) % max(avail, 1) for i in range(n_dev)]
+        if os.environ.get("BHGEO_DEVICES"):
+            # an explicit device list, e.g. "2,3" or -- several contexts of ONE GPU, the N > 1 code path on a one-GPU
+            # machine (tests) -- "0,0"
+            devices = [int(v) for v in os.environ["BHGEO_DEVICES"].split(",")]
+        jitter = python_random_stream(self.sampling_seed, 2 * samples * width * height)          # :189
+        fr = _ffi.Frame(devices, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
+                        origin=np.asarray(origin, dtype=np.float64) - self.bh_loc,               # :278
+                        rot=euler_xyz_matrix(rotation), jitter=jitter)
+        try:
+            sp, lamps = None, None
+            if len(spheres) > 0:
+                sp = np.array(spheres, dtype=np.float64).reshape(-1, 4)
+                sp[:, 0:3] -= self.bh_loc                    # the solver and the shade kernel work BH-centred
+                all_lamps = getattr(self, "lamps", [])
+                if len(all_lamps) > 4:
+                    # (the host path sums over every lamp; the device scene holds four -- say so instead of quietly
+                    # rendering a darker image)
+                    warnings.warn(f"{len(all_lamps)} lamps in the scene: the device path lights objects with the first 4 "
+                                  "(scene.device_shading = 0 sums over all of them)", RuntimeWarning)
+                lamps = [[*(np.array(list(l.location), dtype=np.float64) - self.bh_loc), self.LAMP_INTENSITY]
+                         for l in all_lamps][:4]
+            fr.set_scene(sky, spheres=sp, sphere_rgb=None if sp is None else np.ones((len(sp), 3)), lamps=lamps)
+            rgba = fr.render(self.GeoInt.params(self.max_integration_step, self.int_depth_curve_end))
+            buf[:, :, :] = rgba.reshape(height, width, 4)
+            self.last_device_frame = fr.info()
+        finally:
+            fr.close()
         n = samples * height
-        for i in range(n):                                   # progress: one yield per sample and row, as ray_trace
+        for i in range(n):       # progress: the frame is one launch per device, reported after the fact at ray_trace's cadence
             yield (i + 1) / n
 
     # ---- shading (:366-378), Blender's own texture filter ------------------------------------
@@ -280,7 +304,7 @@ class CUSTOM_RENDER_PT_blackhole(RenderButtonsPanel, Panel):
              ("field_of_view_y", "field_of_view_y"), ("sampling_seed", "Sampling seed"), ("sky_image", "Sky image"),
              ("mark_x_min", "mark_x_min"), ("mark_x_max", "mark_x_max"), ("mark_y_min", "mark_y_min"),
              ("mark_y_max", "mark_y_max"), ("curved_space_objects", "Objects in curved space (0/1)"),
-             ("device_shading", "Shade on the GPU (0/1)"))
+             ("device_shading", "Shade on the GPU (0/1)"), ("render_devices", "GPUs to render on"))
 
     def draw(self, context):
         col = self.layout.split().column()
@@ -304,10 +328,12 @@ PROPS = [
     ("mark_x_max", bpy.props.FloatProperty(name="mark_x_max", default=-1.0)),
 ]
 
-# beyond the reference, both opt-in (module docstring): objects inside the curved region; the frame shaded on the GPU
+# beyond the reference, all opt-in (module docstring): objects inside the curved region; the frame shaded on the GPU;
+# the number of GPUs the device path shards the image over
 EXTRA_PROPS = [
     ("curved_space_objects", bpy.props.FloatProperty(name="curved_space_objects", default=0)),
     ("device_shading", bpy.props.FloatProperty(name="device_shading", default=0)),
+    ("render_devices", bpy.props.FloatProperty(name="render_devices", default=1)),
 ]
 
 _EXCLUDED_PANELS = {"VIEWLAYER_PT_filter", "VIEWLAYER_PT_layer_passes"}

@@ -190,37 +190,45 @@ struct bhg_frame {
 namespace {
 
 // ---- tile dealing (the host logic of dist.py: tile_owner / rank_tiles / rank_pixels, restated) ---------------------
-void deal_tiles(bhg_frame *f)
+// cost: nullptr, or one figure per tile (row-major over the tile grid).  Without: tiles are dealt cyclically along each
+// tile row, every row starting one device further on, and visited row-major.  With: sorted by decreasing cost (stable)
+// and dealt round-robin in THAT order -- every device gets one of each `world` consecutive tiles of the ranking
+// (longest-processing-time-first across devices) -- and, visit_by_cost, each device visits its tiles longest first (a
+// shard's short launch wants its long rays early; over a whole frame on one device row-major measures 1 % faster,
+// DESIGN.md section 5).
+void deal_tiles_into(int W, int H, int T, int world, const double *cost, bool visit_by_cost, std::vector<std::vector<int64_t>> &out)
 {
-    const int W = f->cam.width, H = f->cam.height, T = f->tile, world = (int)f->sh.size();
     const int tx = (W + T - 1) / T, ty = (H + T - 1) / T, nt = tx * ty;
-    std::vector<int> owner(nt);
-    std::vector<int> order(nt);
+    std::vector<int> owner(nt), order(nt);
     std::iota(order.begin(), order.end(), 0);
-    const bool by_cost = f->dealt_by_cost && (int)f->tile_cost.size() == nt;
-    if (by_cost) {
-        // tiles sorted by decreasing cost (stable) and dealt round-robin in THAT order: every device gets one of each
-        // `world` consecutive tiles of the ranking (longest-processing-time-first across devices)
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return f->tile_cost[a] > f->tile_cost[b]; });
+    if (cost) {
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
         for (int i = 0; i < nt; i++) owner[order[i]] = i % world;
     } else {
-        // cyclic along each tile row, every row starting one device further on
         for (int t = 0; t < nt; t++) owner[t] = (t % tx + t / tx) % world;
     }
-    for (auto &s : f->sh) s.pixels.clear();
-    // visit order: by decreasing cost once costs are known and the frame is sharded (a shard's short launch wants its
-    // long rays first); row-major otherwise (1 % faster over a whole frame on one device)
-    const bool visit_cost = by_cost && world > 1;
-    if (!visit_cost) std::iota(order.begin(), order.end(), 0);
+    if (!(cost && visit_by_cost)) std::iota(order.begin(), order.end(), 0);
+    out.assign((size_t)world, {});
     for (int i = 0; i < nt; i++) {
         const int t = order[i], r = owner[t];
         const int y0 = (t / tx) * T, x0 = (t % tx) * T, y1 = std::min(y0 + T, H), x1 = std::min(x0 + T, W);
-        auto &px = f->sh[r].pixels;
+        auto &px = out[(size_t)r];
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) px.push_back((int64_t)y * W + x);
     }
+}
+
+void deal_tiles(bhg_frame *f)
+{
+    const int W = f->cam.width, H = f->cam.height, T = f->tile, world = (int)f->sh.size();
+    const int nt = ((W + T - 1) / T) * ((H + T - 1) / T);
+    const bool by_cost = f->dealt_by_cost && (int)f->tile_cost.size() == nt;
+    std::vector<std::vector<int64_t>> px;
+    deal_tiles_into(W, H, T, world, by_cost ? f->tile_cost.data() : nullptr, world > 1, px);
     f->pmax = 0;
-    for (auto &s : f->sh) {
+    for (size_t r = 0; r < f->sh.size(); r++) {
+        Shard &s = f->sh[r];
+        s.pixels.swap(px[r]);
         s.P = s.pixels.size();
         s.n = s.P * (size_t)f->cam.samples;
         s.rays_ready = false;
@@ -379,6 +387,22 @@ void destroy_frame(bhg_frame *f)
 }  // namespace
 
 extern "C" {
+
+int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, const double *tile_cost, int32_t visit_by_cost,
+                   int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out)
+{
+    if (width <= 0 || height <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world || !n_out)
+        return fail(BHG_E_INVALID, "bad argument");
+    std::vector<std::vector<int64_t>> px;
+    deal_tiles_into(width, height, tile, world, tile_cost, visit_by_cost != 0, px);
+    const auto &mine = px[(size_t)rank];
+    *n_out = mine.size();
+    if (pixels) {
+        if (capacity < mine.size()) return fail(BHG_E_INVALID, "pixel buffer too small");
+        std::memcpy(pixels, mine.data(), mine.size() * sizeof(int64_t));
+    }
+    return BHG_OK;
+}
 
 int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera *cam, const double *jitter, int32_t tile,
                      int32_t gather, bhg_frame **out)

@@ -351,6 +351,12 @@ int bhg_frame_info(const bhg_frame *frame, int64_t out[8]);
  * NULL; 0 for a one-device frame). */
 int bhg_frame_set_profiling(bhg_frame *frame, int enable);
 int bhg_frame_last_ms(bhg_frame *frame, float *trace_ms, float *root_ms);
+/* The frame's tile dealing as a function of its own (host only, no device needed): the flat pixel ids y * width + x
+ * of device `rank` of `world`, tile after tile, row-major inside a tile.  tile_cost NULL: cyclic dealing; else one
+ * figure per tile (row-major over the tile grid): dealt by cost ranking and, visit_by_cost != 0, visited longest first.
+ * pixels NULL: only the count is returned in *n_out. */
+int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, const double *tile_cost, int32_t visit_by_cost,
+                   int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out);
 
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term.  With rhs_form = BHG_RHS_KERR_BL the triples

@@ -104,8 +104,8 @@ def test_public_header_is_plain_c(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "hdr.c"
     src.write_text('#include <stdio.h>\n#include "bhgeo.h"\n'
-                   'int main(void) { printf("%zu %zu %d %d\\n", sizeof(bhg_params), sizeof(bhg_scene), BHG_ABI_VERSION, '
-                   'BHG_MAX_SPHERES); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %d %d %zu %zu\\n", sizeof(bhg_params), sizeof(bhg_scene), BHG_ABI_VERSION, '
+                   'BHG_MAX_SPHERES, sizeof(bhg_frame_scene), sizeof(bhg_camera)); return 0; }\n')
     exe = tmp_path / "hdr"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            str(src), "-o", str(exe)])
@@ -115,6 +115,7 @@ def test_public_header_is_plain_c(tmp_path):
     assert int(out[0]) == ctypes.sizeof(_ffi.Params) == 96
     assert int(out[1]) == ctypes.sizeof(_ffi.Scene)
     assert int(out[2]) == _ffi.ABI_VERSION and int(out[3]) == _ffi.MAX_SPHERES
+    assert int(out[4]) == ctypes.sizeof(_ffi.FrameScene) and int(out[5]) == ctypes.sizeof(_ffi.Camera)
 
 
 def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
@@ -130,6 +131,81 @@ def test_c_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the example would run")
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
+
+
+def test_frame_object_host_side():
+    """The library-owned frame (bhg_frame_*): its tile dealing is dist.py's (cyclic; by cost ranking, visited longest
+    first or row-major -- ties included), argument errors come before any device is touched, and without a device the
+    constructor fails loudly."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd import dist as bdist
+    rng = np.random.default_rng(3)
+    for W, H, T, world in ((100, 70, 32, 3), (64, 64, 8, 4), (33, 17, 16, 2), (256, 192, 32, 8), (40, 40, 64, 2)):
+        tx, ty = bdist.tile_grid(W, H, T)
+        table = rng.integers(0, 40, tx * ty).astype(np.float64)      # (many ties: the sort must be stable like numpy's)
+
+        def tcost(cx, cy):
+            return table[int(cy // T) * tx + int(cx // T)]
+        seen = np.zeros(W * H, dtype=int)
+        for r in range(world):
+            a = _ffi.deal_tiles(W, H, T, world, r)
+            assert np.array_equal(a, bdist.rank_pixels(W, H, T, r, world))
+            seen[a] += 1
+            for visit in ("cost", "row"):
+                tcost.visit = visit
+                assert np.array_equal(_ffi.deal_tiles(W, H, T, world, r, table, visit == "cost"),
+                                      bdist.rank_pixels(W, H, T, r, world, tile_cost=tcost))
+        assert np.all(seen == 1)                                       # a partition of the frame
+    for bad in (dict(devices=[]), dict(devices=[0], gather=9), dict(devices=[0], width=0)):
+        with pytest.raises(_ffi.BhgError) as ei:
+            _ffi.Frame(bad["devices"], bad.get("width", 8), 8, 1, gather=bad.get("gather", _ffi.GATHER_AUTO))
+        assert ei.value.code == _ffi.E_INVALID
+    with pytest.raises(ValueError):
+        _ffi.Frame([0], 8, 8, 2, jitter=np.zeros(10))
+    if _ffi.device_count() == 0:
+        with pytest.raises(_ffi.BhgError) as ei:
+            _ffi.Frame([0], 8, 8, 1)
+        assert ei.value.code == _ffi.E_NO_DEVICE
+
+
+def test_addon_device_path_needs_no_torch():
+    """Blender's bundled Python has no PyTorch: the add-on, its device path included, must import and reach the library
+    with `torch` unimportable (on this GPU-less box the render then stops at bhg_create with the no-device error)."""
+    import subprocess
+    code = (
+        "import sys, importlib\n"
+        "sys.modules['torch'] = None\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import fake_bpy\n"
+        "from blackhole_geodesic_calculator_amd import _ffi\n"
+        "bpy, depsgraph = fake_bpy.install(width=16, height=16, samples=1, device_shading=1.0, render_devices=2.0)\n"
+        "addon = importlib.import_module('blackhole_geodesic_calculator_amd.blender_addon')\n"
+        "addon.register()\n"
+        "assert 'render_devices' in [p[0] for p in addon.EXTRA_PROPS]\n"
+        "eng = addon.RelativisticRenderEngine()\n"
+        "try:\n"
+        "    eng.render(depsgraph)\n"
+        "    print('rendered', eng.last_device_frame)\n"
+        "except _ffi.BhgError as e:\n"
+        "    assert e.code == _ffi.E_NO_DEVICE, e\n"
+        "    print('no device')\n"
+        "assert sys.modules.get('torch') is None\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ("no device" in r.stdout or "rendered" in r.stdout), r.stdout + r.stderr
+
+
+def test_c_frame_example_builds_and_fails_loudly_without_a_gpu(tmp_path):
+    import subprocess
+    libdir = os.path.join(ROOT, "blackhole_geodesic_calculator_amd")
+    exe = tmp_path / "render_frame"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "render_frame.c"), "-L", libdir, "-lbhgeo",
+                           "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)])
+    from blackhole_geodesic_calculator_amd import _ffi
+    if _ffi.device_count() > 0:
+        pytest.skip("a GPU is present: the example would run (tests/test_gpu_frame_object.py)")
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr and r.stdout == ""
 
