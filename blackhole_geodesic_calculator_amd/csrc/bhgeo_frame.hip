@@ -159,6 +159,9 @@ struct Shard {
     bool scene_ready = false;
     bool dir_traced = false;
     nccl_comm_t comm = nullptr;
+    // profiling: HIP event pairs around the trace call of every profiled render since the last bhg_frame_last_ms()
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evs;
+    size_t ev_used = 0;
 };
 
 }  // namespace
@@ -371,6 +374,10 @@ void destroy_frame(bhg_frame *f)
         for (DevBuf *b : {&s.pixels_d, &s.jitter_d, &s.k0, &s.end, &s.dir, &s.flags, &s.steps, &s.acc, &s.obj, &s.slab, &s.sky, &s.disk_tex})
             b->release();
         if (s.done) (void)hipEventDestroy(s.done);
+        for (auto &e : s.evs) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
         if (s.ctx) bhg_destroy(s.ctx);
     }
     f->recv.release();
@@ -562,10 +569,20 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
         // its part of the receive block, the others into their own slab
         float *dst = !gathered ? f->image.as<float>() : ((r == 0 && !loopback) ? f->recv.as<float>() : s.slab.as<float>());
         const int64_t *scatter = !gathered ? s.pixels_d.as<int64_t>() : nullptr;
+        if (f->profiling) {
+            if (s.ev_used == s.evs.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                s.evs.emplace_back(e0, e1);
+            }
+            HIP_TRY(hipEventRecord(s.evs[s.ev_used].first, s.stream));
+        }
         if (dir_only) {
             BHG_TRY(s.dir.ensure(s.device, s.n * 3 * sizeof(double)));
             BHG_TRY(bhg_trace_dir_device(s.ctx, &prm, f->cam.origin, nullptr, s.k0.as<double>(), s.n, s.dir.as<double>(),
                                          s.flags.as<uint8_t>(), s.steps.as<uint32_t>(), s.acc.as<uint32_t>(), s.stream));
+            if (f->profiling) HIP_TRY(hipEventRecord(s.evs[s.ev_used++].second, s.stream));
             BHG_TRY(bhg_shade_dir_device(s.ctx, s.dir.as<double>(), s.flags.as<uint8_t>(), s.P, S, s.sky.as<float>(), f->sky_w,
                                          f->sky_h, nullptr, dst, scatter, s.stream));
         } else {
@@ -575,6 +592,7 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
                                              f->cam.origin, nullptr, s.k0.as<double>(), s.n, s.end.as<double>(),
                                              s.flags.as<uint8_t>(), s.steps.as<uint32_t>(), s.acc.as<uint32_t>(),
                                              has_obj ? s.obj.as<int8_t>() : nullptr, s.stream));
+            if (f->profiling) HIP_TRY(hipEventRecord(s.evs[s.ev_used++].second, s.stream));
             bhg_scene sc;
             fill_scene(f, s, &sc);
             BHG_TRY(bhg_shade_scene_f32_device(s.ctx, s.end.as<double>(), s.flags.as<uint8_t>(), has_obj ? s.obj.as<int8_t>() : nullptr,
@@ -730,22 +748,32 @@ int bhg_frame_info(const bhg_frame *f, int64_t out[8])
 int bhg_frame_set_profiling(bhg_frame *f, int enable)
 {
     if (!f) return fail(BHG_E_INVALID, "frame is NULL");
-    DeviceScope scope;
-    f->profiling = enable != 0;
-    for (auto &s : f->sh) BHG_TRY(bhg_set_profiling(s.ctx, enable));
+    f->profiling = enable != 0;   // (a flag: may be switched per render, e.g. on for every 4th frame of a timed loop)
     return BHG_OK;
 }
 
 int bhg_frame_last_ms(bhg_frame *f, float *trace_ms, float *root_ms)
 {
     if (!f || !trace_ms) return fail(BHG_E_INVALID, "bad argument");
-    if (!f->profiling || !f->rendered) return fail(BHG_E_INVALID, "no profiled render yet (bhg_frame_set_profiling)");
     DeviceScope scope;
+    bool any = false;
     for (size_t r = 0; r < f->sh.size(); r++) {
-        float ms[3] = {0, 0, 0};
-        if (f->sh[r].P) BHG_TRY(bhg_last_pass_ms(f->sh[r].ctx, ms));
-        trace_ms[r] = ms[1];
+        Shard &s = f->sh[r];
+        trace_ms[r] = 0.0f;
+        if (s.ev_used == 0) continue;
+        any = true;
+        HIP_TRY(hipSetDevice(s.device));
+        HIP_TRY(hipEventSynchronize(s.evs[s.ev_used - 1].second));
+        double sum = 0.0;
+        for (size_t i = 0; i < s.ev_used; i++) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, s.evs[i].first, s.evs[i].second));
+            sum += ms;
+        }
+        trace_ms[r] = (float)(sum / (double)s.ev_used);
+        s.ev_used = 0;
     }
+    if (!any) return fail(BHG_E_INVALID, "no profiled render since the last call (bhg_frame_set_profiling)");
     if (root_ms) {
         *root_ms = 0.0f;
         if ((f->sh.size() > 1 || f->gather == BHG_FRAME_GATHER_RCCL) && f->ev_root.size() == 2) {

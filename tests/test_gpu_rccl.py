@@ -106,6 +106,8 @@ def test_bench_self_launches_two_ranks_when_started_without_a_launcher():
     line = json.loads(last)
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["strong"]["value"] > 0 and line["strong"]["scaling"] == "strong"
+    # the sharded path's headline has two frames in flight per rank; the sequential figure sits beside it
+    assert line["strong"]["frames_in_flight"] == 2 and line["strong"]["sequential"]["value"] > 0
     assert "2 rank" in line["config"]["collective"]
 
 
@@ -121,6 +123,8 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and "calibration trace" in line["config"]["tile_order"]
+    env.pop("BHGEO_BENCH_BACKEND")      # (the single-GPU line's rank-0 emulation issues a real 1-rank RCCL gather)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "256", "--samples", "2", "--steps", "8",
                           "--warmup", "2", "--ramp-seconds", "0", "--cpu-seconds", "0", "--emulate-shards", "2"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -131,6 +135,45 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     assert line["full_records"]["value"] > 0 and line["full_records"]["algorithmic_bytes_per_ray"] == 81
     sh = line["strong_predicted"]["shards"]["2"]
     assert sh["rays"] * 2 == 256 * 256 * 2 and 0.2 < sh["efficiency"] < 1.5 and sh["ms_per_step_two_in_flight"] > 0
+    # rank 0's step: the shard's slab through a 1-rank gather + the root's assembly of the whole 2-rank frame
+    assert "rank0_error" not in line["strong_predicted"], line["strong_predicted"].get("rank0_error")
+    assert 0.1 < sh["efficiency_rank0"] < 1.5 and sh["ms_per_step_rank0"] >= 0.8 * sh["ms_per_step"]
+
+
+def test_bench_orbit_two_ranks_reports_whole_frame_sharding_beside_the_tile_figure():
+    """Config 4 over 2 ranks (gloo, one GPU): the headline shards every frame's tiles; `frames_sharded` deals whole
+    frames round-robin with one gather at the end."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BHGEO_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "orbit", "--width", "256",
+                          "--samples", "2", "--steps", "6", "--warmup", "2", "--ramp-seconds", "0", "--cpu-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    fs = line["frames_sharded"]
+    assert fs["value"] > 0 and "round-robin" in fs["what"]
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0"])
+@pytest.mark.parametrize("workload", ["frame", "disk", "orbit"])
+def test_bench_single_process_mode(devices, workload):
+    """`--single-process`: the library-owned frame (bhg_frame_*) over the listed devices of ONE process, no
+    torch.distributed; "0,0" = two contexts of this box's one GPU (the N > 1 code path: dealing, slabs, gather, assembly)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BHGEO_DEVICES=devices)
+    n = len(devices.split(","))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", str(n), "--workload", workload,
+                          "--width", "256", "--samples", "2", "--steps", "8", "--warmup", "2", "--ramp-seconds", "0"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == n and line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert "ONE process" in line["config"]["parallelism"] and len(line["config"]["trace_call_ms_per_device"]) == n
+    frames = 5 if workload == "disk" else 1
+    assert line["config"]["rays_per_gpu"] * n == 256 * 256 * 2 * frames * (n if workload != "orbit" else 1)
+    if n > 1 and workload != "orbit":
+        assert line["strong"]["value"] > 0 and line["config"]["collective"].startswith("copy")
 
 
 def test_bench_measures_traffic_live_with_rocprofv3_child_runs():

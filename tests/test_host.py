@@ -6,6 +6,7 @@ import os
 import random
 import re
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -226,8 +227,8 @@ def test_bench_self_launch_relays_a_failing_launch(tmp_path):
 
 
 def test_bench_live_pmc_declines_cleanly(monkeypatch):
-    """bench.live_pmc(): no rocprofv3 on PATH, or the run already under a profiler -> None (the line then carries the
-    committed profiles/ summary and says so in roofline.traffic_source); never an exception."""
+    """bench.live_pmc(): no rocprofv3 on PATH, or the run already under a profiler -> {"error": why} (the line then
+    carries the committed profiles/ summary and roofline.traffic_source says so, with the reason); never an exception."""
     import importlib
     import shutil
     import types
@@ -236,11 +237,44 @@ def test_bench_live_pmc_declines_cleanly(monkeypatch):
     a = types.SimpleNamespace(regime="adaptive", rhs="christoffel", workload="frame", tile=32, order="model", visit="auto", lpt=1,
                               width=None, height=None, samples=None, full_records=False)
     monkeypatch.setattr(shutil, "which", lambda name: None)
-    assert bench.live_pmc(a) is None
+    assert "rocprofv3" in bench.live_pmc(a)["error"]
     monkeypatch.setattr(shutil, "which", lambda name: "/usr/bin/true")
     monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
-    assert bench.live_pmc(a) is None
+    assert "profiler" in bench.live_pmc(a)["error"]
     # and the replay it falls back to finds this round's summary for the default workload
     a2 = types.SimpleNamespace(regime="adaptive", rhs="christoffel", workload="frame", width=1024, height=1024, samples=5)
     traffic, source, valu = bench.pmc_traffic(a2, "dp54")
     assert source.startswith("profiles/r") and 2.5e8 < traffic < 4.5e8 and 5e8 < valu < 8e8
+    # ... and the line says why it is a replay
+    wl = types.SimpleNamespace(method="dp54")
+    t, src, v64 = bench.counters_for(a2, wl, {"error": "the FETCH_SIZE pass overran the budget"}, 65.0e6)
+    assert t == traffic and "replayed" in src and "overran" in src and 500 < v64 < 800
+    t, src, v64 = bench.counters_for(a2, wl, {"hbm": 3.0e8, "valu": 6.4e8, "source": "live: ...", "ray_steps": 64.0e6}, 65.0e6)
+    assert t == 3.0e8 and src.startswith("live") and abs(v64 - 640.0) < 1e-9      # normalised with the CHILD's ray-steps
+
+
+def test_bench_live_pmc_kills_the_whole_process_group_on_timeout(tmp_path, monkeypatch):
+    """A counter pass that overruns the shared deadline is killed with its descendants (start_new_session + killpg): a
+    surviving grandchild would keep the GPU busy during the headline's timed region."""
+    import importlib
+    import shutil
+    import types
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    fake = tmp_path / "rocprofv3"
+    pidfile = tmp_path / "grandchild.pid"
+    fake.write_text(f"#!/bin/bash\nsleep 300 &\necho $! > {pidfile}\nwait\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    for k in [k for k in os.environ if k.startswith(("ROCPROFILER_", "ROCPROF_"))]:
+        monkeypatch.delenv(k)
+    assert shutil.which("rocprofv3") == str(fake)
+    a = types.SimpleNamespace(regime="adaptive", rhs="christoffel", workload="frame", tile=32, order="model", visit="auto", lpt=1,
+                              width=None, height=None, samples=None, full_records=False)
+    t = time.time()
+    r = bench.live_pmc(a, deadline_s=7.0)
+    assert "killed" in r["error"] and time.time() - t < 30
+    pid = int(pidfile.read_text())
+    time.sleep(0.3)
+    alive = os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[1].split()[0]
+    assert not alive, "the profiler's descendant survived the timeout"
