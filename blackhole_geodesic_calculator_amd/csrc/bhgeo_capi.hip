@@ -193,6 +193,9 @@ struct bhg_context {
     unsigned long long *counter = nullptr;
     int counter_set = 0;
     bool counters_clean = false;
+    hipStream_t last_stream = nullptr;   // the stream of the last trace launch (launches of a context must stay ordered)
+    bool launched = false;
+    hipEvent_t ev_order = nullptr;
     int num_cus = 0;
     char name[256] = {0};
     // device buffers of the host-buffer entry points, grown on demand
@@ -382,7 +385,8 @@ void bhg_destroy(bhg_context *c)
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->counter) (void)hipFree(c->counter);
-    for (int i = 0; i < 3; i++)
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
+    for (int i = 0; i < 4; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -457,11 +461,12 @@ int validate_spheres(const bhg_params *p, const double *spheres, int32_t n_spher
     return BHG_OK;
 }
 
+// ONE launch: n <= BHG_MAX_RAYS_PER_LAUNCH rays (the kernels form a ray's byte offsets in 32 bits).
 // d_end [n][6], or -- d_end == nullptr -- d_end_dir [n][3]: only the direction half of the final states is produced
-int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
-                      const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
-                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream,
-                      double *d_end_dir = nullptr)
+int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                     const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
+                     uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream,
+                     double *d_end_dir)
 {
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
@@ -471,9 +476,20 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     if (n == 0) return BHG_OK;
     if (!d_k0 || (!d_end && !d_end_dir)) return fail(BHG_E_INVALID, "k0 / end is NULL");
     if (!x0_shared && !d_x0) return fail(BHG_E_INVALID, "neither x0_shared nor d_x0 given");
-    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    if (n > bhg::BHG_MAX_RAYS_PER_LAUNCH) return fail(BHG_E_INVALID, "internal: more rays than one launch takes");
     ENTER_DEVICE(c->device);
     hipStream_t s = (hipStream_t)stream;
+    // Launches of one context share its work counters (launch K zeroes the set launch K + 1 counts on) and its workspace:
+    // they must execute in the order they were issued.  On ONE stream they do; a call that arrives on ANOTHER stream than
+    // the previous one is ordered behind it here (an event on the old stream, a wait on the new one) -- it then cannot
+    // overlap the previous call, but it cannot corrupt it either (two traces that are to overlap need two contexts).
+    if (c->launched && s != c->last_stream) {
+        if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_order, c->last_stream));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_order, 0));
+    }
+    c->last_stream = s;
+    c->launched = true;
 
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
     //   ws      [n][8] doubles  Kerr only: the prepare pass's records {a0, h0, r0, 0, E, L} (the Schwarzschild trace kernel
@@ -482,7 +498,8 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     //   n_steps / n_accepted [n] u32 when the caller does not want them (the kernels never test these pointers)
     const bool has_exit = p->r_exit > 0.0;
     const bool kerr = p->rhs_form == BHG_RHS_KERR_BL;
-    const size_t sz_ws = kerr ? n * 8 * sizeof(double) : 0;
+    const bool needs_ws = bhg::needs_prepare_ws(p->rhs_form);   // Kerr; every form in a build without the inlined prepare
+    const size_t sz_ws = needs_ws ? n * 8 * sizeof(double) : 0;
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
     const size_t sz_steps = !d_n_steps ? sz_u32 : 0;
@@ -510,7 +527,7 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     a.end = d_end;
     // (Kerr end states are converted from Boyer-Lindquist by a pass over whole records: directions are split off after it)
     a.end_dir = kerr ? nullptr : d_end_dir;
-    a.ws = kerr ? (double *)c->d_ws : nullptr;
+    a.ws = needs_ws ? (double *)c->d_ws : nullptr;
     a.flags = d_flags ? d_flags : w_flags;
     a.n_steps = d_n_steps ? d_n_steps : w_steps;
     a.n_accepted = d_n_accepted ? d_n_accepted : w_acc;
@@ -618,6 +635,34 @@ int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;
+    return BHG_OK;
+}
+
+// A trace call of any size: launches of at most BHG_MAX_RAYS_PER_LAUNCH rays, one after the other on the caller's stream
+// (BASELINE's largest frame, 2048 x 2048 x 16 = 2^26 rays, is one launch).  Every ray is its own ODE: the split never
+// changes a result.  The work-order hint describes ONE launch's rays and is dropped for a split call.
+int trace_device_impl(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres,
+                      const double *x0_shared, const double *d_x0, const double *d_k0, size_t n, double *d_end,
+                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, int8_t *d_object_id, void *stream,
+                      double *d_end_dir = nullptr)
+{
+    if (n <= bhg::BHG_MAX_RAYS_PER_LAUNCH)
+        return trace_device_one(c, p, spheres, n_spheres, x0_shared, d_x0, d_k0, n, d_end, d_flags, d_n_steps, d_n_accepted,
+                                d_object_id, stream, d_end_dir);
+    if (!p) return fail(BHG_E_INVALID, "params is NULL");
+    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    bhg_params q = *p;
+    q.order_blocks = 0;
+    for (size_t off = 0; off < n; off += bhg::BHG_MAX_RAYS_PER_LAUNCH) {
+        const size_t m = std::min((size_t)bhg::BHG_MAX_RAYS_PER_LAUNCH, n - off);
+        const int rc = trace_device_one(c, &q, spheres, n_spheres, x0_shared, d_x0 ? d_x0 + off * 3 : nullptr,
+                                        d_k0 ? d_k0 + off * 3 : nullptr, m, d_end ? d_end + off * 6 : nullptr,
+                                        d_flags ? d_flags + off : nullptr, d_n_steps ? d_n_steps + off : nullptr,
+                                        d_n_accepted ? d_n_accepted + off : nullptr, d_object_id ? d_object_id + off : nullptr,
+                                        stream, d_end_dir ? d_end_dir + off * 3 : nullptr);
+        if (rc != BHG_OK) return rc;
+    }
+    c->last_launch[3] = (int32_t)((n + bhg::BHG_MAX_RAYS_PER_LAUNCH - 1) / bhg::BHG_MAX_RAYS_PER_LAUNCH);
     return BHG_OK;
 }
 

@@ -22,6 +22,8 @@ constexpr int BHG_METHOD_RK4_ = 1;
 constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
 constexpr int BHG_RHS_REDUCED_ = 1;
 constexpr int BHG_RHS_KERR_BL_ = 2;
+// rays per trace launch: the kernels form a ray's result offsets (idx * 48 at most) in 32 bits
+constexpr uint64_t BHG_MAX_RAYS_PER_LAUNCH = 1ull << 26;
 
 // Kernel arguments (passed by value -> SGPRs).  All pointers are device addresses.
 // Fields the step loop reads come first, in order of use, the ones only the queue fill and the event drain read
@@ -110,6 +112,9 @@ hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t 
 // evt: bit 0 = sphere-exit event compiled in, bit 1 = disk-plane event, bit 2 = object spheres (then all three)
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
+// does a trace launch of this right-hand side read per-ray prepare records from TraceArgs::ws (Kerr always; every form
+// when the kernels were built with -DBHG_INLINE_PREPARE=0)?  The C-ABI layer sizes the workspace by it.
+bool needs_prepare_ws(int rhs);
 // Kerr: after the last pass of a call, Boyer-Lindquist end states -> Cartesian
 hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t s);
 // the Kerr instantiations live in their own translation unit (geodesic_kernels_kerr.hip: same source, built with

@@ -924,16 +924,26 @@ struct Wave {
 
 // A ray's FINAL state: the whole record end[idx] = {x, v}, or -- direction-only calls (A.end_dir; sky frames read
 // nothing else) -- v alone into end_dir[idx]: 24 instead of 48 bytes written per ray and read by the shade kernel.
+// Byte offsets of a ray's results are formed in 32 bits and added to the (wave-uniform) array bases: the stores then
+// take the scalar-base + 32-bit-VGPR-offset form, where 64-bit pointer arithmetic per lane is five more instructions per
+// finished ray -- in a path that runs in nearly every iteration of the step loop.  Good for n * 48 < 2^32: a launch
+// holds at most BHG_MAX_RAYS_PER_LAUNCH = 2^26 rays (the C-ABI layer splits larger calls into several launches).
+template <class T>
+__device__ __forceinline__ T *at_offset(T *base, uint32_t byte_offset)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_offset);
+}
+
 __device__ __forceinline__ void store_end_state(const TraceArgs &A, uint32_t idx, const double x[3], const double v[3])
 {
     if (A.end_dir) {  // (wave-uniform)
-        double *e = A.end_dir + (size_t)idx * 3;
+        double *e = at_offset(A.end_dir, idx * 24u);
         e[0] = v[0];
         e[1] = v[1];
         e[2] = v[2];
         return;
     }
-    double *e = A.end + (size_t)idx * 6;
+    double *e = at_offset(A.end, idx * 48u);
     // 48 contiguous bytes per lane: three 16-byte stores
     reinterpret_cast<double2 *>(e)[0] = make_double2(x[0], x[1]);
     reinterpret_cast<double2 *>(e)[1] = make_double2(x[2], v[0]);
@@ -951,9 +961,10 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     store_end_state(A, idx, x, v);
     // (flags, n_steps, n_accepted are never null here: the C-ABI layer points them at its workspace when the caller
     // passes NULL -- three pointer tests less in a path that runs in nearly every iteration of the step loop)
-    A.flags[idx] = (uint8_t)flags;
-    A.n_steps[idx] = n_att;
-    A.n_accepted[idx] = n_acc;
+    *at_offset(A.flags, idx) = (uint8_t)flags;
+    const uint32_t o4 = idx * 4u;
+    *at_offset(A.n_steps, o4) = n_att;
+    *at_offset(A.n_accepted, o4) = n_acc;
 }
 
 
@@ -1430,7 +1441,7 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // R (out, when true is returned): the ray's state at the step's end; it carries on from there.
 //
 // Root search.  solve_ivp locates an event with brentq on the dense output to 4 eps (ivp.py:51-76).  Where the step
-// holds exactly ONE candidate event (horizon, exit sphere or disk plane) and its event function is provably MONOTONE
+// holds exactly ONE candidate event of a monotone kind (exit sphere or disk plane) and its event function is provably MONOTONE
 // over the whole step, the root is unique and any bracketing search that converges to that tolerance returns it:
 // such lanes run a safeguarded Newton iteration on the polynomial itself (exact derivative, no square root: r^2 - R^2
 // in place of r - R), 3 iterations where Brent takes 7 or 8 of twice the length, the position half of the dense
@@ -1439,7 +1450,7 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // |d_c| <= D_c = 2|q1| + 3|q2| + 4|q3| on [0, 1]:
 //     plane:   |v_z| > D_z                                           (z' keeps its sign)
 //     sphere:  x.x'/h = x.v + h th |v|^2 + [x.d + h th (e.v + v.d + e.d)], bracket bounded by
-//              S = sum_c |x_c| D_c + h (|v_c| (E_c + D_c) + E_c D_c);  outward: x.v > S;  inward: x.v + h |v|^2 < -S
+//              S = sum_c |x_c| D_c + h (|v_c| (E_c + D_c) + E_c D_c);  outward (the exit sphere): x.v > S
 //     Boyer-Lindquist: the event functions are single coordinates (r, theta): |u_c| > D_c.
 // Everything else -- several candidates in one step, object spheres, a failed certificate (a step diving through the
 // horizon with the Christoffel form's 1/f terms: round 2 found dense outputs with several crossings there, and
@@ -1448,9 +1459,9 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // Outcome of a parked step
 constexpr int PARK_ENDED = 0, PARK_RESUME = 1, PARK_UNCERTIFIED = 2;
 
-// The SHORT way: one candidate event (exit sphere or disk plane; the horizon too, where its certificate holds) whose
-// event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything when
-// the certificate (or the iteration) fails: the step then goes to the long list.
+// The SHORT way: one candidate event -- exit sphere or disk plane; a horizon crossing never comes here (short_kind()) --
+// whose event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything
+// when the certificate (or the iteration) fails: the step then goes to the long list.
 template <int RHS, int EVT>
 __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
 {
@@ -1485,25 +1496,23 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
             target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
             mono = fabs(k1 - k0) == 1.0 && fabs(P.v[1]) > 1.0000001 * Dc[1];
         } else {
-            target = kind == EV_HORIZON ? A.r_hor : A.r_exit;
-            mono = kind == EV_HORIZON ? (P.v[0] < -1.0000001 * Dc[0]) : (P.v[0] > 1.0000001 * Dc[0]);
+            target = A.r_exit;
+            mono = P.v[0] > 1.0000001 * Dc[0];
         }
     } else if (is_disk) {
         mono = fabs(P.v[2]) > 1.0000001 * Dc[2];
     } else {
-        const double Rr = kind == EV_HORIZON ? A.r_hor : A.r_exit;
-        target = Rr * Rr;
-        double xv = 0.0, vv = 0.0, S = 0.0;
+        target = A.r_exit * A.r_exit;
+        double xv = 0.0, S = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             xv = __builtin_fma(P.x[c], P.v[c], xv);
-            vv = __builtin_fma(P.v[c], P.v[c], vv);
             const double av = fabs(P.v[c]);
             S = __builtin_fma(fabs(P.x[c]), Dc[c], S);
             S = __builtin_fma(h, __builtin_fma(av, Ec[c] + Dc[c], Ec[c] * Dc[c]), S);
         }
         S *= 1.0000001;
-        mono = kind == EV_HORIZON ? (__builtin_fma(h, vv, xv) < -S) : (xv > S);
+        mono = xv > S;       // (outward crossing)
     }
     // G(th) and dG/dth on the position polynomial
     auto eval = [&](double th, double &g, double &dg, double xs[3]) {
@@ -1581,7 +1590,7 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
     }
     if (terminal) {
         dense_dir_at(th, h, P.v, P.a1, a3, a4, a5, a6, a7, ve);
-        const uint32_t fl = kind == EV_HORIZON ? BHG_FLAG_HIT_HORIZON_ : (is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_);
+        const uint32_t fl = is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_;
         store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
         return PARK_ENDED;
     }
@@ -1909,6 +1918,12 @@ __device__ __forceinline__ bool short_kind(uint32_t kind)
     if (!ADAPTIVE) return true;
     return ((EVT & EVT_EXIT) && kind == EV_EXIT) || ((EVT & EVT_DISK) && kind == EV_DISK);
 }
+// Does this kernel variant have a short list at all?  The adaptive kernel without optional events (the headline frame)
+// parks horizon crossings only, all of them long: its short drain -- 650 instructions -- is not compiled in.
+template <bool ADAPTIVE, int EVT>
+struct HasShort {
+    static constexpr bool value = !ADAPTIVE || (EVT & (EVT_EXIT | EVT_DISK)) != 0;
+};
 
 // Lanes that hold a step to park (L.pend) put its record into free slots, as many as there are.  A lane that finds
 // none keeps its record in its registers and stays inactive until slots come free: every pop frees one, and with an
@@ -2021,18 +2036,18 @@ __device__ __forceinline__ void replenish(const TraceArgs &A, LDS &Q, Wave &W, L
 {
     for (;;) {
         int take_a = 0, take_b = 0;
-        if (W.n_evA >= 64)
+        if (HasShort<ADAPTIVE, EVT>::value && W.n_evA >= 64)
             take_a = 64;
         else if (ADAPTIVE && W.n_evB >= 64)
             take_b = 64;
         else if (W.q_count == 0 && W.n_evA + W.n_evB > 0 &&
                  (W.exhausted ? (__ballot(L.active != 0u) == 0ull) : (W.n_free < 64))) {
-            if (ADAPTIVE && (W.n_evB >= W.n_evA || W.n_evB > NSLOT - 64))
+            if (ADAPTIVE && (!HasShort<ADAPTIVE, EVT>::value || W.n_evB >= W.n_evA || W.n_evB > NSLOT - 64))
                 take_b = W.n_evB;
             else
                 take_a = W.n_evA;
         }
-        if (take_a) {
+        if (HasShort<ADAPTIVE, EVT>::value && take_a) {
 #ifdef BHG_DIAG
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
             W.diag_drained += (unsigned long long)take_a;
@@ -2903,6 +2918,8 @@ hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int gr
     return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
+
+bool needs_prepare_ws(int rhs) { return rhs == BHG_RHS_KERR_BL_ || !BHG_INLINE_PREPARE; }
 
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {

@@ -188,7 +188,9 @@ int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int 
  * stream, as everywhere in HIP; bhg_context_stream() gives the context's own stream) and
  * returns without synchronising -- with or without a disk or objects: ONE persistent launch finishes
  * every ray (events are located and rays that carry on are resumed inside the trace kernel).  Two calls
- * on one context must not be in flight at once: they share the context's work counters and workspace. */
+ * on one context never overlap: they share the context's work counters and workspace, so a call issued on another
+ * stream than the previous one is ordered behind it by the library (an event + a stream wait; calls that are to run
+ * concurrently need a context each).  The launch is not graph-replayable (it consumes and re-arms those counters). */
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
                      uint8_t *d_flags, uint32_t *d_n_steps, uint32_t *d_n_accepted, void *stream);
@@ -387,8 +389,9 @@ int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
 
 /* Kernel launch geometry chosen for the last bhg_trace* call (for DESIGN/bench reporting):
  * out[0] = workgroups, out[1] = threads per workgroup, out[2] = resident waves per CU,
- * out[3] = number of trace launches the call took (always 1: rays whose disk / object candidate step
- *          held no terminal event are resumed inside the same launch). */
+ * out[3] = number of trace launches the call took: 1 -- rays whose disk / object candidate step held no terminal
+ *          event are resumed inside the same launch -- unless the call holds more than 2^26 rays (a launch takes at
+ *          most that many; BASELINE's largest frame, 2048 x 2048 x 16, is exactly one). */
 int bhg_last_launch(bhg_context *ctx, int32_t out[4]);
 
 #ifdef __cplusplus

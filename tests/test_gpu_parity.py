@@ -347,8 +347,8 @@ def test_disk_with_exit_sphere_rk4_and_fine(ctx, oracle):
     b = ctx.trace(k, cam, _params(r_s=1.0, lambda_end=80.0, disk_r_in=500.0, disk_r_out=501.0))
     assert all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))            # flags, step counts
     hor = (a[1] & 1) != 0
-    # (a step that crosses the horizon AND the disk plane holds two candidate events: its roots are Brent's, where the
-    # horizon alone is located by the certified Newton search -- same root to rounding, amplified by the diverging k)
+    # (the disk variant of the kernel is another instruction stream than the plain one: a horizon root -- Brent's in
+    # both -- agrees to rounding, amplified by the diverging k at the coordinate singularity)
     assert np.array_equal(a[0][~hor], b[0][~hor]) and np.abs(a[0][hor] - b[0][hor]).max() < 1e-8
 
 
