@@ -108,8 +108,10 @@ class DeviceFrame:
         [[x, y, z, intensity]] that light them.  Cheap to call per frame (an animation moves them): the
         values travel as kernel arguments."""
         spheres = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
-        if (self.spheres is None or len(self.spheres) == 0) != (len(spheres) == 0):
-            self._traced = None  # objects appeared / went away: the next shade needs a trace in the matching form
+        if self.spheres is None or not np.array_equal(spheres, self.spheres):
+            # the geometry the rays were traced against is gone (spheres moved, resized, appeared or went away): what
+            # the last trace wrote -- end states, flags, object ids -- no longer fits, and shade() says so
+            self._traced = None
         self.spheres = spheres
         self.sphere_rgb = sphere_rgb
         self.lamps = lamps
@@ -122,6 +124,7 @@ class DeviceFrame:
         return self.d_steps.view(self.S, self.P).to(torch.int64).sum(0)
 
     def generate_rays(self):
+        self._traced = None      # new rays: results of an earlier trace belong to the old ones
         self.ctx.raygen_device(self.W, self.H, self.S, self.fov_x, self.fov_y, self.d_jitter.data_ptr(),
                                self.d_k0.data_ptr(), self.P,
                                d_pixels=0 if self.d_pixels is None else self.d_pixels.data_ptr(),

@@ -6,11 +6,18 @@ name=$1; shift
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O
-timeout 600 python3 $R/bench.py "$@" 2>/dev/null | tail -1 > $O/prof_${name}_bench.json
+# (1) the plain line of this box, for the record; (2) the SAME command --lean under rocprofv3 --kernel-trace --stats: its own
+# JSON line (HIP events in that very process) + the per-launch trace, reduced to the timed region's launches
+# (scripts/timed_region_stats.py) -- the two must agree to 1 % (VERDICT r03 task 3)
+timeout 900 python3 $R/bench.py "$@" 2>/dev/null | tail -1 > $O/prof_${name}_bench_plain.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_$name /tmp/pf_$name /tmp/pw_$name
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 $R/bench.py --steps 20 --warmup 3 --lean "$@" > $O/prof_${name}_rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$name -- python3 $R/bench.py --lean "$@" > $O/prof_${name}_rocprof.log 2>&1
+grep '"metric"' $O/prof_${name}_rocprof.log | tail -1 > $O/prof_${name}_bench.json
 for f in $(find /tmp/kt_$name -name "*kernel_stats.csv"); do cp $f $O/prof_${name}_kernel_stats.csv; done
+for f in $(find /tmp/kt_$name -name "*kernel_trace.csv"); do
+  python3 $R/scripts/timed_region_stats.py $f $O/prof_${name}_bench.json $O/prof_${name}_timed_region.json trace_ 8 1
+done
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean "$@" >> $O/prof_${name}_rocprof.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$name -- python3 $R/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean "$@" >> $O/prof_${name}_rocprof.log 2>&1
 for f in $(find /tmp/pf_$name -name "*counter_collection.csv"); do head -1 $f > $O/prof_${name}_pmc_fetch.csv; grep "trace_" $f >> $O/prof_${name}_pmc_fetch.csv; done

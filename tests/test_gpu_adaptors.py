@@ -231,3 +231,62 @@ def test_addon_device_and_host_paths_light_objects_alike(ctx):
     # (the device path hands back float RGBA -- what layer.rect holds, :163-164 -- the host path float64)
     assert np.abs(out[0.0][hit] - out[1.0][hit]).max() < 2e-7
     assert out[1.0][hit][:, :3].max() > 0 and (out[1.0][hit][:, :3].sum(1) == 0).any()    # lit and shadowed / far-side points
+
+
+def test_limited_engine_adaptor_against_oracle(ctx, oracle):
+    """blackhole_geodesic_calculator_amd.limited.SchwarzschildGeodesic -- the solver call of the Limited engine
+    (raytracer/LimitedRelativisticRenderEngine.py:90, :273-279, :308-314): rays started on the object sphere at
+    ratio 30 against oracle.trace(r_exit=...), per ray and batched, with the disk and in flat space."""
+    from blackhole_geodesic_calculator_amd.limited import SchwarzschildGeodesic
+    sw = SchwarzschildGeodesic(metric="schwarzschild", context=ctx)
+    ratio = 30.0
+    assert sw.approximateCurveEnd(ratio) == 50 + 2 * 50 * (ratio / 20 - 1) == 100.0
+    rng = np.random.default_rng(12)
+    n = 4000
+    # hit points on the sphere r = ratio (a mesh hit lies on a facet: up to 1 % inside), directions aimed near the hole
+    p = rng.normal(size=(n, 3))
+    p = ratio * (1.0 - 0.01 * rng.random(n))[:, None] * p / np.linalg.norm(p, axis=1)[:, None]
+    d = rng.normal(size=(n, 3)) * 6.0 - p
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    end_loc, end_dir, mes = sw.ray_trace_many(d, p, exit_tolerance=0.2, ratio_obj_to_blackhole=ratio)
+    o = oracle.trace(d, p, r_s=1.0, lambda_end=100.0, r_exit=ratio)
+    assert np.array_equal(mes["flags"], o["flags"]) and np.array_equal(mes["n_steps"], o["n_attempted"])
+    assert np.array_equal(mes["hit_blackhole"], (o["flags"] & 1) != 0) and not mes["outside"].any()
+    esc = o["flags"] == 8
+    assert esc.sum() > 0.8 * n and mes["hit_blackhole"].sum() > 50
+    assert np.abs(np.linalg.norm(end_loc[esc], axis=1) - ratio).max() < 1e-9           # they end ON the exit sphere
+    assert np.abs(end_loc[esc] - o["end"][esc, 0:3]).max() < 1e-7 and np.abs(end_dir[esc] - o["end"][esc, 3:6]).max() < 1e-7
+    # the per-ray form: same end state, a sampled path that starts at the hit point and ends inside the sphere
+    for i in np.nonzero(esc)[0][:5]:
+        x, y, z, el, ed, m = sw.ray_trace(d[i], loc_hit=p[i], exit_tolerance=0.2, ratio_obj_to_blackhole=ratio,
+                                          curve_end=sw.approximateCurveEnd(ratio), max_step=np.inf)
+        assert not m["hit_blackhole"] and "error" not in m
+        assert np.array_equal(el, end_loc[i]) and np.array_equal(ed, end_dir[i])
+        assert abs(x[0] - p[i, 0]) < 1e-12 and len(x) == len(y) == len(z) > 5
+        assert np.sqrt(x * x + y * y + z * z).max() <= ratio * (1 + 1e-9)
+    i = int(np.nonzero(mes["hit_blackhole"])[0][0])
+    assert sw.ray_trace(d[i], loc_hit=p[i], ratio_obj_to_blackhole=ratio)[5]["hit_blackhole"]
+    # a start beyond the tolerated radius is reported, not integrated (the engine paints it red, :311-314)
+    far = p[0] * 1.25
+    m = sw.ray_trace(d[0], loc_hit=far, exit_tolerance=0.2, ratio_obj_to_blackhole=ratio)[5]
+    assert m["error"] == "Outside" and not m["hit_blackhole"]
+    _, _, mm = sw.ray_trace_many(d[:2], np.stack([far, p[1]]), exit_tolerance=0.2, ratio_obj_to_blackhole=ratio)
+    assert mm["outside"].tolist() == [True, False]
+    # ... while one within the slack is integrated as it stands: it crosses the sphere inward first, and ends on the way out
+    near = p[1] * (ratio * 1.1 / np.linalg.norm(p[1]))
+    el, ed, mm = sw.ray_trace_many(d[1:2], near[None, :], exit_tolerance=0.2, ratio_obj_to_blackhole=ratio)
+    assert not mm["outside"][0] and (mm["hit_blackhole"][0] or abs(np.linalg.norm(el[0]) - ratio) < 1e-9)
+    # the disk, with the engine's radii (disk_R_in * ratio, :285): against the oracle's disk event
+    disk = (0.15 * ratio, 0.35 * ratio)
+    el, ed, md = sw.ray_trace_many(d, p, ratio_obj_to_blackhole=ratio, disk=disk)
+    od = oracle.trace(d, p, r_s=1.0, lambda_end=100.0, r_exit=ratio, disk_r_in=disk[0], disk_r_out=disk[1])
+    assert np.array_equal(md["flags"], od["flags"]) and md["hit_disk"].sum() > 100
+    assert np.abs(el[md["hit_disk"], 2]).max() < 1e-12
+    # metric='flat' (README.md:233): straight lines through the sphere, nothing hits a hole
+    fl = SchwarzschildGeodesic(metric="flat", context=ctx)
+    el, ed, mf = fl.ray_trace_many(d, p, ratio_obj_to_blackhole=ratio)
+    assert not mf["hit_blackhole"].any() and np.abs(ed - d).max() < 1e-12
+    chord = -2.0 * (p * d).sum(1)                                     # exit point of the straight line p + t d on |x| = ratio ...
+    t_exit = 0.5 * (chord + np.sqrt(chord * chord - 4.0 * ((p * p).sum(1) - ratio * ratio)))
+    through = t_exit < 100.0                                          # ... where curve_end lets it get there
+    assert through.sum() > 0.9 * n and np.abs(el[through] - (p + t_exit[:, None] * d)[through]).max() < 1e-7
