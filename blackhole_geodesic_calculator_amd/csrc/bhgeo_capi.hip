@@ -560,6 +560,9 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 40.0 * std::nextafter(std::fmax(p->lambda_end, 1.0), INFINITY) * 2.220446049250313e-16;
+    // (lambda_end = 0: every ray is "already at t_bound" at its first step -- the rare-path prologue handles that, and an
+    // infinite cap sends every lane there)
+    if (p->lambda_end == 0.0) a.min_step_cap = INFINITY;
     // work-order hint: honoured when the call is that many equal blocks of whole 64-ray batches
     bool order_hint = p->order_blocks > 1 && n % p->order_blocks == 0 && (n / p->order_blocks) % 64 == 0;
 #ifdef BHG_TUNING

@@ -950,14 +950,21 @@ __device__ __forceinline__ void store_end_state(const TraceArgs &A, uint32_t idx
     reinterpret_cast<double2 *>(e)[2] = make_double2(v[1], v[2]);
 }
 
+// CHECK = false: the state is the end of an ACCEPTED step, which is finite by construction -- a non-finite component makes
+// the error norm NaN (a NaN reaches it through the stage-7 acceleration, an infinity through a scale factor of 0 times an
+// infinite product), and a NaN error norm rejects the step -- so the test (seven instructions) is left out of the one
+// store that runs in nearly every iteration of the step loop: a ray reaching lambda_end.
+template <bool CHECK = true>
 __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, const double x[3],
                                              const double v[3], uint32_t flags, uint32_t n_att,
                                              uint32_t n_acc)
 {
-    // any NaN or infinity among the six makes their sum non-finite (inf - inf is NaN): five additions and one class test
-    // instead of six class tests and their combination (the state is O(1e2) at most, the sum cannot overflow)
-    const bool bad = !isfinite(((x[0] + x[1]) + (x[2] + v[0])) + (v[1] + v[2]));
-    if (bad) flags |= BHG_FLAG_NAN_;
+    if (CHECK) {
+        // any NaN or infinity among the six makes their sum non-finite (inf - inf is NaN): five additions and one class test
+        // instead of six class tests and their combination (the state is O(1e2) at most, the sum cannot overflow)
+        const bool bad = !isfinite(((x[0] + x[1]) + (x[2] + v[0])) + (v[1] + v[2]));
+        if (bad) flags |= BHG_FLAG_NAN_;
+    }
     store_end_state(A, idx, x, v);
     // (flags, n_steps, n_accepted are never null here: the C-ABI layer points them at its workspace when the caller
     // passes NULL -- three pointer tests less in a path that runs in nearly every iteration of the step loop)
@@ -2142,6 +2149,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     TraceArgs A = A0;  // (a copy the Kerr variant below can move fields of into VGPRs; free for the others)
     double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     double max_step = A.max_step;
+    const bool has_cap = A.max_step < __builtin_inf();    // (wave-uniform)
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
@@ -2210,7 +2218,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             // practically never bite: 10 ulp(t) <= A.min_step_cap for every t in [0, t_bound], so ONE wave-wide test
             // covers them, and the common case is a min, a select and nothing else (the full prologue below is forty
             // instructions in every iteration of every ray).
-            const bool odd = !(L.h_abs > A.min_step_cap) || L.n_att >= A.max_steps || L.t == t_bound;
+            // ("already at t_bound" at the START of a step only happens with lambda_end = 0: a ray that reaches t_bound
+            // is final in that same step.  The C-ABI layer then sets min_step_cap = +inf, which sends every lane here.)
+            const bool odd = !(L.h_abs > A.min_step_cap) || L.n_att >= A.max_steps;
             if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
                 // (written as selects: as nested ifs this is eight divergent branches)
                 const bool tiny = !(L.h_abs > A.min_step_cap);
@@ -2226,12 +2236,17 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 // (the bound as a SCALAR operand of the min, pinned there by the empty asm: left to itself the compiler
                 // shares one VGPR copy of max_step between this path and the selects above, hoists it out of the loop,
                 // spills it -- and reloads it here behind a vmcnt(0) that waits for the previous iteration's result stores)
-                if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
-                    L.h_abs = L.rejected ? L.h_abs : fmin(L.h_abs, max_step);
-                } else {
-                    double ms = A.max_step;
-                    asm volatile("" : "+s"(ms));
-                    L.h_abs = L.rejected ? L.h_abs : fmin(L.h_abs, ms);
+                // (a compare and a select, not fmin: minnum wants both operands canonicalised first, two more instructions;
+                // h_abs is never NaN.  With max_step = +inf -- the engine's default, :59-60 -- the clamp is not there at all:
+                // wave-uniform branch.)
+                if (has_cap) {
+                    if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
+                        L.h_abs = (!L.rejected && L.h_abs > max_step) ? max_step : L.h_abs;
+                    } else {
+                        double ms = A.max_step;
+                        asm volatile("" : "+s"(ms));
+                        L.h_abs = (!L.rejected && L.h_abs > ms) ? ms : L.h_abs;
+                    }
                 }
             }
             if (term) {
@@ -2268,8 +2283,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 // 0.9 * err^(-1/5) = 0.9 * errsq^(-1/10), clamped to [0.2, 10] (rk.py:148-163)
                 double fac = dp54_factor(errsq);
                 if (errsq < 1.0) {
-                    fac = (errsq == 0.0) ? 10.0 : fmin(10.0, fac);
-                    if (L.rejected) fac = fmin(1.0, fac);
+                    // min(10, factor), and min(1, .) right after a rejection (rk.py:156-160): ONE min against a selected
+                    // bound.  (errsq == 0 -> 10, rk.py:153-154, needs no case of its own: dp54_factor clamps its argument
+                    // at 1e-11, where 0.9 x^(-1/10) = 11.3 > 10.)
+                    fac = fmin(fac, L.rejected ? 1.0 : 10.0);
                     L.h_abs *= fac;
                     L.rejected = 0u;
                     L.n_acc++;
@@ -2316,7 +2333,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                             L.a1[c] = a7[c];
                         }
                         if (t_new - t_bound >= 0.0) {  // base.py:203-204
-                            store_result(A, L.idx, L.x, L.v, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
+                            store_result<false>(A, L.idx, L.x, L.v, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
                             L.active = 0u;
                         }
                     }

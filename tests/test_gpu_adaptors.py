@@ -261,7 +261,8 @@ def test_limited_engine_adaptor_against_oracle(ctx, oracle):
         x, y, z, el, ed, m = sw.ray_trace(d[i], loc_hit=p[i], exit_tolerance=0.2, ratio_obj_to_blackhole=ratio,
                                           curve_end=sw.approximateCurveEnd(ratio), max_step=np.inf)
         assert not m["hit_blackhole"] and "error" not in m
-        assert np.array_equal(el, end_loc[i]) and np.array_equal(ed, end_dir[i])
+        # (the sampled-path kernel locates the exit with Brent, the frame kernel with the certified Newton search: one root, to rounding)
+        assert np.abs(el - end_loc[i]).max() < 1e-10 and np.abs(ed - end_dir[i]).max() < 1e-10
         assert abs(x[0] - p[i, 0]) < 1e-12 and len(x) == len(y) == len(z) > 5
         assert np.sqrt(x * x + y * y + z * z).max() <= ratio * (1 + 1e-9)
     i = int(np.nonzero(mes["hit_blackhole"])[0][0])
