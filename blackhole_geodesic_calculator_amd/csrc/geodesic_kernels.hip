@@ -2255,7 +2255,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             } else {
                 const double h_try = L.h_abs;   // (the event drain redoes the next three lines from this value)
                 double t_new = L.t + h_try;
-                if (t_new - t_bound > 0.0) t_new = t_bound;
+                if (t_new > t_bound) t_new = t_bound;     // (rk.py:128-129; x - y > 0 and x > y are the same test in IEEE arithmetic)
                 const double h = t_new - L.t;
                 L.h_abs = fabs(h);
 
@@ -2268,8 +2268,10 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 L.n_att++;
 
                 double errsq = dp54_errsq(L.x, L.v, xn, vn, L.a1, a2, a3, a4, a5, a6, a7, h, rtol, atol);
-                // NaN anywhere in the step must reject (np.maximum / norm propagate NaN)
-                if (!(r_new == r_new)) errsq = __builtin_nan("");
+                // NaN anywhere in the step must reject (np.maximum / norm propagate NaN) -- and does, without a test of its
+                // own: a NaN in xn or vn makes the stage-7 acceleration NaN in all three components (through r^2, |k|^2 or
+                // x.k), that the error sum, and `errsq < 1` is false for a NaN.  (r_new alone can only be NaN with a finite
+                // state when r^2 overflows, |x| > 1e154: such a state is still finite and ends the ray at lambda_end.)
 #ifdef BHG_DIAG
                 if (A.diag && L.idx == A.dbg_idx && L.n_att <= 64) {
                     double *dd = reinterpret_cast<double *>(A.diag) + 262144 + (L.n_att - 1) * 4;
@@ -2291,9 +2293,11 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     L.rejected = 0u;
                     L.n_acc++;
 
-                    // events between step ends (ivp.py:109-126): horizon any direction, exit outward
-                    const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
-                                      ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+                    // events between step ends (ivp.py:109-126): horizon any direction, exit outward.  A ray in the step
+                    // loop is OUTSIDE the horizon radius at the start of every step (it starts there -- start-inside rays
+                    // never get here -- and a step that ends at or inside it is parked, which always ends the ray), so the
+                    // sign-change rule g(t) g(t_new) <= 0 is one comparison (r_new is finite in an accepted step)
+                    const bool ev_h = r_new <= r_s;
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                     bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                 crossed_disk_plane<RHS>(L.x, xn);
@@ -2332,7 +2336,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                             L.v[c] = vn[c];
                             L.a1[c] = a7[c];
                         }
-                        if (t_new - t_bound >= 0.0) {  // base.py:203-204
+                        if (t_new >= t_bound) {  // base.py:203-204
                             store_result<false>(A, L.idx, L.x, L.v, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
                             L.active = 0u;
                         }
@@ -2418,8 +2422,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
             }
             rk4_step<RHS>(L.x, L.v, L.a1, h, met, xn, vn, an, r_new);
             L.n_att++;
-            const bool ev_h = ((L.r_cur - r_s <= 0.0) && (r_new - r_s >= 0.0)) ||
-                              ((L.r_cur - r_s >= 0.0) && (r_new - r_s <= 0.0));
+            const bool ev_h = r_new <= r_s;     // (outside at every step's start, see the adaptive kernel; NaN: `bad` below)
             const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
             bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
             const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
