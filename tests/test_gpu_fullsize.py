@@ -141,14 +141,33 @@ def test_config5_kerr_frame_full_size(ctx, oracle):
     flg, stp = fl.cpu().numpy(), st.cpu().numpy().astype(np.uint32)
     fbad = flg != o["flags"]
     sbad = ~fbad & (stp != o["n_attempted"])
-    assert fbad.sum() <= 100, int(fbad.sum())
-    assert sbad.mean() < 0.003, float(sbad.mean())
+    # (measured 21 flag differences and 0.097 % step-count differences: asserted with a 50 % margin)
+    assert fbad.sum() <= 32, int(fbad.sum())
+    assert sbad.mean() < 0.00146, float(sbad.mean())
     # the rays that differ pass closer to the axis than the frame's typical ray
     kperp = np.hypot(*fr.d_k0[:, 0:2].cpu().numpy().T)
     assert np.median(kperp[fbad | sbad]) < 0.6 * np.median(kperp)
     same = ~fbad & ~sbad
     d = np.abs(end.cpu().numpy() - o["end"]).max(1)
-    assert np.median(d[same & (o["flags"] == 4)]) < 1e-11 and np.quantile(d[same & (o["flags"] == 4)], 0.99) < 1e-4
+    esc = same & (o["flags"] == 4)
+    assert np.median(d[esc]) < 1e-11
+    # the stated per-class bound for Kerr escaping rays (5e-8, tests/test_gpu_parity.py STATED) plus the ray's own
+    # conditioning: for every ray beyond the plain bound the oracle's sensitivity S_i to a 1-ulp change of k0 is measured
+    # (three perturbation patterns, as _sensitivity in test_gpu_parity.py) and the difference must lie within 1e4 S_i --
+    # the Kerr fuzz test's factor
+    over = np.nonzero(esc & (d > 5e-8))[0]
+    k_all = fr.d_k0.cpu().numpy()
+    if len(over):
+        ko = k_all[over]
+        eps = np.finfo(float).eps
+        pats = (np.nextafter(ko, np.inf), np.nextafter(ko, -np.inf), ko * (1.0 + np.array([2.0, -2.0, 2.0]) * eps))
+        S = np.max([np.abs(oracle.trace(kp, CAM, **kw)["end"] - o["end"][over]).max(1) for kp in pats], axis=0)
+        beyond = d[over] > 5e-8 + 1e4 * np.nan_to_num(S, nan=np.inf, posinf=np.inf)
+        print(f"config 5: {len(over)} of {int(esc.sum())} agreeing escaping rays beyond 5e-8 (worst {d[over].max():.3g}); "
+              f"{int(beyond.sum())} of them beyond 5e-8 + 1e4 S_i")
+        # (measured: 170,771 rays = 3.5 % beyond 5e-8 -- this camera sits ON the polar axis, where Boyer-Lindquist phi
+        # amplifies an ulp of k0 without bound; the worst differs by 7.2 -- and NONE of them beyond 5e-8 + 1e4 S_i)
+        assert len(over) < 0.05 * esc.sum() and beyond.sum() <= 10, (len(over), int(beyond.sum()))
     # ... and what it does to the picture: the frame shaded on the device against the frame shaded from the oracle's states
     sky = synthetic_sky(2048, 1024)
     fr.set_sky(sky)
@@ -156,5 +175,6 @@ def test_config5_kerr_frame_full_size(ctx, oracle):
     img = fr.shade().cpu().numpy()
     img_o = sh.shade_reduce(o["end"], o["flags"], 1024 * 1024, 5, sky)
     dimg = np.abs(img - img_o)[:, :3].max(1)
-    assert (dimg > 1e-3).mean() < 1e-3 and (dimg > 1e-6).mean() < 0.015, ((dimg > 1e-3).sum(), (dimg > 1e-6).sum())
+    # (measured 285 pixels beyond 1e-3 and 4,746 beyond 1e-6: a 50 % margin)
+    assert (dimg > 1e-3).sum() <= 430 and (dimg > 1e-6).sum() <= 7100, ((dimg > 1e-3).sum(), (dimg > 1e-6).sum())
     assert np.median(dimg) < 1e-12
