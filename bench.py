@@ -114,6 +114,10 @@ def parse(argv=None):
                          "contexts, one gather onto device 0 -- RCCL single-process mode when the devices are distinct); no "
                          "torch.distributed.  BHGEO_DEVICES=0,0 lists the devices explicitly (a repeated index = several contexts "
                          "of one GPU)")
+    ap.add_argument("--root-share", type=str, default="auto",
+                    help="N > 1: what rank 0 -- which also receives the gather and assembles the frame -- is dealt, as a multiple of "
+                         "what every other rank is dealt; auto = from the assembly kernel's and a shard frame's measured times, so "
+                         "that all ranks finish together; 1 = equal shares")
     ap.add_argument("--shard", choices=["tiles", "frames", "both"], default="both",
                     help="orbit workload, N > 1: tiles = every frame's tiles over all ranks + one gather per frame (the headline); "
                          "frames = whole frames dealt round-robin to the ranks, no tail, one gather at the end; both = the second "
@@ -533,6 +537,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
     jitter = python_random_stream(42.0, 2 * S * W * H)
     pixels = bdist.rank_pixels(W, H, a.tile, shard_rank, shard_world, tile_cost=tcost)
     frames, batch = build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky)
+    root_share = None
     if a.lpt and a.order == "measured":
         # One untimed calibration trace of the frame prices every tile by the attempted steps of its rays; the tiles
         # are then dealt to the ranks and visited longest-first by THAT (the renderer traces the same pixels sample
@@ -546,6 +551,45 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
         del frames, batch
         pixels = bdist.rank_pixels(W, H, a.tile, shard_rank, shard_world, tile_cost=tcost)
         frames, batch = build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky)
+    if shard_world > 1 and tcost is not None and a.root_share != "1":
+        # Rank 0 owns the frame: on top of its shard it receives the gather and assembles W x H pixels per frame.  Dealt a
+        # correspondingly smaller shard, all ranks finish together.  Measured here (rank 0, HIP events, untimed): T = trace +
+        # shade of one frame of an equal shard, t_root = the assembly kernel over the whole frame; with rank 0 dealt rho
+        # times what the others get, rho T_o + t_root = T_o and (N - 1 + rho) T_o = N T give
+        # rho = (N T - (N - 1) t_root) / (N T + t_root); rank 0 broadcasts it and the tiles are dealt again.
+        if a.root_share == "auto":
+            rho = torch.zeros(1, dtype=torch.float64, device="cuda")
+            if rank == 0:
+                probe = bdist.FrameGatherer(W, H, a.tile, channels=4, dtype=torch.float32, device="cuda", assemble=rt.assemble,
+                                            tile_cost=tcost)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                slab = torch.zeros((len(pixels), 4), dtype=torch.float32, device="cuda")
+                for rep in range(2):        # (first pass: warm-up)
+                    ev[0].record(rt.stream)
+                    for _ in range(4):
+                        for f in ([batch] if batch is not None else frames):
+                            f.trace(wl.params)
+                        for f in frames:
+                            f.shade_f32(slab, None)
+                    ev[1].record(rt.stream)
+                    ev[2].record(rt.stream)
+                    for _ in range(4):
+                        if getattr(probe, "recv_all", None) is not None:
+                            rt.assemble(probe.recv_all[0], probe.perm, probe.frame)
+                    ev[3].record(rt.stream)
+                    torch.cuda.synchronize()
+                T_, t_root = ev[0].elapsed_time(ev[1]) / 4.0, ev[2].elapsed_time(ev[3]) / 4.0
+                rho[0] = (shard_world * T_ - (shard_world - 1) * t_root) / (shard_world * T_ + t_root)
+                del probe, slab
+            dist.broadcast(rho, src=0)
+            root_share = float(min(1.0, max(0.5, rho.item())))
+        else:
+            root_share = float(a.root_share)
+        if root_share < 0.995:
+            tcost.root_share = root_share
+            del frames, batch
+            pixels = bdist.rank_pixels(W, H, a.tile, shard_rank, shard_world, tile_cost=tcost)
+            frames, batch = build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky)
     del jitter
     fr = frames[0]
     n = sum(f.n for f in frames)
@@ -672,7 +716,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
         lanes.close()
     return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                 steps_all=float(tot[1].item()), launch=rt.ctx.last_launch(), fr=fr, tcost=tcost,
-                visit=tile_cost.visit)
+                visit=tile_cost.visit, root_share=root_share)
 
 
 def time_frame(fr_, params, steps, warmup, overlap=False, device=0, ramp=0.25, after_shade=None):
@@ -799,8 +843,37 @@ def strong_predicted(rt, wl, sky, m, t1):
             root.drain()
             torch.cuda.synchronize()
             rec.update(ms_per_step_rank0=r_ms, ms_per_step_rank0_two_in_flight=ro_ms,
-                       efficiency_rank0_sequential=t1_ms / (N * r_ms), efficiency_rank0=t1o_ms / (N * ro_ms))
+                       efficiency_rank0_sequential=t1_ms / (N * r_ms), efficiency_rank0_equal_shares=t1o_ms / (N * ro_ms))
             del root
+            # ... and with rank 0 dealt a smaller shard, so that root and peers finish together (what bench.py does at N > 1,
+            # --root-share auto): rho from the two measured times, then rank 0's biased shard WITH the root's work and rank 1's
+            # biased shard without, both with two frames in flight; the step is the slower of the two
+            t_extra = max(ro_ms - mso_n, 0.0)
+            rho = min(1.0, max(0.5, (N * mso_n - (N - 1) * t_extra) / (N * mso_n + t_extra)))
+            rec["root_share"] = rho
+            if tc is not None and rho < 0.995:
+                def tcb(cx, cy, _tc=tc):
+                    return _tc(cx, cy)
+                tcb.visit, tcb.root_share = tc.visit, rho
+                t_b = []
+                for r_ in (0, 1):
+                    pix_b = bdist.rank_pixels(W, H, a.tile, r_, N, tile_cost=tcb)
+                    frb = DeviceFrame(rt.ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=CAM, pixels=pix_b,
+                                      jitter=jit, directions_only=fr.directions_only)
+                    frb.set_sky(sky)
+                    frb.generate_rays()
+                    rootb = EmulatedRoot(rt, W, H, a.tile, N, tcb) if r_ == 0 else None
+                    tb, _, _ = time_frame(frb, wl.params, a.steps, a.warmup, overlap=True, device=rt.local_rank, ramp=a.ramp_seconds,
+                                          after_shade=None if rootb is None else rootb.after_shade)
+                    if rootb is not None:
+                        rootb.drain()
+                        torch.cuda.synchronize()
+                    t_b.append(tb)
+                    del frb, rootb
+                rec.update(ms_per_step_rank0_biased=t_b[0], ms_per_step_rank1_biased=t_b[1],
+                           efficiency_rank0=t1o_ms / (N * max(t_b)))
+            else:
+                rec["efficiency_rank0"] = rec["efficiency_rank0_equal_shares"]
         pred["shards"][str(N)] = rec
         del frs
     del jit
@@ -808,9 +881,11 @@ def strong_predicted(rt, wl, sky, m, t1):
         pred["rank0_error"] = group_error
     pred["what"] = ("rank 0's shard of a world-N dealing of the fixed %dx%d x%d frame on this one GPU; efficiency = T1 / (N T_N).  "
                     "efficiency / _two_in_flight: trace + shade of the shard alone, no collective (round 3's figures).  "
-                    "efficiency_rank0 (two frames in flight, the default of the sharded path) / efficiency_rank0_sequential: the "
-                    "shard's slab additionally goes through a 1-rank %s gather (asynchronous, two slabs in rotation) and the root "
-                    "assembles the WHOLE N-rank frame from the receive block -- rank 0's step, the slowest rank's.  two_in_flight: "
+                    "efficiency_rank0_equal_shares (two frames in flight) / efficiency_rank0_sequential: the shard's slab additionally "
+                    "goes through a 1-rank %s gather (asynchronous, two slabs in rotation) and the root assembles the WHOLE N-rank "
+                    "frame from the receive block -- rank 0's step, the slowest rank's.  efficiency_rank0: the same with rank 0 dealt "
+                    "root_share times what the others get (the default of the sharded path, --root-share auto): the slower of rank 0's "
+                    "biased shard with the root's work and rank 1's biased shard without.  two_in_flight: "
                     "consecutive frames alternate between two streams / library contexts, the second stream at another priority "
                     "(a hardware queue of its own), so a frame's first waves start while the previous frame's last ones drain; T1 is "
                     "measured the same way" % (W, H, S, "RCCL" if rt.backend == "nccl" else rt.backend))
@@ -1041,6 +1116,7 @@ def main():
                   "frames_in_flight": 2 if head is not seq else 1,
                   "workload": f"ONE {seq['W']}x{seq['H']} x{seq['S']} frame sharded over {world} GPUs ({seq['n']} rays on rank 0), same K / W, "
                               f"barrier + max-over-ranks timing",
+                  "root_share": head["root_share"],
                   "sequential": {"value": seq["rays_all"] / per_step(seq) / 1e6, "unit": "Mrays/s", "ms_per_step": per_step(seq) * 1e3,
                                  "trace_kernel_ms_rank0": seq["k_ms"]}}
         del seq, head
@@ -1085,6 +1161,7 @@ def main():
                 "collective": ("%s gather, %d rank(s)%s" % ("rccl" if rt.backend == "nccl" else rt.backend + " (development aid, ranks sharing a GPU)", world,
                                                            " (BHGEO_FORCE_COLLECTIVE)" if world == 1 else "")) if rt.collective else "none (single rank)",
                 "parallelism": f"one process per GPU (torch.distributed), {world} rank(s)",
+                "root_share": m["root_share"],
                 "launch": m["launch"],
             },
             "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64),

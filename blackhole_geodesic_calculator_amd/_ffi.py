@@ -267,7 +267,7 @@ def load():
     L.bhg_frame_device_image.restype = C.c_void_p
     L.bhg_frame_device_image.argtypes = [C.c_void_p]
     L.bhg_frame_rebalance.restype = C.c_int
-    L.bhg_frame_rebalance.argtypes = [C.c_void_p]
+    L.bhg_frame_rebalance.argtypes = [C.c_void_p, C.c_double]
     L.bhg_frame_stats.restype = C.c_int
     L.bhg_frame_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.bhg_frame_info.restype = C.c_int
@@ -277,8 +277,8 @@ def load():
     L.bhg_frame_last_ms.restype = C.c_int
     L.bhg_frame_last_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.bhg_deal_tiles.restype = C.c_int
-    L.bhg_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, C.POINTER(C.c_int64),
-                                 C.c_size_t, C.POINTER(C.c_size_t)]
+    L.bhg_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_double, C.c_int32,
+                                 C.POINTER(C.c_int64), C.c_size_t, C.POINTER(C.c_size_t)]
     if L.bhg_version() != ABI_VERSION:
         raise ImportError(f"libbhgeo ABI {L.bhg_version()} != expected {ABI_VERSION}")
     _lib = L
@@ -442,12 +442,13 @@ class RaySet:
         return out
 
 
-def deal_tiles(width, height, tile, world, rank, tile_cost=None, visit_by_cost=True):
+def deal_tiles(width, height, tile, world, rank, tile_cost=None, visit_by_cost=True, root_share=1.0):
     """bhg_deal_tiles: the pixel list of device `rank` of a library-owned frame (host logic, no GPU needed).
-    tile_cost: None or one figure per tile, row-major over the tile grid."""
+    tile_cost: None or one figure per tile, row-major over the tile grid; root_share: rank 0's part of an equal share."""
     n = C.c_size_t()
     tc = None if tile_cost is None else np.ascontiguousarray(tile_cost, dtype=np.float64).reshape(-1)
-    args = (int(width), int(height), int(tile), int(world), None if tc is None else _np_dp(tc), 1 if visit_by_cost else 0, int(rank))
+    args = (int(width), int(height), int(tile), int(world), None if tc is None else _np_dp(tc), 1 if visit_by_cost else 0,
+            float(root_share), int(rank))
     _check(load().bhg_deal_tiles(*args, None, 0, C.byref(n)))
     px = np.empty(n.value, dtype=np.int64)
     _check(load().bhg_deal_tiles(*args, px.ctypes.data_as(C.POINTER(C.c_int64)), px.size, C.byref(n)))
@@ -549,8 +550,10 @@ class Frame:
     def device_image(self) -> int:
         return load().bhg_frame_device_image(self._h) or 0
 
-    def rebalance(self):
-        _check(load().bhg_frame_rebalance(self._h))
+    def rebalance(self, root_share=1.0):
+        """Re-deal the tiles by the last render's measured cost; root_share < 1 gives the first device -- which also
+        receives the gather and assembles the frame -- that part of an equal share."""
+        _check(load().bhg_frame_rebalance(self._h, float(root_share)))
 
     def stats(self):
         out = (C.c_uint64 * 4)()

@@ -183,6 +183,7 @@ struct bhg_frame {
     size_t pin_bytes = 0;
     std::vector<double> tile_cost;  // measured attempted steps per tile of the last render (bhg_frame_rebalance)
     bool dealt_by_cost = false;
+    double root_share = 1.0;        // part of an equal share the first device is dealt (bhg_frame_rebalance)
     bool rendered = false;
     bool profiling = false;
     std::vector<hipEvent_t> ev_root;   // around the root's gather + assembly (profiling)
@@ -199,14 +200,23 @@ namespace {
 // (longest-processing-time-first across devices) -- and, visit_by_cost, each device visits its tiles longest first (a
 // shard's short launch wants its long rays early; over a whole frame on one device row-major measures 1 % faster,
 // DESIGN.md section 5).
-void deal_tiles_into(int W, int H, int T, int world, const double *cost, bool visit_by_cost, std::vector<std::vector<int64_t>> &out)
+// root_share in (0, 1): device 0 -- the frame's owner, which also receives the gather and assembles the frame -- sits out
+// a fraction 1 - root_share of the dealing rounds (evenly spread), i.e. is dealt that share of an equal part (dist.py's
+// deal_sequence, restated); only with a cost ranking.
+void deal_tiles_into(int W, int H, int T, int world, const double *cost, bool visit_by_cost, double root_share,
+                     std::vector<std::vector<int64_t>> &out)
 {
     const int tx = (W + T - 1) / T, ty = (H + T - 1) / T, nt = tx * ty;
     std::vector<int> owner(nt), order(nt);
     std::iota(order.begin(), order.end(), 0);
     if (cost) {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-        for (int i = 0; i < nt; i++) owner[order[i]] = i % world;
+        const double q = world > 1 ? std::min(std::max(1.0 - root_share, 0.0), 1.0) : 0.0;
+        int i = 0;
+        for (long r = 0; i < nt; r++) {
+            const bool skip = (long)((double)(r + 1) * q) > (long)((double)r * q);
+            for (int k = skip ? 1 : 0; k < world && i < nt; k++) owner[order[i++]] = k;
+        }
     } else {
         for (int t = 0; t < nt; t++) owner[t] = (t % tx + t / tx) % world;
     }
@@ -227,7 +237,7 @@ void deal_tiles(bhg_frame *f)
     const int nt = ((W + T - 1) / T) * ((H + T - 1) / T);
     const bool by_cost = f->dealt_by_cost && (int)f->tile_cost.size() == nt;
     std::vector<std::vector<int64_t>> px;
-    deal_tiles_into(W, H, T, world, by_cost ? f->tile_cost.data() : nullptr, world > 1, px);
+    deal_tiles_into(W, H, T, world, by_cost ? f->tile_cost.data() : nullptr, world > 1, f->root_share, px);
     f->pmax = 0;
     for (size_t r = 0; r < f->sh.size(); r++) {
         Shard &s = f->sh[r];
@@ -396,12 +406,12 @@ void destroy_frame(bhg_frame *f)
 extern "C" {
 
 int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, const double *tile_cost, int32_t visit_by_cost,
-                   int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out)
+                   double root_share, int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out)
 {
-    if (width <= 0 || height <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world || !n_out)
+    if (width <= 0 || height <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world || !n_out || !(root_share > 0.0 && root_share <= 1.0))
         return fail(BHG_E_INVALID, "bad argument");
     std::vector<std::vector<int64_t>> px;
-    deal_tiles_into(width, height, tile, world, tile_cost, visit_by_cost != 0, px);
+    deal_tiles_into(width, height, tile, world, tile_cost, visit_by_cost != 0, root_share, px);
     const auto &mine = px[(size_t)rank];
     *n_out = mine.size();
     if (pixels) {
@@ -719,12 +729,16 @@ int bhg_frame_stats(bhg_frame *f, uint64_t out[4])
     return BHG_OK;
 }
 
-int bhg_frame_rebalance(bhg_frame *f)
+int bhg_frame_rebalance(bhg_frame *f, double root_share)
 {
+    if (!f) return fail(BHG_E_INVALID, "frame is NULL");
+    if (root_share == 0.0) root_share = 1.0;
+    if (!(root_share > 0.0 && root_share <= 1.0)) return fail(BHG_E_INVALID, "root_share must be in (0, 1] (0 = 1)");
     uint64_t st[4];
     BHG_TRY(bhg_frame_stats(f, st));   // (fills tile_cost from the last render's attempted steps)
     DeviceScope scope;
     f->dealt_by_cost = true;
+    f->root_share = root_share;
     deal_tiles(f);
     return build_root(f);
 }

@@ -21,6 +21,27 @@ def _tile_costs(width, height, tile, tile_cost):
     return np.array([tile_cost((x + 0.5) * tile, (y + 0.5) * tile) for y, x in zip(ids // tx, ids % tx)], dtype=np.float64)
 
 
+def deal_sequence(n_tiles: int, world: int, root_share: float = 1.0) -> np.ndarray:
+    """The ranks the tiles of a cost ranking are dealt to, in ranking order: rounds of one tile per rank -- and, with
+    root_share < 1, rank 0 sits out a fraction 1 - root_share of the rounds (evenly spread, Bresenham fashion), so that
+    it ends up with root_share of an equal part, the others with correspondingly more.  Rank 0 is the frame's owner: on
+    top of its shard it receives the gather and assembles the frame, and a smaller shard lets all ranks finish
+    together (bench.py measures the assembly time and derives the share)."""
+    world = int(world)
+    q = min(max(1.0 - float(root_share), 0.0), 1.0) if world > 1 else 0.0
+    seq = np.empty(int(n_tiles), dtype=np.int64)
+    i = r = 0
+    while i < n_tiles:
+        skip = int((r + 1) * q) > int(r * q)
+        for k in range(1 if skip else 0, world):
+            if i >= n_tiles:
+                break
+            seq[i] = k
+            i += 1
+        r += 1
+    return seq
+
+
 def tile_owner(width: int, height: int, tile: int, world: int, tile_cost=None) -> np.ndarray:
     """Owner rank of every tile (row-major over the tile grid).
 
@@ -30,14 +51,16 @@ def tile_owner(width: int, height: int, tile: int, world: int, tile_cost=None) -
     With tile_cost(cx, cy) -> float (expected work of the tile centred there): the tiles are sorted by decreasing
     cost (stable) and dealt round-robin in THAT order, so every rank gets one of each `world` consecutive tiles
     of the cost ranking -- longest-processing-time-first across ranks.  A thin ring of expensive tiles (the
-    shadow edge) then spreads to within one tile per rank, where any fixed lattice leaves +-10 % at 8 ranks."""
+    shadow edge) then spreads to within one tile per rank, where any fixed lattice leaves +-10 % at 8 ranks.
+    An attribute tile_cost.root_share in (0, 1) deals rank 0 that share of an equal part (deal_sequence)."""
     tx, ty = tile_grid(width, height, tile)
     ids = np.arange(tx * ty, dtype=np.int64)
     if tile_cost is None:
         return (ids % tx + ids // tx) % int(world)
     order = np.argsort(-_tile_costs(width, height, tile, tile_cost), kind="stable")
     own = np.empty(tx * ty, dtype=np.int64)
-    own[order] = np.arange(tx * ty, dtype=np.int64) % int(world)
+    # (tile_cost.root_share < 1: rank 0 -- the frame's owner -- is dealt a smaller part, see deal_sequence)
+    own[order] = deal_sequence(tx * ty, world, getattr(tile_cost, "root_share", 1.0))
     return own
 
 

@@ -341,8 +341,11 @@ int bhg_frame_set_scene(bhg_frame *frame, const bhg_frame_scene *scene);
 int bhg_frame_render(bhg_frame *frame, const bhg_params *p, float *rgba_host);
 int bhg_frame_synchronize(bhg_frame *frame);
 const float *bhg_frame_device_image(bhg_frame *frame); /* device address (first listed device) of the last image */
-/* Re-deal the tiles by the measured cost of the last render (see above); the next render regenerates the rays. */
-int bhg_frame_rebalance(bhg_frame *frame);
+/* Re-deal the tiles by the measured cost of the last render (see above); the next render regenerates the rays.
+ * root_share in (0, 1] (0 = 1): the part of an equal share the FIRST device is dealt -- it also receives the gather and
+ * assembles the frame, and with a smaller shard all devices finish together (e.g. 1 - (N-1)/N * t_root / t_trace from
+ * bhg_frame_last_ms). */
+int bhg_frame_rebalance(bhg_frame *frame, double root_share);
 /* out = {rays, attempted steps, accepted steps, horizon rays} of the last render, summed over the devices (waits). */
 int bhg_frame_stats(bhg_frame *frame, uint64_t out[4]);
 /* out = {n_devices, gather mode in use (BHG_FRAME_GATHER_COPY / _RCCL), largest shard in pixels, smallest shard,
@@ -357,10 +360,11 @@ int bhg_frame_set_profiling(bhg_frame *frame, int enable);
 int bhg_frame_last_ms(bhg_frame *frame, float *trace_ms, float *root_ms);
 /* The frame's tile dealing as a function of its own (host only, no device needed): the flat pixel ids y * width + x
  * of device `rank` of `world`, tile after tile, row-major inside a tile.  tile_cost NULL: cyclic dealing; else one
- * figure per tile (row-major over the tile grid): dealt by cost ranking and, visit_by_cost != 0, visited longest first.
- * pixels NULL: only the count is returned in *n_out. */
+ * figure per tile (row-major over the tile grid): dealt by cost ranking (root_share in (0, 1]: rank 0's part of an equal
+ * share, see bhg_frame_rebalance) and, visit_by_cost != 0, visited longest first.  pixels NULL: only the count is
+ * returned in *n_out. */
 int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, const double *tile_cost, int32_t visit_by_cost,
-                   int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out);
+                   double root_share, int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out);
 
 /* Acceleration probe: acc[n][3] = -Gamma^i_{mu nu} k^mu k^nu at (x[n][3], k[n][3]); host buffers.
  * Lets tests compare the device RHS with the oracle's term by term.  With rhs_form = BHG_RHS_KERR_BL the triples

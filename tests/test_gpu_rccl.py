@@ -108,6 +108,8 @@ def test_bench_self_launches_two_ranks_when_started_without_a_launcher():
     assert line["strong"]["value"] > 0 and line["strong"]["scaling"] == "strong"
     # the sharded path's headline has two frames in flight per rank; the sequential figure sits beside it
     assert line["strong"]["frames_in_flight"] == 2 and line["strong"]["sequential"]["value"] > 0
+    # rank 0 -- the frame's owner -- is dealt a smaller shard, derived from measured times
+    assert 0.5 <= line["config"]["root_share"] <= 1.0 and 0.5 <= line["strong"]["root_share"] <= 1.0
     assert "2 rank" in line["config"]["collective"]
 
 
@@ -138,6 +140,7 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     # rank 0's step: the shard's slab through a 1-rank gather + the root's assembly of the whole 2-rank frame
     assert "rank0_error" not in line["strong_predicted"], line["strong_predicted"].get("rank0_error")
     assert 0.1 < sh["efficiency_rank0"] < 1.5 and sh["ms_per_step_rank0"] >= 0.8 * sh["ms_per_step"]
+    assert 0.5 <= sh["root_share"] <= 1.0 and sh["efficiency_rank0_equal_shares"] > 0
 
 
 def test_bench_orbit_two_ranks_reports_whole_frame_sharding_beside_the_tile_figure():

@@ -159,6 +159,22 @@ def test_frame_object_host_side():
                 assert np.array_equal(_ffi.deal_tiles(W, H, T, world, r, table, visit == "cost"),
                                       bdist.rank_pixels(W, H, T, r, world, tile_cost=tcost))
         assert np.all(seen == 1)                                       # a partition of the frame
+        # rank 0 dealt a smaller part (it also assembles the frame): still a partition, the same lists from C++ and Python
+        for share in (0.9, 0.5):
+            tcost.visit, tcost.root_share = "cost", share
+            seen[:] = 0
+            sizes = []
+            for r in range(world):
+                a = _ffi.deal_tiles(W, H, T, world, r, table, True, share)
+                assert np.array_equal(a, bdist.rank_pixels(W, H, T, r, world, tile_cost=tcost))
+                seen[a] += 1
+                sizes.append(len(a))
+            assert np.all(seen == 1) and (tx * ty < 4 * world or sizes[0] <= max(sizes[1:]))
+        del tcost.root_share
+    seq = bdist.deal_sequence(8000, 8, 0.9)
+    counts = np.bincount(seq, minlength=8)
+    assert abs(counts[0] / counts[1:].mean() - 0.9) < 0.01 and counts[1:].max() - counts[1:].min() <= 1
+    assert np.array_equal(bdist.deal_sequence(20, 4, 1.0), np.arange(20) % 4)
     for bad in (dict(devices=[]), dict(devices=[0], gather=9), dict(devices=[0], width=0)):
         with pytest.raises(_ffi.BhgError) as ei:
             _ffi.Frame(bad["devices"], bad.get("width", 8), 8, 1, gather=bad.get("gather", _ffi.GATHER_AUTO))
