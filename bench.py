@@ -118,6 +118,10 @@ def parse(argv=None):
                     help="N > 1: what rank 0 -- which also receives the gather and assembles the frame -- is dealt, as a multiple of "
                          "what every other rank is dealt; auto = from the assembly kernel's and a shard frame's measured times, so "
                          "that all ranks finish together; 1 = equal shares")
+    ap.add_argument("--frame-gather", choices=["auto", "copy", "rccl", "peer"], default="auto",
+                    help="--single-process: how the devices' pixels reach the first device (bhg_frame_create's gather mode): auto = RCCL "
+                         "single-process mode for distinct devices else device-to-device copies; peer = no exchange, every device's "
+                         "shade kernel stores straight into the first device's image over xGMI")
     ap.add_argument("--shard", choices=["tiles", "frames", "both"], default="both",
                     help="orbit workload, N > 1: tiles = every frame's tiles over all ranks + one gather per frame (the headline); "
                          "frames = whole frames dealt round-robin to the ranks, no tail, one gather at the end; both = the second "
@@ -1228,6 +1232,9 @@ def main_single_process(a):
     N = len(devices)
     sky = synthetic_sky(2048, 1024)
     disk_tex = synthetic_sky(1024, 128, seed=3) if a.workload == "disk" else None
+    gmode = {"auto": _ffi.GATHER_AUTO, "copy": _ffi.GATHER_COPY, "rccl": _ffi.GATHER_RCCL, "peer": _ffi.GATHER_PEER}[a.frame_gather]
+
+    shares = []
 
     def build(nx, ny):
         W, H, S = a.width * nx, a.height * ny, a.samples
@@ -1236,11 +1243,11 @@ def main_single_process(a):
         if a.workload == "disk":
             for cam in wl.disk_cameras():
                 f = _ffi.Frame(devices, W, H, S, fov_x=0.9, fov_y=0.9, origin=cam["origin"], rot=euler_xyz_matrix(cam["rotation_euler"]),
-                               jitter=jit, tile=a.tile)
+                               jitter=jit, tile=a.tile, gather=gmode)
                 f.set_scene(sky, disk=DISK, disk_tex=disk_tex)
                 frames.append(f)
         else:
-            f = _ffi.Frame(devices, W, H, S, fov_x=0.6, fov_y=0.6 * nx / ny, origin=CAM, jitter=jit, tile=a.tile)
+            f = _ffi.Frame(devices, W, H, S, fov_x=0.6, fov_y=0.6 * nx / ny, origin=CAM, jitter=jit, tile=a.tile, gather=gmode)
             if a.workload == "orbit":
                 sp, rgb, lamps = wl.orbit_scene(0)
                 f.set_scene(sky, spheres=sp, sphere_rgb=rgb, lamps=lamps)
@@ -1249,10 +1256,19 @@ def main_single_process(a):
             frames.append(f)
         del jit
         if a.lpt and a.order != "none" and N > 1:
-            # one untimed calibration render prices the tiles; they are then re-dealt longest-processing-time-first
+            # one untimed, profiled calibration render prices the tiles and times the devices' traces and the first device's
+            # frame end; the tiles are then re-dealt longest-processing-time-first, the first device a smaller part
+            # (rho = (N T - (N - 1) t_root) / (N T + t_root), see measure()) unless the frame end is free (peer stores)
             for f in frames:
+                f.set_profiling(True)
                 f.render(wl.params, to_host=False)
-                f.rebalance()
+                tr, t_root = f.last_ms()
+                f.set_profiling(False)
+                T_ = float(np.mean(tr))
+                rho = 1.0 if a.root_share == "1" else (float(a.root_share) if a.root_share != "auto" else
+                                                       min(1.0, max(0.5, (N * T_ - (N - 1) * t_root) / (N * T_ + t_root))))
+                f.rebalance(root_share=rho)
+                shares.append(rho)
         return frames, W, H, S
 
     def timed(frames):
@@ -1338,6 +1354,7 @@ def main_single_process(a):
             "collective": (f"{m['info']['gather']} (single-process mode), {N} device(s)") if N > 1 else "none (single device)",
             "parallelism": f"ONE process, {N} device(s) {devices}: the library-owned frame (bhg_frame_*), no torch.distributed",
             "root_gather_assembly_ms": m["root_ms"],
+            "root_share": shares[0] if shares else None,
             "trace_call_ms_per_device": [float(v) for v in m["call_ms"]],
         },
         "roofline": roofline_block(wl, per_dev_steps, k_ms, k_ms, m["rays"] // N, bytes_per_ray, traffic,

@@ -51,7 +51,7 @@ EXPORTS = (
     "bhg_frame_last_ms", "bhg_deal_tiles",
 )
 
-GATHER_AUTO, GATHER_COPY, GATHER_RCCL = 0, 1, 2
+GATHER_AUTO, GATHER_COPY, GATHER_RCCL, GATHER_PEER = 0, 1, 2, 3
 
 
 class Camera(C.Structure):
@@ -563,7 +563,7 @@ class Frame:
     def info(self):
         out = (C.c_int64 * 8)()
         _check(load().bhg_frame_info(self._h, out))
-        return {"n_devices": int(out[0]), "gather": {GATHER_COPY: "copy", GATHER_RCCL: "rccl"}.get(int(out[1]), str(out[1])),
+        return {"n_devices": int(out[0]), "gather": {GATHER_COPY: "copy", GATHER_RCCL: "rccl", GATHER_PEER: "peer"}.get(int(out[1]), str(out[1])),
                 "largest_shard_pixels": int(out[2]), "smallest_shard_pixels": int(out[3]), "tile": int(out[4]),
                 "dealt_by_measured_cost": bool(out[5]), "renders": int(out[6]), "directions_only": bool(out[7])}
 

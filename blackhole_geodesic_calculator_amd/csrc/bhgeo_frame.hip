@@ -325,7 +325,7 @@ int build_root(bhg_frame *f)
         HIP_TRY(hipEventCreateWithFlags(&f->assembled, hipEventDisableTiming));
     }
     // (a ONE-device frame in RCCL mode sends its slab to itself: the whole gather path on a single GPU, for tests)
-    if (world > 1 || f->gather == BHG_FRAME_GATHER_RCCL) {
+    if ((world > 1 && f->gather != BHG_FRAME_GATHER_PEER) || f->gather == BHG_FRAME_GATHER_RCCL) {
         BHG_TRY(f->recv.ensure(root, world * f->pmax * 4 * sizeof(float)));
         BHG_TRY(f->perm.ensure(root, HW * sizeof(int64_t)));
         std::vector<int64_t> perm(HW);
@@ -430,7 +430,8 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
     if (!cam) return fail(BHG_E_INVALID, "camera is NULL");
     if (cam->width <= 0 || cam->height <= 0 || cam->samples <= 0) return fail(BHG_E_INVALID, "width, height, samples must be > 0");
     if (tile <= 0) tile = 32;
-    if (gather != BHG_FRAME_GATHER_AUTO && gather != BHG_FRAME_GATHER_COPY && gather != BHG_FRAME_GATHER_RCCL)
+    if (gather != BHG_FRAME_GATHER_AUTO && gather != BHG_FRAME_GATHER_COPY && gather != BHG_FRAME_GATHER_RCCL &&
+        gather != BHG_FRAME_GATHER_PEER)
         return fail(BHG_E_INVALID, "unknown gather mode");
     const size_t HW = (size_t)cam->width * (size_t)cam->height;
     if (HW * (size_t)cam->samples > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays in the frame");
@@ -481,14 +482,19 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
             for (int i = 0; i < n_devices; i++) f->sh[i].comm = comms[i];
         }
     }
-    if (rc == BHG_OK && f->gather == BHG_FRAME_GATHER_COPY && n_devices > 1 && distinct) {
-        // peer access for the copies (best effort: without it the runtime stages through the host)
-        for (int i = 1; i < n_devices; i++) {
+    if (rc == BHG_OK && gather == BHG_FRAME_GATHER_PEER) f->gather = BHG_FRAME_GATHER_PEER;
+    if (rc == BHG_OK && (f->gather == BHG_FRAME_GATHER_COPY || f->gather == BHG_FRAME_GATHER_PEER) && n_devices > 1) {
+        // peer access to the first device: for the copies best effort (without it the runtime stages through the host),
+        // for the peer stores a must
+        for (int i = 1; i < n_devices && rc == BHG_OK; i++) {
+            if (devices[i] == devices[0]) continue;
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
                 (void)hipSetDevice(devices[i]);
                 hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
                 if (e != hipSuccess) (void)hipGetLastError();   // (already enabled is fine)
+            } else if (f->gather == BHG_FRAME_GATHER_PEER) {
+                rc = fail(BHG_E_HIP, "BHG_FRAME_GATHER_PEER: a listed device cannot access the first device's memory");
             }
         }
     }
@@ -560,7 +566,8 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
     const bool has_obj = f->scene.n_spheres > 0, has_disk = f->scene.disk_r_out > 0.0;
     const bool dir_only = !has_obj && !has_disk;
     const bool loopback = world == 1 && f->gather == BHG_FRAME_GATHER_RCCL;   // (see build_root)
-    const bool gathered = world > 1 || loopback;
+    const bool peer = f->gather == BHG_FRAME_GATHER_PEER;     // every device's shade stores straight into the image
+    const bool gathered = (world > 1 && !peer) || loopback;
     Shard &root = f->sh[0];
     bhg_params prm = *p;
     if (prm.order_blocks == 0 && S > 1) prm.order_blocks = (uint32_t)S;   // the rays are S blocks of P (sample-major)
@@ -617,6 +624,19 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
             f->ev_root.resize(2, nullptr);
             for (auto &e : f->ev_root) HIP_TRY(hipEventCreate(&e));
         }
+    }
+    if (peer && world > 1) {
+        // no exchange at all: the image is complete when every device's shade kernel has retired
+        for (size_t r = 1; r < world; r++) {
+            if (f->sh[r].P == 0) continue;
+            HIP_TRY(hipSetDevice(f->sh[r].device));
+            HIP_TRY(hipEventRecord(f->sh[r].done, f->sh[r].stream));
+        }
+        HIP_TRY(hipSetDevice(root.device));
+        if (f->profiling) HIP_TRY(hipEventRecord(f->ev_root[0], root.stream));
+        for (size_t r = 1; r < world; r++)
+            if (f->sh[r].P) HIP_TRY(hipStreamWaitEvent(root.stream, f->sh[r].done, 0));
+        if (f->profiling) HIP_TRY(hipEventRecord(f->ev_root[1], root.stream));
     }
     if (gathered) {
         const size_t slab_floats = f->pmax * 4;

@@ -306,6 +306,10 @@ int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const 
  *             else device-to-device copies (hipMemcpyPeerAsync over xGMI; same-device copies for a repeated device);
  *             _COPY / _RCCL force one (RCCL with a repeated device is BHG_E_INVALID; with ONE device it sends the
  *             frame's slab to itself -- the whole gather path on a single GPU, for tests).
+ *             BHG_FRAME_GATHER_PEER (never chosen by AUTO): no exchange at all -- every device's shade kernel stores its
+ *             pixels straight into the first device's image, in frame order, over xGMI peer access (16-byte stores in
+ *             512-byte runs per tile row); no slabs, no gather, no assembly kernel, and the first device has no more to
+ *             do than the others.  Needs peer access from every listed device to the first (else BHG_E_HIP).
  * Tiles are dealt cyclically ((tile_x + tile_y) mod n_devices) until bhg_frame_rebalance() re-deals them by the
  * MEASURED cost of the last render (attempted steps per tile, longest-processing-time-first across devices, each
  * device visiting its tiles longest first): the engine renders the same view sample after sample and frame after
@@ -314,6 +318,7 @@ int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const 
 #define BHG_FRAME_GATHER_AUTO 0
 #define BHG_FRAME_GATHER_COPY 1
 #define BHG_FRAME_GATHER_RCCL 2
+#define BHG_FRAME_GATHER_PEER 3
 typedef struct bhg_frame bhg_frame;
 /* The scene of a frame; everything lives on the HOST and is copied by bhg_frame_set_scene (images are uploaded to
  * every device on the next render).  Members as in bhg_scene.  sky = NULL keeps the current sky image (the first call

@@ -127,6 +127,32 @@ def test_disk_and_object_frames_are_bit_identical_to_device_frame(ctx, devices):
     fr.close()
 
 
+def test_peer_store_frame_end_is_bit_identical(ctx):
+    """BHG_FRAME_GATHER_PEER: every context's shade kernel stores its pixels straight into the first device's image (no
+    slab, no gather, no assembly) -- here with three contexts of the one GPU; sky and scene frames, the same images."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    W, H, S = 160, 96, 2
+    sky = synthetic_sky(256, 128)
+    p = _params(r_s=1.0, lambda_end=60.0, r_exit=40.0)
+    sph, rgb, lamps = [[2.5, 1.0, 10.0, 1.5]], [[1.0, 0.8, 0.6]], [[10.0, 10.0, 30.0, 30.0]]
+    imgs = {}
+    for mode in (_ffi.GATHER_COPY, _ffi.GATHER_PEER):
+        fr = _frame([0, 0, 0], W, H, S, gather=mode)
+        fr.set_scene(sky)
+        a = fr.render(p)
+        fr.set_scene(None, spheres=sph, sphere_rgb=rgb, lamps=lamps)
+        b = fr.render(p)
+        fr.rebalance(root_share=0.8)
+        c = fr.render(p)
+        assert fr.info()["gather"] == ("peer" if mode == _ffi.GATHER_PEER else "copy")
+        imgs[mode] = (a, b, c)
+        fr.close()
+    for x, y in zip(imgs[_ffi.GATHER_COPY], imgs[_ffi.GATHER_PEER]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(imgs[_ffi.GATHER_PEER][1], imgs[_ffi.GATHER_PEER][2]) and not np.array_equal(imgs[_ffi.GATHER_PEER][0], imgs[_ffi.GATHER_PEER][1])
+
+
 def test_frame_argument_checks(ctx):
     from blackhole_geodesic_calculator_amd import _ffi
     from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
