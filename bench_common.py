@@ -1,0 +1,275 @@
+"""bench_common.py -- what bench.py and bench_figures.py share: the measurement constants, the Workload (what is traced:
+parameters, scenes, the strings of the JSON line), the Runtime (this process's place in the job), the two-frames-in-flight
+lanes, the roofline block.  See bench.py."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic flop per attempted ray-step: 6 RHS x 44 + 390 bookkeeping
+# Kerr (config 5): the generated Boyer-Lindquist RHS is 90 operations (tools/gen_kerr_rhs.py: the structured
+# omega / chi form; the sympy-CSE'd contraction it is checked against has 127), sin / cos / each reciprocal counted as one
+# -> 6 x 90 + 390 and 4 x 90 + 78
+FLOP_PER_STEP = {("dp54", "christoffel"): 654, ("dp54", "reduced"): 468, ("dp54", "kerr"): 930,
+                 ("rk4", "christoffel"): 254, ("rk4", "reduced"): 130, ("rk4", "kerr"): 438}
+# What the kernels' own evaluation order of the Christoffel form amounts to under the same counting rules (mul / add 1, FMA 2,
+# rcp / rsqrt 1): 35 per RHS evaluation + 1 (r at the step's end) instead of SURVEY's 44 -- reported beside the
+# accounting figure as roofline.flop_per_ray_step_executed / frac_executed, never instead of it
+FLOP_PER_STEP_EXECUTED = {("dp54", "christoffel"): 6 * 35 + 1 + 390, ("rk4", "christoffel"): 4 * 35 + 1 + 78}
+PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector fp64: 256 CU x 128 flop/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+BYTES_PER_RAY = 24 + 48 + 1 + 4 + 4  # k0 in; end state, flag, n_steps, n_accepted out
+BYTES_PER_RAY_DIR = 24 + 24 + 1 + 4 + 4  # direction-only traces (sky frames): the direction half of the end state
+
+EV_EVERY = 4   # HIP event pairs around the trace call of every 4th timed step (an event pair costs 7-9 us of stream time)
+DISK = (4.5, 10.5)   # 0.15 .. 0.35 x ratio 30 (tests/golden disk set; LimitedRelativisticRenderEngine.py:283-286)
+CAM = np.array([1e-4, 0.0, 30.0])
+DISK_INCLINATIONS_DEG = [85.0, 80.0, 60.0, 30.0, 5.0]
+
+
+def grid_for(n):
+    nx = n
+    ny = 1
+    while nx % 2 == 0 and nx // 2 >= ny * 2:
+        nx //= 2
+        ny *= 2
+    return nx, ny
+
+
+class Workload:
+    """The configuration BASELINE.json names, as parameters, scenes and the strings of the JSON line."""
+
+    def __init__(self, a):
+        from blackhole_geodesic_calculator_amd import _ffi
+        self.a = a
+        self.method = "rk4" if a.regime == "rk4" else "dp54"
+        # oracle-style keyword set; the same dict configures the CPU baseline
+        self.okw = dict(r_s=1.0, lambda_end=50.0, max_step=(0.1 if a.regime == "fine" else np.inf), rtol=1e-3, atol=1e-6,
+                        h_fixed=0.1, method=1 if self.method == "rk4" else 0, rhs_form={"reduced": 1, "kerr": 2}.get(a.rhs, 0),
+                        spin=0.45 if a.rhs == "kerr" else 0.0)
+        if a.workload == "disk":
+            self.okw.update(lambda_end=80.0, r_exit=40.0, disk_r_in=DISK[0], disk_r_out=DISK[1])
+        elif a.workload == "orbit":
+            self.okw.update(lambda_end=80.0, r_exit=40.0)
+        self.params = _ffi.make_params(**self.okw)
+        self.flop = FLOP_PER_STEP[(self.method, a.rhs)]
+        self.flop_executed = FLOP_PER_STEP_EXECUTED.get((self.method, a.rhs), self.flop)
+        self.metric_name = a.rhs == "kerr" and "Kerr" or "Schwarzschild"
+
+    @staticmethod
+    def orbit_scene(i):
+        # config 4: a sphere of radius 1.5 on a circular orbit of radius 8 r_s, inclined 20 degrees to the line of
+        # sight plane, one revolution per 100 frames; lit by one lamp beside the camera
+        ph = 2.0 * np.pi * (i % 100) / 100.0
+        tilt = np.radians(70.0)
+        c = 8.0 * np.array([np.cos(ph), np.sin(ph) * np.cos(tilt), np.sin(ph) * np.sin(tilt)])
+        return [[c[0], c[1], c[2], 1.5]], [[1.0, 0.85, 0.7]], [[10.0, 10.0, 30.0, 30.0]]
+
+    @staticmethod
+    def disk_cameras():
+        # five inclinations of a camera at r = 30 looking at the hole (rotation about y by the inclination)
+        return [dict(origin=(30 * np.sin(i), 0.0, 30 * np.cos(i)), rotation_euler=(0.0, i, 0.0)) for i in np.radians(DISK_INCLINATIONS_DEG)]
+
+    def shadow_edge_cost(self, W, H):
+        """tile_cost(cx, cy): steps per ray peak at the shadow edge (impact parameter b_c = 2.6 r_s -> radius
+        b_c / |cam| / fov * width pixels around the frame centre); the model only holds for the plain frame."""
+        def tile_cost(cx, cy):
+            ax, ay = 0.6 * (cx - W / 2) / W, 0.6 * (cy - H / 2) / H
+            return -abs(np.hypot(ax, ay) - 2.598 / 30.0)
+        return tile_cost
+
+    def metric(self):
+        a = self.a
+        if a.workload == "frame":
+            return f"Mrays/s (null geodesics traced to curve_end or horizon), 1024x1024x5 {self.metric_name} frame per GPU"
+        return {"disk": f"Mrays/s, 1024x1024 {self.metric_name} + thin disk, 5 camera inclinations per step",
+                "orbit": "Mrays/s, 2048x2048x16 orbiting-sphere animation frame"}[a.workload]
+
+    def describe(self, W, H, S, world):
+        a = self.a
+        hole = "Kerr a/M=0.9" if a.rhs == "kerr" else "Schwarzschild"
+        if a.workload == "frame":
+            return (f"BASELINE.json configs[{4 if a.rhs == 'kerr' else 1}]: {a.width}x{a.height} x{S} multisample {hole} frame per GPU "
+                    f"(frame {W}x{H} over {world} GPU(s)), camera (1e-4,0,30), fov 0.6, r_s=1, curve_end=50")
+        if a.workload == "disk":
+            return (f"BASELINE.json configs[2]: {a.width}x{a.height} x{S} {hole} + thin disk {DISK[0]}..{DISK[1]} r_s, camera r=30 at "
+                    f"inclinations 85/80/60/30/5 deg (5 frames per step, one trace call with per-ray origins, shaded per frame), "
+                    f"fov 0.9, exit sphere 40, curve_end 80; frame {W}x{H} over {world} GPU(s)")
+        return (f"BASELINE.json configs[3]: {W}x{H} x{S} frame of the orbiting-sphere animation (sphere radius 1.5 on an r=8 orbit, "
+                f"new position every step, lamp-lit), tiles sharded over {world} GPU(s); camera (1e-4,0,30), fov 0.6, exit sphere 40, "
+                f"curve_end 80")
+
+    def tile_order_text(self, visit):
+        a = self.a
+        if not a.lpt:
+            return "row-major"
+        if a.order == "measured":
+            return "longest first by the attempted steps of an untimed calibration trace"
+        if a.order == "model" and a.workload == "frame":
+            return "dealt by the shadow-edge model, visited " + ("row-major" if visit == "row" else "longest first")
+        return "row-major"
+
+
+class Runtime:
+    """This process's place in the job: rank / world, the process group (if any), its library context."""
+
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # development aid: BHGEO_BENCH_BACKEND=gloo exercises the N > 1 code path with several ranks on ONE GPU
+        # (RCCL refuses two ranks per device); never used by the driver's runs
+        self.backend = os.environ.get("BHGEO_BENCH_BACKEND", "nccl")
+        if self.backend != "nccl":
+            self.local_rank = self.local_rank % max(torch.cuda.device_count(), 1)
+        if self.world != a.gpus and self.world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        torch.cuda.set_device(self.local_rank)
+        self.force_collective = os.environ.get("BHGEO_FORCE_COLLECTIVE", "0") == "1"
+        self.group_up = False
+        if self.world > 1 or self.force_collective:
+            self.init_group()
+        self.collective = self.world > 1 or self.force_collective
+        from blackhole_geodesic_calculator_amd import _ffi
+        self.ctx = _ffi.Context(self.local_rank)
+        self.stream = torch.cuda.current_stream()
+
+    def init_group(self):
+        """The process group (RCCL, or gloo as the development aid); a one-rank group for a single process."""
+        if self.group_up:
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if self.backend == "nccl":
+            self.dist.init_process_group("nccl", device_id=self.torch.device("cuda", self.local_rank))
+        else:
+            self.dist.init_process_group(self.backend)
+        self.group_up = True
+
+    def close(self):
+        if self.group_up:
+            if self.world > 1:
+                self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.group_up = False
+
+    def assemble(self, slabs, perm, frame):   # rank 0, N > 1: slabs -> frame order in one kernel
+        self.ctx.assemble_frame_f32_device(slabs.data_ptr(), perm.data_ptr(), frame.shape[0], frame.data_ptr(),
+                                           stream=self.torch.cuda.current_stream().cuda_stream)
+
+
+def twin_of(fr_, ctx2):
+    """A second DeviceFrame over the SAME rays (shared d_k0) with result buffers of its own, on another library
+    context (its own work counters): consecutive frames of an animation are independent, so frame i + 1 can be
+    traced on a second stream while frame i's last waves drain."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    n_ = fr_.n
+    buf = (fr_.d_k0, None if fr_.directions_only else torch.empty((n_, 6), dtype=torch.float64, device="cuda"),
+           torch.empty(n_, dtype=torch.uint8, device="cuda"), torch.empty(n_, dtype=torch.int32, device="cuda"),
+           torch.empty(n_, dtype=torch.int32, device="cuda"))
+    f2 = DeviceFrame(ctx2, fr_.W, fr_.H, fr_.S, fov_x=fr_.fov_x, fov_y=fr_.fov_y, origin=fr_.origin,
+                     pixels=None if fr_.d_pixels is None else fr_.d_pixels.cpu().numpy(), jitter=np.zeros(2), buffers=buf,
+                     directions_only=fr_.directions_only)
+    f2.d_sky, f2.sky_wh = fr_.d_sky, fr_.sky_wh
+    return f2
+
+
+class Lanes:
+    """[(frame, stream)] that consecutive steps alternate between.  One lane: the frame on the current stream.  Two: the
+    frame and its twin (same rays, own result buffers, own library context) on two streams of DIFFERENT priority -- two
+    streams of the same priority share one hardware queue on this ROCm build (rocprofv3 shows one queue id and strictly
+    serial kernels, the pair measures exactly like one stream); a stream of another priority gets a queue of its own, and
+    only then do the second frame's first waves start while the first frame's last ones drain."""
+
+    def __init__(self, fr, device, two):
+        import torch
+        from blackhole_geodesic_calculator_amd import _ffi
+        self.ctx2 = _ffi.Context(device) if two else None
+        if two:
+            self.lanes = [(fr, torch.cuda.Stream()), (twin_of(fr, self.ctx2), torch.cuda.Stream(priority=-1))]
+        else:
+            self.lanes = [(fr, torch.cuda.current_stream())]
+
+    def __len__(self):
+        return len(self.lanes)
+
+    def __getitem__(self, i):
+        return self.lanes[i % len(self.lanes)]
+
+    def close(self):
+        if self.ctx2 is not None:
+            self.ctx2.close()
+            self.ctx2 = None
+
+
+def ramp_clocks(run, seconds):
+    """Untimed frames until `seconds` of wall time have passed: the GPU's clocks take tens of milliseconds of load to
+    settle, and every secondary figure of the line starts after host-side work during which the GPU sat idle (a
+    K = 20 / W = 3 run read 5-10 % low without this)."""
+    import torch
+    t = time.perf_counter()
+    while seconds > 0 and time.perf_counter() - t < seconds:
+        run(4)
+        torch.cuda.synchronize()
+
+
+def traced_with_events(f, params, stream, sink):
+    """f.trace(params) between two HIP events recorded on the stream the library launches on."""
+    import torch
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    f.trace(params)
+    e1.record(stream)
+    sink.append((e0, e1))
+
+
+def roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64):
+    achieved_tf = ray_steps * wl.flop / (k_ms * 1e-3) / 1e12
+    return {
+        "bound": "valu_fp64",
+        "kernel": f"trace_{wl.method}_kernel<{wl.a.rhs}>: ONE launch per trace call integrates every ray to its end "
+                  f"(step loop + in-kernel event location and resumption)",
+        "achieved": achieved_tf,
+        "peak": PEAK_FP64_VALU_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS,
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        # wave-level VALU instructions the whole launch issues (SQ_INSTS_VALU) per 64 attempted ray-steps: step loop +
+        # setup + pop + events; the instruction-stream ceiling is F*64 / (2*64*this)
+        "valu_insts_per_64_ray_steps": valu_per_64,
+        "flop_per_ray_step": wl.flop,
+        "flop_per_ray_step_executed": wl.flop_executed,
+        "frac_executed": achieved_tf / PEAK_FP64_VALU_TFLOPS * wl.flop_executed / wl.flop,
+        "ray_steps_per_launch": ray_steps,
+        "kernel_ms": k_ms,
+        "trace_call_ms": call_ms,
+        "hbm_algorithmic_GBps": n * bytes_per_ray / (k_ms * 1e-3) / 1e9,
+        "hbm_frac": n * bytes_per_ray / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "algorithmic_bytes_per_ray": bytes_per_ray,
+    }
+
+
+def emit(out):
+    # the JSON line goes out LAST: RCCL writes a version banner through C stdio, which sits in libc's buffer
+    # (stdout is a pipe under the driver) until it is flushed -- flush it first
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
