@@ -6,9 +6,8 @@
 //     per-pixel multisample mean (sbuf += colour; buf = sbuf/(s+1), :242-250); rays that ended on the
 //     thin disk get the Limited engine's disk colour (LimitedRelativisticRenderEngine.py:427-436, :300),
 //     rays that ended on an object sphere the Lambert lamp sum of spacetime_hit (:356-363).
-// Both are HBM-bound element-wise kernels: coalesced loads/stores, no LDS needed -- the S
-// samples of a pixel are accumulated in registers in sample order (the reference's order), so
-// the result is deterministic; there is no cross-lane reduction to stage.
+// Ray generation is an HBM-bound element-wise kernel.  The shade kernel runs one thread per RAY and stages the S samples of
+// a pixel in LDS, where one thread sums them in sample order (the reference's order: the result is deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -191,61 +190,32 @@ __device__ __forceinline__ void object_colour(const ShadeArgs &A, const double *
     rgb[2] = A.sphere_rgb[j][2] * sum;
 }
 
-// One thread per pixel; samples accumulated in sample order (:242-250).  Rays are laid out
-// [S][P] so every load is coalesced across the pixels of a wavefront.
-__global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
+// The colour of ONE ray (sample s of pixel p): black for a horizon ray (:242-244), the disk's / an object's colour, or the
+// sky in its exit direction.
+__device__ __forceinline__ void ray_colour(const ShadeArgs &A, uint64_t i, uint8_t fl, double c0, double c1, double c2, double rgb[3])
 {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= A.n_pixels) return;
-    double acc[3] = {0.0, 0.0, 0.0};
-    // software pipeline: the next sample's flag and exit direction are in flight while this sample's
-    // acos / atan2 / texel gathers run (the samples of a pixel are n_pixels records apart)
-    // exit directions: the second half of the end records, or (direction-only traces of sky frames) an array of their own
-    const double *dsrc = A.dir ? A.dir : A.end + 3;
-    const uint64_t dstride = A.dir ? 3 : 6;
-    uint8_t fl_next = A.flags[p];
-    double dn0 = dsrc[p * dstride], dn1 = dsrc[p * dstride + 1], dn2 = dsrc[p * dstride + 2];
-    for (int s = 0; s < A.samples; s++) {
-        const uint64_t i = (uint64_t)s * A.n_pixels + p;
-        const uint8_t fl = fl_next;
-        const double c0 = dn0, c1 = dn1, c2 = dn2;
-        if (s + 1 < A.samples) {
-            const uint64_t in = i + A.n_pixels;
-            fl_next = A.flags[in];
-            dn0 = dsrc[in * dstride];
-            dn1 = dsrc[in * dstride + 1];
-            dn2 = dsrc[in * dstride + 2];
-        }
-        if (fl & BHG_FLAG_HIT_HORIZON_) continue;  // black (:242-244)
-        const double *e = A.end + i * 6;
-        if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0 && A.end) {
-            double rgb[3];
-            disk_colour(A, e, rgb);
-            acc[0] += rgb[0];
-            acc[1] += rgb[1];
-            acc[2] += rgb[2];
-            continue;
-        }
-        if (fl == BHG_FLAG_HIT_OBJECT_ && A.object_id && A.end) {
-            double rgb[3];
-            object_colour(A, e, (int)A.object_id[i], rgb);
-            acc[0] += rgb[0];
-            acc[1] += rgb[1];
-            acc[2] += rgb[2];
-            continue;
-        }
-        // theta = 1 - acos(d_z / |d|) / pi (:373), phi = atan2(d_y, d_x) / pi (:374); exit directions are not unit
-        // vectors (the Cam edition normalises, CamEdition.py:433-437) -- both angles as scale-free atan2's:
-        // acos(d_z / |d|) = atan2(sqrt(d_x^2 + d_y^2), d_z)
-        const double rho = sqrt(c0 * c0 + c1 * c1);
-        const double theta = 1.0 - atan2_fast(rho, c2) * 0.3183098861837907;
-        const double phi = atan2_fast(c1, c0) * 0.3183098861837907;
-        double rgb[3];
-        sky_lookup(A.sky, A.sky_w, A.sky_h, -phi, 2.0 * theta - 1.0, rgb);  // :375
-        acc[0] += rgb[0];
-        acc[1] += rgb[1];
-        acc[2] += rgb[2];
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    if (fl & BHG_FLAG_HIT_HORIZON_) return;
+    const double *e = A.end + i * 6;
+    if (fl == BHG_FLAG_HIT_DISK_ && A.disk_r_out > 0.0 && A.end) {
+        disk_colour(A, e, rgb);
+        return;
     }
+    if (fl == BHG_FLAG_HIT_OBJECT_ && A.object_id && A.end) {
+        object_colour(A, e, (int)A.object_id[i], rgb);
+        return;
+    }
+    // theta = 1 - acos(d_z / |d|) / pi (:373), phi = atan2(d_y, d_x) / pi (:374); exit directions are not unit
+    // vectors (the Cam edition normalises, CamEdition.py:433-437) -- both angles as scale-free atan2's:
+    // acos(d_z / |d|) = atan2(sqrt(d_x^2 + d_y^2), d_z)
+    const double rho = sqrt(c0 * c0 + c1 * c1);
+    const double theta = 1.0 - atan2_fast(rho, c2) * 0.3183098861837907;
+    const double phi = atan2_fast(c1, c0) * 0.3183098861837907;
+    sky_lookup(A.sky, A.sky_w, A.sky_h, -phi, 2.0 * theta - 1.0, rgb);  // :375
+}
+
+__device__ __forceinline__ void write_pixel(const ShadeArgs &A, uint64_t p, const double acc[3])
+{
     const double inv_s = 1.0 / (double)A.samples;  // buf = sbuf / (s+1) after the last sample (:250)
     if (A.rgba) {
         double *o = A.rgba + p * 4;
@@ -259,6 +229,61 @@ __global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A)
         reinterpret_cast<float4 *>(A.rgba_f32)[q] =
             make_float4((float)(acc[0] * inv_s), (float)(acc[1] * inv_s), (float)(acc[2] * inv_s), 1.0f);
     }
+}
+
+// One thread per RAY, the S samples of a pixel staged in LDS and summed by one thread in sample order (:242-250: sbuf +=
+// colour, sample after sample -- the order is part of the result).  A workgroup of 256 threads takes PPB = 256 / S
+// pixels; thread t = s * PPB + q is sample s of the block's q-th pixel, so that for a fixed s the block reads PPB
+// consecutive rays of the [S][P] layout (coalesced).  Against one thread per pixel walking its samples one after the
+// other (round 3; kept below for S > 256) this puts S times as many independent atan2 / texel-gather chains in flight:
+// the kernel is a latency chain per ray, not a bandwidth problem (131 MB in, 16 MB out per config-2 frame).
+__global__ void __launch_bounds__(256) shade_reduce_kernel(const ShadeArgs A, const uint32_t ppb)
+{
+    __shared__ double col[256 * 3];
+    const uint32_t t = threadIdx.x, S = (uint32_t)A.samples;
+    const uint32_t s = t / ppb, q = t - s * ppb;
+    const uint64_t p = (uint64_t)blockIdx.x * ppb + q;
+    const bool live = s < S && p < A.n_pixels;
+    if (live) {
+        const uint64_t i = (uint64_t)s * A.n_pixels + p;
+        // exit directions: the second half of the end records, or (direction-only traces of sky frames) an array of their own
+        const double *d = A.dir ? A.dir + i * 3 : A.end + i * 6 + 3;
+        double rgb[3];
+        ray_colour(A, i, A.flags[i], d[0], d[1], d[2], rgb);
+        col[t * 3 + 0] = rgb[0];
+        col[t * 3 + 1] = rgb[1];
+        col[t * 3 + 2] = rgb[2];
+    }
+    __syncthreads();
+    if (s == 0 && live) {
+        // (a horizon sample contributes an exact 0: acc + 0.0 is acc, the sum is bit for bit the skipping loop's)
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (uint32_t k = 0; k < S; k++) {
+            const double *c = col + (size_t)(k * ppb + q) * 3;
+            acc[0] += c[0];
+            acc[1] += c[1];
+            acc[2] += c[2];
+        }
+        write_pixel(A, p, acc);
+    }
+}
+
+// More samples than a workgroup has threads: one thread per pixel, samples accumulated in registers in sample order.
+__global__ void __launch_bounds__(256) shade_reduce_serial_kernel(const ShadeArgs A)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.n_pixels) return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int s = 0; s < A.samples; s++) {
+        const uint64_t i = (uint64_t)s * A.n_pixels + p;
+        const double *d = A.dir ? A.dir + i * 3 : A.end + i * 6 + 3;
+        double rgb[3];
+        ray_colour(A, i, A.flags[i], d[0], d[1], d[2], rgb);
+        acc[0] += rgb[0];
+        acc[1] += rgb[1];
+        acc[2] += rgb[2];
+    }
+    write_pixel(A, p, acc);
 }
 
 // dst[i] = src[index[i]] for rows of four floats: puts the gathered per-rank slabs into frame order on the
@@ -306,7 +331,12 @@ hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s)
 hipError_t launch_shade(const ShadeArgs &a, hipStream_t s)
 {
     if (a.n_pixels == 0) return hipSuccess;
-    hipLaunchKernelGGL(shade_reduce_kernel, dim3((unsigned)((a.n_pixels + 255) / 256)), dim3(256), 0, s, a);
+    if (a.samples > 256) {
+        hipLaunchKernelGGL(shade_reduce_serial_kernel, dim3((unsigned)((a.n_pixels + 255) / 256)), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    const uint32_t ppb = 256u / (uint32_t)a.samples;      // pixels per workgroup
+    hipLaunchKernelGGL(shade_reduce_kernel, dim3((unsigned)((a.n_pixels + ppb - 1) / ppb)), dim3(256), 0, s, a, ppb);
     return hipGetLastError();
 }
 
