@@ -1,3 +1,1 @@
-timeout 1200 python -m pytest tests/test_gpu_frame.py tests/test_gpu_frame_object.py tests/test_gpu_adaptors.py tests/test_gpu_multirank.py -q -m gpu --timeout 600 2>&1 | tail -3
-for w in "--workload frame" "--workload disk" "--workload orbit --steps 40 --warmup 5"; do echo "== $w"; bash scripts/ab.sh "$w" base prev base prev; done
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $GRAFT_REPO_ROOT/bench.py --lean --steps 50 --warmup 5 > /dev/null 2>&1; for f in $(find /tmp/kt -name "*kernel_stats.csv"); do grep -E "shade|Name" $f | cut -c1-200; done
+timeout 1200 python -m pytest tests/test_gpu_fullsize.py -q -m gpu --timeout 900 -k "beyond_one_launch" 2>&1 | tail -5

@@ -178,3 +178,40 @@ def test_config5_kerr_frame_full_size(ctx, oracle):
     # (measured 285 pixels beyond 1e-3 and 4,746 beyond 1e-6: a 50 % margin)
     assert (dimg > 1e-3).sum() <= 430 and (dimg > 1e-6).sum() <= 7100, ((dimg > 1e-3).sum(), (dimg > 1e-6).sum())
     assert np.median(dimg) < 1e-12
+
+
+def test_a_call_beyond_one_launch_is_split_and_every_part_is_right(ctx, oracle):
+    """A trace launch takes at most 2^26 rays (the kernels form a ray's result offsets in 32 bits); a larger call is split
+    into consecutive launches by the C-ABI layer.  2^26 + 70,001 rays -- the frame's rays repeated: the second launch
+    holds 70,001 rays whose results must equal the first occurrences' bit for bit, and a subsample agrees with the oracle;
+    direction-only form too."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    fr = DeviceFrame(ctx, 1024, 1024, 1, fov_x=0.6, fov_y=0.6)
+    fr.generate_rays()
+    n = (1 << 26) + 70001
+    k0 = fr.d_k0.repeat((n + fr.n - 1) // fr.n, 1)[:n].contiguous()
+    kw = dict(r_s=1.0, lambda_end=50.0)
+    p = _params(**kw)
+    end = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+    fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.trace_device(p, n, k0.data_ptr(), end.data_ptr(), x0_shared=CAM, d_flags=fl.data_ptr(), d_n_steps=st.data_ptr(),
+                     stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.last_launch()["passes"] == 2
+    m = fr.n
+    tail = slice(1 << 26, n)
+    src = slice((1 << 26) % m, (1 << 26) % m + 70001)          # (2^26 is a multiple of 2^20: the tail repeats rays 0 .. 70000)
+    assert _same_bits(end[tail], end[src]) and _same_bits(fl[tail], fl[src]) and _same_bits(st[tail], st[src])
+    idx = torch.cat([torch.arange(0, m, 4099, device="cuda"), torch.arange((1 << 26) - 500, n, 137, device="cuda")])
+    o = oracle.trace(k0[idx].cpu().numpy(), CAM, **kw)
+    assert np.array_equal(fl[idx].cpu().numpy(), o["flags"]) and np.array_equal(st[idx].cpu().numpy().astype(np.uint32), o["n_attempted"])
+    assert np.abs(end[idx].cpu().numpy() - o["end"]).max() < 1e-7
+    # the direction-only form over the same split
+    d = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+    fl2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.trace_dir_device(p, n, k0.data_ptr(), d.data_ptr(), x0_shared=CAM, d_flags=fl2.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ctx.last_launch()["passes"] == 2 and _same_bits(fl2, fl) and _same_bits(d, end[:, 3:6].contiguous())
