@@ -117,3 +117,36 @@ class SchwarzschildGeodesic:
         if verbose:
             print("ray_trace:", mes)
         return traj[0, 0, :m].copy(), traj[0, 1, :m].copy(), traj[0, 2, :m].copy(), end[0, 0:3].copy(), end[0, 3:6].copy(), mes
+
+
+class ApproxSchwarzschildGeodesic:
+    """`curvedpy.ApproxSchwarzschildGeodesic(ratio_obj_to_blackhole=, exit_tolerance=)` with `.generatedRayTracer(loc,
+    direction) -> (end_loc, end_dir, mes)` and the attributes `.ratio_obj_to_blackhole`, `.exit_tolerance` the engine
+    compares its settings with (raytracer/LimitedRelativisticRenderEngine.py:39, :97-101, :269).  In the reference this is
+    a pre-tabulated approximation of the exact solve, keyed on the two settings, there because the exact solve is slow on
+    the CPU; here it IS the exact solve (one GPU call), so nothing is tabulated and nothing depends on a data file --
+    `generatedRayTracer` returns what `SchwarzschildGeodesic.ray_trace` returns, minus the sampled path."""
+
+    def __init__(self, ratio_obj_to_blackhole=30.0, exit_tolerance=0.2, *, metric="schwarzschild", device=0, context=None, **solver_kw):
+        self.ratio_obj_to_blackhole = float(ratio_obj_to_blackhole)
+        self.exit_tolerance = float(exit_tolerance)
+        self._sw = SchwarzschildGeodesic(metric=metric, device=device, context=context, **solver_kw)
+
+    @property
+    def context(self) -> _ffi.Context:
+        return self._sw.context
+
+    def generatedRayTracer(self, loc, direction):
+        end_loc, end_dir, mes = self._sw.ray_trace_many(np.asarray(direction, dtype=np.float64).reshape(1, 3),
+                                                        np.asarray(loc, dtype=np.float64).reshape(1, 3),
+                                                        exit_tolerance=self.exit_tolerance,
+                                                        ratio_obj_to_blackhole=self.ratio_obj_to_blackhole)
+        out = {"hit_blackhole": bool(mes["hit_blackhole"][0])}
+        if mes["outside"][0]:
+            out["error"] = "Outside"
+        return end_loc[0], end_dir[0], out
+
+    def generatedRayTracer_many(self, locs, directions):
+        """The batched form: (end_loc [N, 3], end_dir [N, 3], mes) as SchwarzschildGeodesic.ray_trace_many."""
+        return self._sw.ray_trace_many(directions, locs, exit_tolerance=self.exit_tolerance,
+                                       ratio_obj_to_blackhole=self.ratio_obj_to_blackhole)

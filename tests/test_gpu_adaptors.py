@@ -277,6 +277,16 @@ def test_limited_engine_adaptor_against_oracle(ctx, oracle):
     near = p[1] * (ratio * 1.1 / np.linalg.norm(p[1]))
     el, ed, mm = sw.ray_trace_many(d[1:2], near[None, :], exit_tolerance=0.2, ratio_obj_to_blackhole=ratio)
     assert not mm["outside"][0] and (mm["hit_blackhole"][0] or abs(np.linalg.norm(el[0]) - ratio) < 1e-9)
+    # the "approximate" solver object of the same engine (:97-101, :269) is the exact solve here
+    from blackhole_geodesic_calculator_amd.limited import ApproxSchwarzschildGeodesic
+    asw = ApproxSchwarzschildGeodesic(ratio_obj_to_blackhole=ratio, exit_tolerance=0.2, context=ctx)
+    assert round(asw.exit_tolerance, 4) == 0.2 and round(asw.ratio_obj_to_blackhole, 4) == 30.0       # what :98 compares
+    j = int(np.nonzero(esc)[0][0])
+    el1, ed1, m1 = asw.generatedRayTracer(p[j], d[j])
+    assert np.array_equal(el1, end_loc[j]) and np.array_equal(ed1, end_dir[j]) and m1 == {"hit_blackhole": False}
+    assert asw.generatedRayTracer(far, d[0])[2]["error"] == "Outside"
+    ela, eda, ma = asw.generatedRayTracer_many(p, d)
+    assert np.array_equal(ela, end_loc) and np.array_equal(ma["flags"], mes["flags"])
     # the disk, with the engine's radii (disk_R_in * ratio, :285): against the oracle's disk event
     disk = (0.15 * ratio, 0.35 * ratio)
     el, ed, md = sw.ray_trace_many(d, p, ratio_obj_to_blackhole=ratio, disk=disk)
