@@ -984,10 +984,26 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
 constexpr int NSLICE = 8;
 constexpr int SLICE_STRIDE = 32;  // in unsigned long long: 256 bytes
 
+// Kernel arguments only the RARE paths of a trace kernel read -- the queue fill and the batch claim, once per 64 rays -- are
+// fetched from the kernarg segment AT THOSE SITES (scalar loads of a few dwords) instead of living in SGPRs for the
+// life of the kernel: the step loop is short of SGPRs (106 allocated, 14-18 spilled to VGPR lanes and fetched back with
+// v_readlane in every iteration), and these are two dozen of them.  The empty asm makes the segment's address opaque at
+// each use, so that the loads are neither hoisted out of the loop nor shared between sites.  (The trace kernels take
+// the TraceArgs struct as their ONE argument: its fields sit at their offsetof in the segment.)
+#define BHG_KERNARG_PTR __attribute__((address_space(4))) const char *
+__device__ __forceinline__ BHG_KERNARG_PTR kernarg_base()
+{
+    BHG_KERNARG_PTR kp = (BHG_KERNARG_PTR)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+#define BHG_COLD(kp, field) (*(__attribute__((address_space(4))) const decltype(TraceArgs::field) *)((kp) + offsetof(TraceArgs, field)))
+
 __device__ __forceinline__ unsigned long long issue_fetch(const TraceArgs &A, uint32_t lane, uint32_t slice)
 {
     unsigned long long b = 0;
-    if (lane == 0) b = atomicAdd(A.counter + slice * SLICE_STRIDE, 1ull);
+    unsigned long long *counter = BHG_COLD(kernarg_base(), counter);
+    if (lane == 0) b = atomicAdd(counter + slice * SLICE_STRIDE, 1ull);
     return b;
 }
 
@@ -1060,13 +1076,22 @@ __device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric 
 template <int RHS, bool ADAPTIVE, class LDS>
 __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, uint32_t lane, uint64_t base)
 {
+    // (this function's arguments straight from the kernarg segment, see kernarg_base())
+    BHG_KERNARG_PTR kp = kernarg_base();
+    struct {
+        const double *k0, *x0, *ws;
+        uint64_t n;
+        int32_t ws_stride, from_records, inline_prepare;
+        int8_t *object_id;
+    } C = {BHG_COLD(kp, k0), BHG_COLD(kp, x0), BHG_COLD(kp, ws), BHG_COLD(kp, n), BHG_COLD(kp, ws_stride), BHG_COLD(kp, from_records),
+           BHG_COLD(kp, inline_prepare), BHG_COLD(kp, object_id)};
     // Schwarzschild forms: no prepare pass has run, the wave works the records out itself
-    const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && A.inline_prepare;
+    const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && C.inline_prepare;
     const uint64_t i = base + lane;
     double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0;
     double pE = 0.0, pL = 0.0;
-    if (i < A.n) {
-        if (A.from_records) {
+    if (i < C.n) {
+        if (C.from_records) {
             const double *e = A.end + i * 6;
             px[0] = e[0];
             px[1] = e[1];
@@ -1074,36 +1099,37 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, 
             pk[0] = e[3];
             pk[1] = e[4];
             pk[2] = e[5];
-            const double *w = A.ws + i * (uint64_t)A.ws_stride;
+            const double *w = C.ws + i * (uint64_t)C.ws_stride;
             pa[0] = w[0];
             pa[1] = w[1];
             pa[2] = w[2];
             ph = w[3];
             pr = w[4];
-            if (A.ws_stride == 8) {
+            if (C.ws_stride == 8) {
                 pE = w[6];
                 pL = w[7];
             }
         } else {
             if (!inline_prepare) {
-                const double *w = A.ws + i * (uint64_t)A.ws_stride;
+                const double *w = C.ws + i * (uint64_t)C.ws_stride;
                 pa[0] = w[0];
                 pa[1] = w[1];
                 pa[2] = w[2];
                 ph = w[3];
                 pr = w[4];
             }
-            pk[0] = A.k0[i * 3 + 0];
-            pk[1] = A.k0[i * 3 + 1];
-            pk[2] = A.k0[i * 3 + 2];
-            if (A.x0) {
-                px[0] = A.x0[i * 3 + 0];
-                px[1] = A.x0[i * 3 + 1];
-                px[2] = A.x0[i * 3 + 2];
+            pk[0] = C.k0[i * 3 + 0];
+            pk[1] = C.k0[i * 3 + 1];
+            pk[2] = C.k0[i * 3 + 2];
+            if (C.x0) {
+                px[0] = C.x0[i * 3 + 0];
+                px[1] = C.x0[i * 3 + 1];
+                px[2] = C.x0[i * 3 + 2];
             } else {
-                px[0] = A.x0s[0];
-                px[1] = A.x0s[1];
-                px[2] = A.x0s[2];
+                const __attribute__((address_space(4))) double *xs = (const __attribute__((address_space(4))) double *)(kp + offsetof(TraceArgs, x0s));
+                px[0] = xs[0];
+                px[1] = xs[1];
+                px[2] = xs[2];
             }
         }
     }
@@ -1111,8 +1137,8 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, 
     // to assume they may still be in flight on the not-valid path and puts a vmcnt(0) in front of
     // the step code, which then waits for the previous iteration's result stores every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && i < A.n) {
-        if (A.object_id) A.object_id[i] = (int8_t)-1;
+    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && i < C.n) {
+        if (C.object_id) C.object_id[i] = (int8_t)-1;
         const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
         if (r0 <= A.r_hor) {
             // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313): final at once, never queued
@@ -2085,21 +2111,23 @@ __device__ __forceinline__ void replenish(const TraceArgs &A, LDS &Q, Wave &W, L
         if (W.q_count > 0 || W.exhausted || __ballot(!L.active) == 0ull) return;
         // the queue is empty, lanes wait, 64 slots are free: claim a batch
         const uint64_t base = take_fetch(issue_fetch(A, lane, W.slice), W.slice);
-        if (base >= A.n) {
+        BHG_KERNARG_PTR kp = kernarg_base();
+        if (base >= BHG_COLD(kp, n)) {
             // this slice is dry: steal from the next one
             W.slice = (W.slice + 1) % NSLICE;
             if (++W.dry == NSLICE) W.exhausted = true;
             continue;
         }
         uint64_t first = base;
-        if (A.order_blocks > 1) {
+        const int32_t order_blocks = BHG_COLD(kp, order_blocks);
+        if (order_blocks > 1) {
             // work-order hint: the rays are `order_blocks` equal blocks (the samples of a frame, block s =
             // sample s of every pixel).  Hand the 64-ray batches out chunk-major -- chunk 0 of every block,
             // then chunk 1 of every block ... -- so that a region's rays of ALL blocks start together: with
             // the caller's pixels sorted longest-first the long rays then all start early, instead of once
             // per block through the whole launch.  A pure permutation of the batch order.
-            const uint64_t g = base >> 6, q = g / (uint64_t)A.order_blocks, sblk = g - q * (uint64_t)A.order_blocks;
-            first = sblk * A.order_block_len + (q << 6);
+            const uint64_t g = base >> 6, q = g / (uint64_t)order_blocks, sblk = g - q * (uint64_t)order_blocks;
+            first = sblk * BHG_COLD(kp, order_block_len) + (q << 6);
         }
 #ifdef BHG_DIAG
         const unsigned long long c0 = __builtin_amdgcn_s_memtime();
@@ -2149,7 +2177,11 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     TraceArgs A = A0;  // (a copy the Kerr variant below can move fields of into VGPRs; free for the others)
     double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     double max_step = A.max_step;
-    const bool has_cap = A.max_step < __builtin_inf();    // (wave-uniform)
+    // (The two scalars the prologue of every step reads, min_step_cap and max_steps, sit in SGPRs the compiler spills to
+    // VGPR lanes: four v_readlane per iteration.  Holding them in VGPRs instead was tried: the 168-VGPR budget is full, they
+    // went to scratch and came back with two scratch loads per iteration.)
+    const double min_step_cap = A.min_step_cap;
+    const uint32_t max_steps = A.max_steps;
     Metric met;
     met.r_s = A.r_s;
     met.M = 0.5 * A.r_s;
@@ -2220,16 +2252,16 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
             // instructions in every iteration of every ray).
             // ("already at t_bound" at the START of a step only happens with lambda_end = 0: a ray that reaches t_bound
             // is final in that same step.  The C-ABI layer then sets min_step_cap = +inf, which sends every lane here.)
-            const bool odd = !(L.h_abs > A.min_step_cap) || L.n_att >= A.max_steps;
+            const bool odd = !(L.h_abs > min_step_cap) || L.n_att >= max_steps;
             if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
                 // (written as selects: as nested ifs this is eight divergent branches)
-                const bool tiny = !(L.h_abs > A.min_step_cap);
+                const bool tiny = !(L.h_abs > min_step_cap);
                 double min_step = 0.0;
                 if (__ballot(tiny)) min_step = tiny ? 10.0 * ulp_of(L.t) : 0.0;
                 const double h_clamped = (L.h_abs > max_step) ? max_step : ((L.h_abs < min_step) ? min_step : L.h_abs);
                 L.h_abs = L.rejected ? L.h_abs : h_clamped;
                 term = (L.h_abs < min_step) ? (uint32_t)BHG_FLAG_STEP_TOO_SMALL_
-                                            : ((L.n_att >= A.max_steps) ? (uint32_t)BHG_FLAG_MAX_STEPS_ : 0u);
+                                            : ((L.n_att >= max_steps) ? (uint32_t)BHG_FLAG_MAX_STEPS_ : 0u);
                 term = (term == 0u && L.t == t_bound) ? (uint32_t)BHG_FLAG_REACHED_END_ : term;  // base.py:189-194
             } else {
                 // (min_step = 0 here: the clamp of rk.py:121-124 is the upper one alone; not after a rejection)
@@ -2239,7 +2271,11 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 // (a compare and a select, not fmin: minnum wants both operands canonicalised first, two more instructions;
                 // h_abs is never NaN.  With max_step = +inf -- the engine's default, :59-60 -- the clamp is not there at all:
                 // wave-uniform branch.)
-                if (has_cap) {
+                // (the test on the bits of max_step, from a scalar the empty asm re-reads in every iteration: a flag computed
+                // once outside the loop is one more SGPR pair to spill and reload)
+                double ms_bits = A.max_step;
+                asm volatile("" : "+s"(ms_bits));
+                if ((uint32_t)__double2hiint(ms_bits) != 0x7FF00000u) {
                     if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
                         L.h_abs = (!L.rejected && L.h_abs > max_step) ? max_step : L.h_abs;
                     } else {

@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B of the working tree's library against build/variants/libbhgeo_head.so on the main workloads + parity tests + VALU count
+# A/B of the working tree's library against build/variants/libbhgeo_prev.so on the main workloads + parity tests + VALU count
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adaptors.py -q -m gpu --timeout 900 -x 2>&1 | tail -3
-for w in "--workload frame" "--workload disk" "--workload orbit --steps 40 --warmup 5" "--workload disk --rhs kerr --steps 100 --warmup 10"; do
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adaptors.py tests/test_gpu_fullsize.py -q -m gpu --timeout 900 -x 2>&1 | tail -3
+for w in "--workload frame" "--workload disk" "--workload orbit --steps 40 --warmup 5" "--workload frame --rhs kerr --steps 60 --warmup 5" "--workload disk --rhs kerr --steps 100 --warmup 10" "--workload frame --regime rk4 --steps 20 --warmup 3"; do
   echo "== $w"
-  bash scripts/ab.sh "$w" base head base head
-done 2>&1 | tee gpurun_out/r04_ab2.log
+  bash scripts/ab.sh "$w" base prev base prev
+done 2>&1 | tee gpurun_out/r04_ab3.log
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/dv && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d /tmp/dv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --ramp-seconds 0 --lean > /tmp/dv.log 2>&1
 python3 - <<'PY'
 import csv, glob, json
