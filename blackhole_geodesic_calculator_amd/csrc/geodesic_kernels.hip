@@ -2174,7 +2174,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     using LDS = WaveLds<RHS, Pool<RHS, true>::N>;
     __shared__ LDS Q;
     const uint32_t lane = threadIdx.x;
-    TraceArgs A = A0;  // (a copy the Kerr variant below can move fields of into VGPRs; free for the others)
+    const TraceArgs &A = A0;
     double r_s = A.r_hor, rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end;  // r_s: horizon EVENT radius
     double max_step = A.max_step;
     // (The two scalars the prologue of every step reads, min_step_cap and max_steps, sit in SGPRs the compiler spills to
@@ -2187,17 +2187,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     met.M = 0.5 * A.r_s;
     met.a = A.spin;
     met.E = met.L = 0.0;
-    if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
-        // Kerr frames without optional events: the scalars every step reads, kept in VGPRs.  They are wave-uniform and the compiler would hold them in
-        // SGPRs, of which the Kerr kernel is short (67 spilled): it parks them in VGPR lanes and fetches them back with
-        // v_readlane at every use, ~130 times per iteration.  Config 5 +2 to +3 %; the Schwarzschild kernels and the Kerr
-        // variants with a disk have no VGPRs to spare for this (config 3 -11 %, Kerr + disk -4 % with it).
-        asm volatile("" : "+v"(r_s), "+v"(rtol), "+v"(atol), "+v"(t_bound), "+v"(max_step));
-        asm volatile("" : "+v"(met.r_s), "+v"(met.M), "+v"(met.a));
-        // ... and the four result pointers (the spilled unit is the whole 16-dword kernarg chunk they sit in: every
-        // result store fetched all sixteen lanes back)
-        asm volatile("" : "+v"(A.end), "+v"(A.flags), "+v"(A.n_steps), "+v"(A.n_accepted));
-    }
+    // (Round 3 held the scalars every Kerr step reads in VGPRs, because that kernel spilled 67 SGPRs and fetched them back
+    // with v_readlane ~130 times per iteration.  With the rare paths' arguments read from the kernarg segment at their use
+    // sites -- kernarg_base() -- no trace kernel spills an SGPR any more, and the plain form measures 0.3 % faster.)
 
     Lane L;
 #pragma unroll
@@ -2275,15 +2267,8 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                 // once outside the loop is one more SGPR pair to spill and reload)
                 double ms_bits = A.max_step;
                 asm volatile("" : "+s"(ms_bits));
-                if ((uint32_t)__double2hiint(ms_bits) != 0x7FF00000u) {
-                    if (RHS == BHG_RHS_KERR_BL_ && EVT == 0) {
-                        L.h_abs = (!L.rejected && L.h_abs > max_step) ? max_step : L.h_abs;
-                    } else {
-                        double ms = A.max_step;
-                        asm volatile("" : "+s"(ms));
-                        L.h_abs = (!L.rejected && L.h_abs > ms) ? ms : L.h_abs;
-                    }
-                }
+                if ((uint32_t)__double2hiint(ms_bits) != 0x7FF00000u)
+                    L.h_abs = (!L.rejected && L.h_abs > ms_bits) ? ms_bits : L.h_abs;
             }
             if (term) {
                 store_result(A, L.idx, L.x, L.v, term, L.n_att, L.n_acc);
