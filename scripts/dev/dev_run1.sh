@@ -1,2 +1,2 @@
-timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_adaptors.py tests/test_gpu_fullsize.py -q -m gpu --timeout 900 -k "kerr or Kerr or config5 or golden or frame" 2>&1 | tail -2
-bash scripts/ab.sh "--workload frame --rhs kerr --steps 60 --warmup 5" base prev base prev | awk '{print $1,$2,$3,$4,$5}'
+# a build WITHOUT the inlined prepare (every form runs the prepare pass and reads per-ray records from the workspace): golden parity
+BHGEO_LIB=$PWD/build/variants/libbhgeo_noinline.so timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu --timeout 600 -k "golden or disk_five or objects" 2>&1 | tail -2
