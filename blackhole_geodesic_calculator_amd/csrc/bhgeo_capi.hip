@@ -492,13 +492,13 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     c->launched = true;
 
     // Workspace, grown on demand (the first call at a new size allocates; steady-state calls do not):
-    //   ws      [n][8] doubles  Kerr only: the prepare pass's records {a0, h0, r0, 0, E, L} (the Schwarzschild trace kernel
-    //                           works its start records out itself, and parked steps live in the waves' LDS pools)
+    //   ws      [n][8] doubles  only in a build without the inlined prepare: that pass's records {a0, h0, r0, 0, E, L} (the
+    //                           trace kernels work their start records out themselves; parked steps live in the waves' LDS pools)
     //   flags   [n] bytes       when the caller does not want flags
     //   n_steps / n_accepted [n] u32 when the caller does not want them (the kernels never test these pointers)
     const bool has_exit = p->r_exit > 0.0;
     const bool kerr = p->rhs_form == BHG_RHS_KERR_BL;
-    const bool needs_ws = bhg::needs_prepare_ws(p->rhs_form);   // Kerr; every form in a build without the inlined prepare
+    const bool needs_ws = bhg::needs_prepare_ws(p->rhs_form);   // only in a build without the inlined prepare
     const size_t sz_ws = needs_ws ? n * 8 * sizeof(double) : 0;
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
     const size_t sz_u32 = n * sizeof(uint32_t);
@@ -555,7 +555,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     if (p->rhs_form == BHG_RHS_KERR_BL) {
         const double M = 0.5 * p->r_s;
         a.r_hor = (M + std::sqrt(M * M - p->spin * p->spin)) * (1.0 + BHG_KERR_HORIZON_MARGIN);
-        a.from_records = 1;
+        a.from_records = needs_ws ? 1 : 0;     // (only a build without the inlined prepare starts Kerr rays from records)
         a.ws_stride = 8;
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
@@ -618,7 +618,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     }
 #endif
     // ONE persistent launch finishes every ray: events are resolved and rays resumed inside the trace kernel, so
-    // the call only enqueues (Kerr: prepare, trace, finalize) and returns
+    // the call only enqueues (Kerr: trace, finalize) and returns
     if (!c->counters_clean) HIP_TRY(hipMemsetAsync(c->counter, 0, 2 * 8 * 256, s));   // first call, or after a failed enqueue
     c->counters_clean = false;
     HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
@@ -1265,7 +1265,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     if (p->rhs_form == BHG_RHS_KERR_BL) {
         const double M = 0.5 * p->r_s;
         a.r_hor = (M + std::sqrt(M * M - p->spin * p->spin)) * (1.0 + BHG_KERR_HORIZON_MARGIN);
-        a.from_records = 1;
+        a.from_records = 1;                    // (the trajectory kernel reads the prepare pass's records)
         a.ws_stride = 8;
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);

@@ -18,9 +18,9 @@
 //     heuristic, start-inside test) and compacted with __ballot/mbcnt, so the expensive setup
 //     always runs converged and the integrate loop always runs (nearly) full;
 //   * ONE launch per trace call takes every ray to its end (~120 VGPRs in the step loop; the kernels run at 3 waves per
-//     SIMD so that the event drain next to it does not spill).  For the Schwarzschild forms the waves also work out
-//     each batch's start records -- f0, r0, scipy's initial step -- while they fill their queue; Kerr runs a PREPARE
-//     pass first (Cartesian -> Boyer-Lindquist, E, L) and a finalize pass last;
+//     SIMD so that the event drain next to it does not spill).  The waves also work out each batch's start records -- Kerr:
+//     Cartesian -> Boyer-Lindquist, E, L; every form: f0, r0, scipy's initial step -- while they fill their queue, 64 rays
+//     wide; Kerr runs a finalize pass last (Boyer-Lindquist -> Cartesian end states);
 //   * a lane whose accepted step crosses the horizon / exit sphere / disk plane, or whose chord may touch an object
 //     sphere, does not take the step: it keeps the step's START state, and at its next service() that record goes into
 //     the wave's LDS slot pool (WaveLds: queue entries, parked steps and free slots share it) and the lane pops the
@@ -40,9 +40,10 @@
 #include <stdint.h>
 
 #include "geodesic_kernels.h"
+#include "device_math.h"
 
-// 1: the Schwarzschild trace kernels work out the start records themselves (no prepare launch); 0: every form
-// runs the prepare pass (the code is then not compiled into the trace kernels at all)
+// 1: the trace kernels work out the start records themselves (no prepare launch); 0: every form runs the prepare
+// pass (the code is then not compiled into the trace kernels at all).  The trajectory kernels always use the pass.
 #ifndef BHG_INLINE_PREPARE
 #define BHG_INLINE_PREPARE 1
 #endif
@@ -285,6 +286,61 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
     acc[1] = ath;
     acc[2] = aph;
     r_out = r;
+}
+
+// Kerr: a ray's Cartesian start state (x, k) -> Boyer-Lindquist (r, theta, phi) and d/dlambda of those, in place, plus the
+// Killing constants E = -k_t, L = k_phi from the null condition at the start point (future-directed root, g_tt < 0).
+//     x = sqrt(r^2 + a^2) sin th cos ph,  y = sqrt(r^2 + a^2) sin th sin ph,  z = r cos th
+// theta is DEFINED as acos(z / r) of the rounded quotient (the CPU checker's cart_to_bl): for the reference's camera, 1e-4
+// off the rotation axis at z = 30 (CamEdition.py:208-221), that quotient is 1 - 5.6e-12 and its rounding moves theta by
+// 2e-11 of itself -- far above anything else in the conversion, and Kerr rays amplify it.  So r and z / r are formed with
+// IEEE square roots and an IEEE division in the checker's order of operations (bit-identical quotient), and the rest is
+// free: acos(c) = 2 atan2(sqrt(1 - c), sqrt(1 + c)) (1 - c is exact for c > 1/2), sin / cos of theta from sincos_pi4,
+// cos ph = x / w and sin ph = y / w as ratios (w = sqrt(x^2 + y^2)), and the inverse of the Jacobian in closed form (its
+// (r, theta) block has determinant -(r^2 sin^2 th + R^2 cos^2 th) / R, R = sqrt(r^2 + a^2)):
+//     k_rho = cos ph k_x + sin ph k_y,   dphi = (cos ph k_y - sin ph k_x) / (R sin th),
+//     dr = (r sin th k_rho + R cos th k_z) R / D,   dtheta = (R cos th k_rho - r sin th k_z) / D.
+// About 330 instructions, 64 rays wide inside a trace wave's queue fill (the prepare pass uses the same function, so every
+// path starts a ray from bit-identical Boyer-Lindquist data).  A start ON the rotation axis (w = 0) has no azimuth: NaN, as
+// the checker's 3x3 solve gives (0 / 0).
+__device__ __forceinline__ void kerr_cart_to_bl(double a, double M, double px[3], double pk[3], double &E, double &L)
+{
+    const double x = px[0], y = px[1], z = px[2], a2 = a * a;
+    const double rho2 = x * x + y * y + z * z;
+    const double b = rho2 - a2;
+    const double r = sqrt(0.5 * (b + sqrt(b * b + 4.0 * a * a * z * z)));       // (IEEE sqrt, the checker's expression)
+    const double c = z / r;                                                      // (IEEE division)
+    const double th = 2.0 * atan2_fast(sqrt_nr(1.0 - c), sqrt_nr(1.0 + c));
+    double st, ct;
+    sincos_pi4(th, st, ct);
+    const double r2 = r * r, R2 = r2 + a2, w2 = __builtin_fma(y, y, x * x);
+    const double iR = rsqrt_nr(R2), iw = rsqrt_nr(w2);
+    const double R = R2 * iR, cp = x * iw, sp = y * iw;
+    const double rst = r * st, Rct = R * ct;
+    const double D = __builtin_fma(rst, rst, Rct * Rct);
+    const double Sig = __builtin_fma(a2 * ct, ct, r2);
+    const double Del = __builtin_fma(-2.0 * M, r, R2);
+    double iD, iRst, iSD;
+    rcp3_nr(D, R * st, Sig * Del, iD, iRst, iSD);
+    const double iSig = iSD * Del, iDel = iSD * Sig;
+    const double krho = __builtin_fma(cp, pk[0], sp * pk[1]);
+    const double u2 = __builtin_fma(cp, pk[1], -(sp * pk[0])) * iRst;
+    const double u0 = __builtin_fma(rst, krho, Rct * pk[2]) * (R * iD);
+    const double u1 = __builtin_fma(Rct, krho, -(rst * pk[2])) * iD;
+    px[0] = r;
+    px[1] = th;
+    px[2] = atan2_fast(y, x);
+    pk[0] = u0;
+    pk[1] = u1;
+    pk[2] = u2;
+    const double s2 = st * st, tmr = 2.0 * M * r * iSig;        // 2 M r / Sigma
+    const double gtt = tmr - 1.0, gtp = -tmr * a * s2;
+    const double gpp = __builtin_fma(a2 * tmr, s2, R2) * s2;
+    const double S = __builtin_fma(gpp * u2, u2, __builtin_fma(Sig * u1, u1, Sig * iDel * u0 * u0));
+    const double B = gtp * u2;
+    const double kt = (-B - sqrt_nr(__builtin_fma(B, B, -(gtt * S)))) * rcp_nr(gtt);
+    E = -__builtin_fma(gtt, kt, gtp * u2);
+    L = __builtin_fma(gtp, kt, gpp * u2);
 }
 
 template <int RHS>
@@ -1070,8 +1126,8 @@ __device__ __forceinline__ void initial_record(const TraceArgs &A, const Metric 
     }
 }
 
-// Put rays base .. base+63 into the ray queue: coalesced loads of k0, x0 and -- Kerr -- of the prepare
-// pass's record {a0, h0, r0, 0, E, L}; the Schwarzschild forms work the records out here, all lanes together.
+// Put rays base .. base+63 into the ray queue: coalesced loads of k0, x0; the start records {a0, h0, r0, E, L} are
+// worked out here, all lanes together (a build without BHG_INLINE_PREPARE loads the prepare pass's records instead).
 // Items that pass (h >= 0) take a free slot each (ballot/mbcnt ranks); the caller has made sure 64 are free.
 template <int RHS, bool ADAPTIVE, class LDS>
 __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, uint32_t lane, uint64_t base)
@@ -1085,8 +1141,8 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, 
         int8_t *object_id;
     } C = {BHG_COLD(kp, k0), BHG_COLD(kp, x0), BHG_COLD(kp, ws), BHG_COLD(kp, n), BHG_COLD(kp, ws_stride), BHG_COLD(kp, from_records),
            BHG_COLD(kp, inline_prepare), BHG_COLD(kp, object_id)};
-    // Schwarzschild forms: no prepare pass has run, the wave works the records out itself
-    const bool inline_prepare = BHG_INLINE_PREPARE && RHS != BHG_RHS_KERR_BL_ && C.inline_prepare;
+    // no prepare pass has run: the wave works the records out itself (Kerr: unless the rays come as prepared records)
+    const bool inline_prepare = BHG_INLINE_PREPARE && C.inline_prepare;
     const uint64_t i = base + lane;
     double px[3] = {0, 0, 0}, pk[3] = {0, 0, 0}, pa[3] = {0, 0, 0}, pr = 0.0, ph = -1.0;
     double pE = 0.0, pL = 0.0;
@@ -1137,17 +1193,27 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, 
     // to assume they may still be in flight on the not-valid path and puts a vmcnt(0) in front of
     // the step code, which then waits for the previous iteration's result stores every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-    if (RHS != BHG_RHS_KERR_BL_ && inline_prepare && i < C.n) {
+    if (inline_prepare && !C.from_records && i < C.n) {
         if (C.object_id) C.object_id[i] = (int8_t)-1;
-        const double r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+        Metric met;
+        met.r_s = A.r_s;
+        met.M = 0.5 * A.r_s;
+        met.a = met.E = met.L = 0.0;
+        const double cx[3] = {px[0], px[1], px[2]}, ck[3] = {pk[0], pk[1], pk[2]};   // the Cartesian input, for a start inside
+        double r0;
+        if (RHS == BHG_RHS_KERR_BL_) {
+            met.a = A.spin;
+            kerr_cart_to_bl(met.a, met.M, px, pk, met.E, met.L);
+            pE = met.E;
+            pL = met.L;
+            r0 = px[0];
+        } else {
+            r0 = sqrt(__builtin_fma(px[2], px[2], __builtin_fma(px[1], px[1], px[0] * px[0])));
+        }
         if (r0 <= A.r_hor) {
             // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313): final at once, never queued
-            store_result(A, (uint32_t)i, px, pk, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+            store_result(A, (uint32_t)i, cx, ck, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
         } else {
-            Metric met;
-            met.r_s = A.r_s;
-            met.M = 0.5 * A.r_s;
-            met.a = met.E = met.L = 0.0;
             ph = 0.0;
             initial_record<RHS, ADAPTIVE>(A, met, px, pk, pa, pr, ph);
         }
@@ -2510,36 +2576,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
     met.E = met.L = 0.0;
     double cx[3] = {px[0], px[1], px[2]}, ck[3] = {pk[0], pk[1], pk[2]};  // Cartesian input, kept for start-inside
     if (RHS == BHG_RHS_KERR_BL_) {
-        // Cartesian -> Boyer-Lindquist: x = sqrt(r^2+a^2) sin th cos ph, y = ... sin ph, z = r cos th
-        const double a = met.a, M = met.M;
-        const double rho2 = px[0] * px[0] + px[1] * px[1] + px[2] * px[2];
-        const double b = rho2 - a * a;
-        const double r = sqrt(0.5 * (b + sqrt(b * b + 4.0 * a * a * px[2] * px[2])));
-        const double th = acos(px[2] / r), ph = atan2(px[1], px[0]);
-        const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
-        const double J00 = r / R * st * cp, J01 = R * ct * cp, J02 = -R * st * sp;
-        const double J10 = r / R * st * sp, J11 = R * ct * sp, J12 = R * st * cp;
-        const double J20 = ct, J21 = -r * st, J22 = 0.0;
-        const double det = J00 * (J11 * J22 - J12 * J21) - J01 * (J10 * J22 - J12 * J20) + J02 * (J10 * J21 - J11 * J20);
-        const double u0 = (pk[0] * (J11 * J22 - J12 * J21) - J01 * (pk[1] * J22 - J12 * pk[2]) + J02 * (pk[1] * J21 - J11 * pk[2])) / det;
-        const double u1 = (J00 * (pk[1] * J22 - J12 * pk[2]) - pk[0] * (J10 * J22 - J12 * J20) + J02 * (J10 * pk[2] - pk[1] * J20)) / det;
-        const double u2 = (J00 * (J11 * pk[2] - pk[1] * J21) - J01 * (J10 * pk[2] - pk[1] * J20) + pk[0] * (J10 * J21 - J11 * J20)) / det;
-        px[0] = r;
-        px[1] = th;
-        px[2] = ph;
-        pk[0] = u0;
-        pk[1] = u1;
-        pk[2] = u2;
-        // E = -k_t, L = k_phi from the null condition at the camera (future-directed root, g_tt < 0)
-        const double s2 = st * st, c2 = ct * ct;
-        const double Sig = r * r + a * a * c2, Del = r * r - 2.0 * M * r + a * a;
-        const double gtt = -(1.0 - 2.0 * M * r / Sig), gtp = -2.0 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
-        const double gpp = (r * r + a * a + 2.0 * M * a * a * r * s2 / Sig) * s2;
-        const double S = grr * u0 * u0 + gthth * u1 * u1 + gpp * u2 * u2;
-        const double B = gtp * u2;
-        const double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
-        met.E = -(gtt * kt + gtp * u2);
-        met.L = gtp * kt + gpp * u2;
+        kerr_cart_to_bl(met.a, met.M, px, pk, met.E, met.L);
     }
     const double r0 = (RHS == BHG_RHS_KERR_BL_)
                           ? px[0]
@@ -2870,9 +2907,10 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
     const unsigned gp = (unsigned)((a_in.n + 255) / 256);
     // Schwarzschild forms: the trace kernel's waves work out the start records themselves while they fill
     // their ray queues (converged, 64 lanes wide) -- no prepare launch, no 40-byte record round trip per ray.
-    // Kerr keeps the prepare pass (Cartesian -> Boyer-Lindquist, E and L: trig-heavy, 200 registers).
+    // Kerr too since round 4 (Cartesian -> Boyer-Lindquist, E and L without a trigonometric call, kerr_cart_to_bl);
+    // a build with BHG_INLINE_PREPARE 0 runs the prepare pass here and, for Kerr, starts the rays from its records.
     TraceArgs a = a_in;
-    a.inline_prepare = (RHS != BHG_RHS_KERR_BL_ && BHG_INLINE_PREPARE) ? 1 : 0;
+    a.inline_prepare = BHG_INLINE_PREPARE ? 1 : 0;
     if (ev) (void)hipEventRecord(ev[0], s);
     if (!a.inline_prepare) {
         if (method == BHG_METHOD_RK4_)
@@ -2960,7 +2998,7 @@ hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int gr
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
 
-bool needs_prepare_ws(int rhs) { return rhs == BHG_RHS_KERR_BL_ || !BHG_INLINE_PREPARE; }
+bool needs_prepare_ws(int) { return !BHG_INLINE_PREPARE; }
 
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {

@@ -386,8 +386,9 @@ int bhg_synchronize(bhg_context *ctx);
 void *bhg_context_stream(bhg_context *ctx);
 
 /* Per-pass timing of the trace calls.  A trace call runs up to two passes on the caller's stream:
- * PREPARE (per-ray setup: f0, initial step -- its own launch for BHG_RHS_KERR_BL only; the Schwarzschild
- * forms do it inside TRACE and report 0 here) and TRACE (the integrate loop including the root search for
+ * PREPARE (per-ray setup: f0, initial step, Kerr's Cartesian -> Boyer-Lindquist conversion -- done inside
+ * TRACE by the waves' queue fill for every form since ABI 6, so this slot reads 0; it was a launch of its own
+ * for BHG_RHS_KERR_BL before) and TRACE (the integrate loop including the root search for
  * rays that end on an event; the dominant kernel).  With profiling enabled the library records HIP
  * events around each pass on that stream; bhg_last_pass_ms() waits for the last call's events and
  * returns {prepare, trace, post} in milliseconds: post is the pass after the trace kernel -- the

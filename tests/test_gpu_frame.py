@@ -181,8 +181,8 @@ def test_work_order_hint_never_changes_results(ctx):
 
 
 def test_profiled_passes_and_pixel_cost(ctx):
-    """bhg_set_profiling / bhg_last_pass_ms: {prepare, trace, post} -- Kerr has all three passes, the Schwarzschild forms
-    only the trace kernel; DeviceFrame.pixel_cost() = the steps of a pixel's rays summed over its samples."""
+    """bhg_set_profiling / bhg_last_pass_ms: {prepare, trace, post} -- the start records are worked out inside the trace kernel
+    (prepare reads ~0 for every form), Kerr has the finalize pass after it; DeviceFrame.pixel_cost() = the steps of a pixel's rays summed over its samples."""
     import torch
     from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
     fr = DeviceFrame(ctx, 64, 48, 3, fov_x=0.6, fov_y=0.6)
@@ -197,7 +197,7 @@ def test_profiled_passes_and_pixel_cost(ctx):
         assert cost.shape == (64 * 48,) and np.array_equal(cost, st.reshape(3, -1).sum(0)) and cost.min() > 0
         fr.trace(_params(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45))
         t = ctx.last_pass_ms()
-        assert t["trace"] > 0.0 and t["prepare"] > 0.0 and t["post"] > 0.0
+        assert t["trace"] > 0.0 and 0.0 <= t["prepare"] < 0.1 * t["trace"] and t["post"] > 0.0
     finally:
         ctx.set_profiling(False)
     torch.cuda.synchronize()
