@@ -387,6 +387,21 @@ def host_buffer_figures(ctx, fr, cam, params, n):
                             "what": "bhg_frame_render into a pageable numpy array, best of 3: rays resident, trace + shade + sample "
                                     "mean on the device, one [H, W, 4] float image back (the add-on's device path; no torch)"}
     fo.close()
+    # the engine's literal per-ray call (RelativisticRenderEngine.py:293-294: one ray, nr_points_curve = 10000) through the
+    # adaptor -- what a caller gets who swaps the integrator object and nothing else
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    if params.rhs_form != _ffi.RHS_KERR_BL:
+        gi = GeodesicIntegratorSchwarzschild(mass=0.5 * params.r_s, time_like=False, verbose=False, context=ctx)
+        cam_np = np.asarray(cam, dtype=np.float64)
+        for i in range(20):
+            gi.calc_trajectory(k_host[i], cam_np, max_step=1e4, curve_end=params.lambda_end, nr_points_curve=10000, verbose=False)
+        t = time.perf_counter()
+        for i in range(200):
+            gi.calc_trajectory(k_host[(i * 2621) % len(k_host)], cam_np, max_step=1e4, curve_end=params.lambda_end, nr_points_curve=10000, verbose=False)
+        us = (time.perf_counter() - t) / 200 * 1e6
+        out["per_ray_call"] = {"us_per_call": us, "rays_per_s": 1e6 / us, "nr_points_curve": 10000,
+                               "what": "GeodesicIntegratorSchwarzschild.calc_trajectory(k0, x0, ..., nr_points_curve=10000), mean of 200 "
+                                       "calls: the reference engine's own call, one ray at a time (one wave per ray, samples over the lanes)"}
     out["unit"] = "Mrays/s"
     out["what"] = ("bhg_trace, PCIe-inclusive, best of 3 after one warm-up call: k0 from a pageable numpy array (staged by worker "
                    "threads), H2D || trace || D2H pipelined over 2^20-ray chunks; value: end/flags/n_steps/n_accepted arrive in "

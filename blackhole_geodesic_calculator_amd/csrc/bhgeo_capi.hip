@@ -1271,6 +1271,22 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
     HIP_TRY(bhg::launch_trajectory(a, p->rhs_form, (double *)o, (uint32_t *)(o + off_nv), n_points, s));
+    const size_t total = off_flags + n;
+    if (total <= (size_t(4) << 20)) {
+        // the engine's per-ray call (one ray, 10,000 samples: 480 kB): ONE copy of the whole output block into page-locked
+        // memory and a host-side split, instead of four copies into the caller's pageable arrays (each of which the
+        // runtime stages and waits for on its own)
+        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, total < (size_t(1) << 20) ? (size_t(1) << 20) : (size_t(4) << 20));
+        if (rc != BHG_OK) return rc;
+        const char *h = (const char *)c->pin_out;
+        HIP_TRY(hipMemcpyAsync(c->pin_out, o, total, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(traj, h, sz_traj);
+        std::memcpy(n_valid, h + off_nv, n * sizeof(uint32_t));
+        if (end) std::memcpy(end, h + off_end, n * 6 * sizeof(double));
+        if (flags) std::memcpy(flags, h + off_flags, n);
+        return BHG_OK;
+    }
     HIP_TRY(hipMemcpyAsync(traj, o, sz_traj, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(n_valid, o + off_nv, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (end) HIP_TRY(hipMemcpyAsync(end, o + off_end, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -2691,16 +2691,22 @@ __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A, d
 
 // ------------------------------------------------------------------------------------------
 // Sampled trajectories: what calc_trajectory returns with nr_points_curve (RelativisticRenderEngine.py:
-// 293-294; the curves of README Fig. 5/6).  One lane per ray, a plain loop -- this is the small-n
-// plotting path, not the frame path.  Same prepare record, same stages / error norm / factor helpers as
+// 293-294; the curves of README Fig. 5/6).  A plain loop per ray -- this is the small-n plotting path, not the
+// frame path.  Same prepare record, same stages / error norm / factor helpers as
 // the integrate loop; after every accepted step the samples t_eval_j <= t are emitted through the step's
 // dense output (solve_ivp's t_eval semantics, ivp.py:706-723); rays that end early emit fewer samples.
+// Two shapes, same arithmetic and same bits: WAVE = false, one LANE per ray (many rays, few samples each); WAVE = true,
+// one WAVE per ray -- every lane steps the same ray (wave-uniform loads and arithmetic cost a SIMD nothing extra) and
+// the samples of a step are shared out over the 64 lanes, stored coalesced.  That is the shape of the engine's literal
+// call, ONE ray with nr_points_curve = 10000 (:293-294): a single lane spent 1.9 ms of its 2.0 ms evaluating 10,000
+// dense-output points one after the other.
 // ------------------------------------------------------------------------------------------
-template <int RHS>
+template <int RHS, bool WAVE>
 __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, double *traj, uint32_t *n_valid,
                                                              uint32_t T)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t i = WAVE ? (uint64_t)blockIdx.x : (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     const double rtol = A.rtol, atol = A.atol, t_bound = A.lambda_end, max_step = A.max_step;
     double x[3], v[3], a1[3], h_abs, r_cur;
@@ -2797,9 +2803,26 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             evflag = (rh <= re) ? BHG_FLAG_HIT_HORIZON_ : BHG_FLAG_EXITED_SPHERE_;
         }
         // emit every sample time up to where this step ends
-        while (next < T) {
-            const double te = (next + 1 == T) ? t_bound : (double)next * dt;
-            if (!(te <= t_stop)) break;
+        uint32_t first = next, stride = 1, last = T;
+        if (WAVE) {
+            // the samples of this step are next .. g-1 with g the first index whose time lies beyond t_stop (the times
+            // are nondecreasing in the index): a guess from the quotient, put right with the serial loop's own comparison
+            auto te_of = [&](uint32_t j) { return (j + 1 == T) ? t_bound : (double)j * dt; };
+            const double q = floor(t_stop / dt) + 1.0;
+            uint32_t g = q >= (double)T ? T : (q > (double)next ? (uint32_t)q : next);
+            while (g > next && !(te_of(g - 1) <= t_stop)) g--;
+            while (g < T && te_of(g) <= t_stop) g++;
+            first = next + lane;
+            stride = 64;
+            last = g;
+            next = g;
+        }
+        for (uint32_t j = first; j < last; j += stride) {
+            const double te = (j + 1 == T) ? t_bound : (double)j * dt;
+            if (!WAVE) {
+                if (!(te <= t_stop)) break;
+                next = j + 1;
+            }
             double sx[3], sv[3];
             dense_pos(d, te, sx);
             dense_dir(d, te, sv);
@@ -2815,10 +2838,9 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
                 sv[2] = ct * u0 + (-r * st) * u1;
             }
             for (int c = 0; c < 3; c++) {
-                out[(uint64_t)c * T + next] = sx[c];
-                out[(uint64_t)(3 + c) * T + next] = sv[c];
+                out[(uint64_t)c * T + j] = sx[c];
+                out[(uint64_t)(3 + c) * T + j] = sv[c];
             }
-            next++;
         }
         if (evflag) {
             flags = evflag;
@@ -2848,16 +2870,23 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             ve[c] = v[c];
         }
     }
+    if (WAVE && lane != 0) return;
     n_valid[i] = next;
     store_result(A, (uint32_t)i, xe, ve, flags, n_att, n_acc);  // Kerr: still Boyer-Lindquist, finalised next
 }
+
+// one wave per ray while the rays are too few to fill the chip's lanes anyway
+__host__ inline bool trajectory_wave_per_ray(uint64_t n) { return n <= 2048; }
 
 #ifdef BHG_TU_KERR
 hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
     hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+    if (trajectory_wave_per_ray(a.n))
+        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_, true>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
+    else
+        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_, false>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
     hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a, (double *)nullptr);
     return hipGetLastError();
 }
@@ -2866,12 +2895,20 @@ hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t
 {
     if (rhs == BHG_RHS_KERR_BL_) return launch_trajectory_kerr(a, traj, n_valid, T, s);
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
+    const bool wave = trajectory_wave_per_ray(a.n);
+    const dim3 g(wave ? (unsigned)a.n : gt);
     if (rhs == BHG_RHS_REDUCED_) {
         hipLaunchKernelGGL((prepare_kernel<BHG_RHS_REDUCED_, true>), dim3(gp), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+        if (wave)
+            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_, true>), g, dim3(64), 0, s, a, traj, n_valid, T);
+        else
+            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_, false>), g, dim3(64), 0, s, a, traj, n_valid, T);
     } else {
         hipLaunchKernelGGL((prepare_kernel<BHG_RHS_CHRISTOFFEL_, true>), dim3(gp), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+        if (wave)
+            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_, true>), g, dim3(64), 0, s, a, traj, n_valid, T);
+        else
+            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_, false>), g, dim3(64), 0, s, a, traj, n_valid, T);
     }
     return hipGetLastError();
 }

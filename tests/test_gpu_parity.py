@@ -928,6 +928,33 @@ def test_calc_trajectory_adaptor(ctx, oracle):
     assert result["start_inside_hole"] is True and result["hit_blackhole"] is True and x_xyz.shape == (3, 0)
 
 
+def test_trajectory_kernel_shapes_give_the_same_bits(ctx):
+    """bhg_trajectory runs one WAVE per ray up to 2048 rays (the engine's literal call: one ray, 10,000 samples, shared
+    out over the 64 lanes) and one LANE per ray above: same arithmetic, so the same rays sampled either way must come
+    back bit for bit, sample counts and NaN padding included; sample counts that are not multiples of 64 and a
+    trajectory cut short by the horizon are in the set."""
+    k = frame_rays(2100, seed=52)
+    for kw, T in ((dict(r_s=1.0, lambda_end=50.0), 37), (dict(r_s=1.0, lambda_end=50.0, rhs_form=1, r_exit=31.0), 130),
+                  (dict(r_s=1.0, lambda_end=40.0, rhs_form=2, spin=0.45), 65)):
+        cam = CAM if kw.get("rhs_form") != 2 else np.array([2.0, -24.0, 14.0])
+        kk = k if kw.get("rhs_form") != 2 else (k @ np.array([[1, 0, 0], [0, 0.5, 0.866], [0, -0.866, 0.5]]))
+        big = ctx.trajectory(kk, cam, _params(**kw), T)           # 2100 rays: one lane per ray
+        sub = ctx.trajectory(kk[:500], cam, _params(**kw), T)     # 500 rays: one wave per ray
+        for a, b in zip(big, sub):
+            assert np.array_equal(a[:500], b, equal_nan=True)
+        nv, flags = sub[1], sub[3]
+        assert (nv == T).any() and ((nv < T) & ((flags & 1) != 0)).any()
+    # the literal call's size, against a per-sample restatement of t_eval's rule: sample j is there iff its time
+    # j * dt (the last one: curve_end) does not lie beyond where the ray ends
+    k3 = np.array([[b / 30.0, 0.0, -1.0] for b in (5.0, 8.0, 12.0)])
+    k3 /= np.linalg.norm(k3, axis=1)[:, None]
+    traj, nv, end, flags = ctx.trajectory(k3, CAM, _params(r_s=1.0, lambda_end=50.0), 10000)
+    assert np.all(nv == 10000) and np.isfinite(traj).all() and np.abs(traj[:, :, -1] - end).max() < 1e-9
+    # consecutive samples are dt apart along a smooth curve: no sample was skipped or written twice by the lane split
+    step = np.linalg.norm(np.diff(traj[:, 0:3, :], axis=2), axis=1)
+    assert step.min() > 0.5 * 50.0 / 9999 * 0.9 and step.max() < 2.0 * 50.0 / 9999
+
+
 def test_trajectories_batch_match_trace_and_oracle(ctx, oracle):
     k = frame_rays(300, seed=51)
     for kw in (dict(r_s=1.0, lambda_end=50.0), dict(r_s=1.0, lambda_end=50.0, rhs_form=1, r_exit=31.0),
