@@ -150,6 +150,8 @@ class Params(C.Structure):
         ("disk_r_in", C.c_double),
         ("disk_r_out", C.c_double),
         ("spin", C.c_double),
+        ("time_like", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -298,10 +300,10 @@ def default_params() -> Params:
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
                 r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
-                disk_r_out=0.0, spin=0.0, order_blocks=0) -> Params:
+                disk_r_out=0.0, spin=0.0, order_blocks=0, time_like=0) -> Params:
     return Params(float(r_s), float(lambda_end), float(max_step), float(rtol), float(atol),
                   float(h_fixed), float(r_exit), int(method), int(rhs_form), int(max_steps), int(order_blocks),
-                  float(disk_r_in), float(disk_r_out), float(spin))
+                  float(disk_r_in), float(disk_r_out), float(spin), int(bool(time_like)), 0)
 
 
 def device_count() -> int:

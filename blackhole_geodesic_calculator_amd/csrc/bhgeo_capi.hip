@@ -35,7 +35,7 @@ static_assert(BHG_METHOD_DP54 == bhg::BHG_METHOD_DP54_ && BHG_METHOD_RK4 == bhg:
 static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCED == bhg::BHG_RHS_REDUCED_ &&
                   BHG_RHS_KERR_BL == bhg::BHG_RHS_KERR_BL_,
               "rhs mismatch");
-static_assert(sizeof(bhg_params) == 96, "bhg_params layout is part of the ABI");
+static_assert(sizeof(bhg_params) == 104, "bhg_params layout is part of the ABI");
 static_assert(BHG_FLAG_HIT_DISK == bhg::BHG_FLAG_HIT_DISK_, "flag mismatch");
 
 namespace {
@@ -216,7 +216,7 @@ struct bhg_context {
     void *d_endws = nullptr;   // end records as workspace of direction-only calls
     size_t d_endws_bytes = 0;
     int32_t last_launch[4] = {0, 0, 0, 0};
-    int occupancy[48] = {0};  // resident waves per CU of each trace-kernel variant (0 = not asked yet)
+    int occupancy[96] = {0};  // resident waves per CU of each trace-kernel variant (0 = not asked yet)
     // optional per-pass timing (bhg_set_profiling)
     bool profiling = false;
     bool ev_valid = false;
@@ -288,6 +288,9 @@ int validate(const bhg_params *p)
         if (!std::isfinite(p->spin) || !(std::fabs(p->spin) < 0.5 * p->r_s))
             return fail(BHG_E_INVALID, "Kerr needs |spin| < M = r_s/2");
     }
+    if (p->time_like != 0 && p->time_like != 1) return fail(BHG_E_INVALID, "time_like must be 0 or 1");
+    if (p->time_like && p->rhs_form == BHG_RHS_REDUCED)
+        return fail(BHG_E_INVALID, "BHG_RHS_REDUCED is the closed form for null rays: time_like needs BHG_RHS_CHRISTOFFEL or BHG_RHS_KERR_BL");
     if (!(p->disk_r_in >= 0.0) || !(p->disk_r_out >= 0.0) || !std::isfinite(p->disk_r_in) || !std::isfinite(p->disk_r_out))
         return fail(BHG_E_INVALID, "disk radii must be finite and >= 0");
     if (p->disk_r_out > 0.0 && p->disk_r_in > p->disk_r_out) return fail(BHG_E_INVALID, "disk_r_in > disk_r_out");
@@ -330,6 +333,7 @@ void bhg_default_params(bhg_params *p)
     p->disk_r_in = 0.0;
     p->disk_r_out = 0.0;  // no disk
     p->spin = 0.0;
+    p->time_like = 0;
 }
 
 int bhg_create(int device, bhg_context **out)
@@ -498,6 +502,8 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     //   n_steps / n_accepted [n] u32 when the caller does not want them (the kernels never test these pointers)
     const bool has_exit = p->r_exit > 0.0;
     const bool kerr = p->rhs_form == BHG_RHS_KERR_BL;
+    // the kernels' right-hand-side id: the time-like Christoffel form is one of its own (the Kerr kernels take the norm at the start)
+    const int rhs_id = (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form;
     const bool needs_ws = bhg::needs_prepare_ws(p->rhs_form);   // only in a build without the inlined prepare
     const size_t sz_ws = needs_ws ? n * 8 * sizeof(double) : 0;
     const size_t sz_flags = d_flags ? 0 : ((n + 7) & ~size_t(7));
@@ -549,6 +555,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     a.disk_r_in = p->disk_r_in;
     a.disk_r_out = p->disk_r_out;
     a.spin = p->spin;
+    a.mu2 = p->time_like ? 1.0 : 0.0;
     a.r_hor = p->r_s;
     a.from_records = 0;
     a.ws_stride = 6;
@@ -578,14 +585,15 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
         for (int q = 0; q < 4; q++) a.spheres[j][q] = spheres[4 * j + q];
     // kernel variant: bit 0 exit sphere, bit 1 disk, bit 2 objects.  With objects: 5 = exit sphere and no disk (the
     // orbiting-sphere frames), otherwise 7, which tests for the exit sphere and the disk at run time
-    const int evt = n_spheres > 0 ? ((has_exit && !(p->disk_r_out > 0.0)) ? 5 : 7)
-                                  : ((has_exit ? 1 : 0) | (p->disk_r_out > 0.0 ? 2 : 0));
+    int evt = n_spheres > 0 ? ((has_exit && !(p->disk_r_out > 0.0)) ? 5 : 7)
+                            : ((has_exit ? 1 : 0) | (p->disk_r_out > 0.0 ? 2 : 0));
+    if (rhs_id == bhg::BHG_RHS_CHRISTOFFEL_TL_) evt = 7;    // (the time-like form exists in the all-events variant only)
 
     // resident waves per CU of the trace kernel variant: asked of the runtime once per variant and context
-    const int vkey = ((p->method & 1) * 3 + (p->rhs_form % 3)) * 8 + evt;
+    const int vkey = ((p->method & 1) * 3 + (p->rhs_form % 3)) * 8 + evt + (rhs_id == bhg::BHG_RHS_CHRISTOFFEL_TL_ ? 48 : 0);
     int per_cu = c->occupancy[vkey];
     if (per_cu == 0) {
-        HIP_TRY(bhg::trace_occupancy(p->method, p->rhs_form, evt, &per_cu));
+        HIP_TRY(bhg::trace_occupancy(p->method, rhs_id, evt, &per_cu));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 32) per_cu = 32;
         c->occupancy[vkey] = per_cu;
@@ -621,7 +629,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     // the call only enqueues (Kerr: trace, finalize) and returns
     if (!c->counters_clean) HIP_TRY(hipMemsetAsync(c->counter, 0, 2 * 8 * 256, s));   // first call, or after a failed enqueue
     c->counters_clean = false;
-    HIP_TRY(bhg::launch_trace(a, p->method, p->rhs_form, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
+    HIP_TRY(bhg::launch_trace(a, p->method, rhs_id, evt, (int)grid, s, c->profiling ? c->ev : nullptr));
     c->counter_set ^= 1;      // (the launch is in the stream: the next call of this context counts on the set it zeroes)
     c->counters_clean = true;
     c->ev_valid = c->profiling;
@@ -1260,6 +1268,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.h_fixed = p->h_fixed;
     a.r_exit = p->r_exit;
     a.spin = p->spin;
+    a.mu2 = p->time_like ? 1.0 : 0.0;
     a.r_hor = p->r_s;
     a.ws_stride = 6;
     if (p->rhs_form == BHG_RHS_KERR_BL) {
@@ -1270,7 +1279,8 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
-    HIP_TRY(bhg::launch_trajectory(a, p->rhs_form, (double *)o, (uint32_t *)(o + off_nv), n_points, s));
+    HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form,
+                                   (double *)o, (uint32_t *)(o + off_nv), n_points, s));
     const size_t total = off_flags + n;
     if (total <= (size_t(4) << 20)) {
         // the engine's per-ray call (one ray, 10,000 samples: 480 kB): ONE copy of the whole output block into page-locked
@@ -1310,7 +1320,8 @@ int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const
     double *dx = (double *)c->d_in, *dk = dx + 3 * n;
     HIP_TRY(hipMemcpyAsync(dx, x, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(dk, k, n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(bhg::launch_accel(dx, dk, p->r_s, p->spin, n, (double *)c->d_out, p->rhs_form, c->stream));
+    HIP_TRY(bhg::launch_accel(dx, dk, p->r_s, p->spin, p->time_like ? 1.0 : 0.0, n, (double *)c->d_out,
+                              (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form, c->stream));
     HIP_TRY(hipMemcpyAsync(acc, c->d_out, n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BHG_OK;

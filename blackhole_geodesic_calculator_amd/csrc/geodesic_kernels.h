@@ -21,6 +21,7 @@ constexpr int BHG_METHOD_DP54_ = 0;
 constexpr int BHG_METHOD_RK4_ = 1;
 constexpr int BHG_RHS_CHRISTOFFEL_ = 0;
 constexpr int BHG_RHS_REDUCED_ = 1;
+constexpr int BHG_RHS_CHRISTOFFEL_TL_ = 3;   // internal: the Christoffel form with g(k, k) = -1 (bhg_params.time_like), own translation unit
 constexpr int BHG_RHS_KERR_BL_ = 2;
 // rays per trace launch: the kernels form a ray's result offsets (idx * 48 at most) in 32 bits
 constexpr uint64_t BHG_MAX_RAYS_PER_LAUNCH = 1ull << 26;
@@ -42,6 +43,8 @@ struct TraceArgs {
     double min_step_cap;         // >= 10 ulp(t) for all t in [0, lambda_end]
     double r_exit, disk_r_in, disk_r_out;
     double spin;                 // Kerr a (BHG_RHS_KERR_BL_)
+    double mu2;                  // -g(k, k): 0 null rays, 1 time-like (read by the Kerr start conversion only; the Cartesian
+                                 // time-like form is a right-hand side of its own, BHG_RHS_CHRISTOFFEL_TL_)
     double h_fixed;
     // ---- chunk 2: parking (in the step loop's event branch), then the rare paths
     double *end_dir;             // nullptr, or [n][3]: FINAL states are written as their direction half only, here (end then
@@ -122,11 +125,16 @@ hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t
 hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu);
 hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+// ... and so does the time-like Christoffel form (geodesic_kernels_timelike.hip; one event variant)
+hipError_t launch_trace_timelike(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev);
+hipError_t trace_occupancy_timelike(int method, int *blocks_per_cu);
+hipError_t launch_trajectory_timelike(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+hipError_t launch_accel_timelike(const double *x, const double *k, double r_s, uint64_t n, double *acc, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 // rhs = Kerr: x, k and acc are Boyer-Lindquist (r, theta, phi) triples, E and L fixed by the null condition at each point
-hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, int rhs,
+hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, int rhs,
                         hipStream_t s);
-hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, hipStream_t s);
+hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, hipStream_t s);
 
 }  // namespace bhg

@@ -289,7 +289,8 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
 }
 
 // Kerr: a ray's Cartesian start state (x, k) -> Boyer-Lindquist (r, theta, phi) and d/dlambda of those, in place, plus the
-// Killing constants E = -k_t, L = k_phi from the null condition at the start point (future-directed root, g_tt < 0).
+// Killing constants E = -k_t, L = k_phi from the norm condition g(k, k) = -mu2 at the start point (mu2 = 0: the engine's
+// null rays; 1: time_like=True, proper time as parameter; future-directed root, g_tt < 0).
 //     x = sqrt(r^2 + a^2) sin th cos ph,  y = sqrt(r^2 + a^2) sin th sin ph,  z = r cos th
 // theta is DEFINED as acos(z / r) of the rounded quotient (the CPU checker's cart_to_bl): for the reference's camera, 1e-4
 // off the rotation axis at z = 30 (CamEdition.py:208-221), that quotient is 1 - 5.6e-12 and its rounding moves theta by
@@ -303,7 +304,7 @@ __device__ __forceinline__ void accel_kerr_bl(const double x[3], const double k[
 // About 330 instructions, 64 rays wide inside a trace wave's queue fill (the prepare pass uses the same function, so every
 // path starts a ray from bit-identical Boyer-Lindquist data).  A start ON the rotation axis (w = 0) has no azimuth: NaN, as
 // the checker's 3x3 solve gives (0 / 0).
-__device__ __forceinline__ void kerr_cart_to_bl(double a, double M, double px[3], double pk[3], double &E, double &L)
+__device__ __forceinline__ void kerr_cart_to_bl(double a, double M, double mu2, double px[3], double pk[3], double &E, double &L)
 {
     const double x = px[0], y = px[1], z = px[2], a2 = a * a;
     const double rho2 = x * x + y * y + z * z;
@@ -336,7 +337,7 @@ __device__ __forceinline__ void kerr_cart_to_bl(double a, double M, double px[3]
     const double s2 = st * st, tmr = 2.0 * M * r * iSig;        // 2 M r / Sigma
     const double gtt = tmr - 1.0, gtp = -tmr * a * s2;
     const double gpp = __builtin_fma(a2 * tmr, s2, R2) * s2;
-    const double S = __builtin_fma(gpp * u2, u2, __builtin_fma(Sig * u1, u1, Sig * iDel * u0 * u0));
+    const double S = __builtin_fma(gpp * u2, u2, __builtin_fma(Sig * u1, u1, Sig * iDel * u0 * u0)) + mu2;   // g(k, k) = -mu2
     const double B = gtp * u2;
     const double kt = (-B - sqrt_nr(__builtin_fma(B, B, -(gtt * S)))) * rcp_nr(gtt);
     E = -__builtin_fma(gtt, kt, gtp * u2);
@@ -381,6 +382,7 @@ __device__ __forceinline__ void accel(const double x[3], const double k[3], cons
         //   s = f' [ 1/2 ((|k|^2 + h (n.k)^2) - (n.k)^2 / f) + (|k|^2 - (n.k)^2) ]
         // (three multiplications fewer per evaluation than forming g and 1/2 f g; the 1/f singularity stays in h and q)
         double T = __builtin_fma(h, nk2, kk);
+        if (RHS == BHG_RHS_CHRISTOFFEL_TL_) T += 1.0;   // time_like=True: f (k^t)^2 = |k|^2 + h (n.k)^2 + 1, the one place the norm enters
         double Y = __builtin_fma(0.5, __builtin_fma(-q, nk2, T), kk - nk2);
         c = (-u * w) * Y;              // f' / r = r_s / r^3 = (r_s / r) (1 / r^2)
     }
@@ -1203,7 +1205,7 @@ __device__ __forceinline__ void fill_batch(const TraceArgs &A, LDS &Q, Wave &W, 
         double r0;
         if (RHS == BHG_RHS_KERR_BL_) {
             met.a = A.spin;
-            kerr_cart_to_bl(met.a, met.M, px, pk, met.E, met.L);
+            kerr_cart_to_bl(met.a, met.M, A.mu2, px, pk, met.E, met.L);
             pE = met.E;
             pL = met.L;
             r0 = px[0];
@@ -2576,7 +2578,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
     met.E = met.L = 0.0;
     double cx[3] = {px[0], px[1], px[2]}, ck[3] = {pk[0], pk[1], pk[2]};  // Cartesian input, kept for start-inside
     if (RHS == BHG_RHS_KERR_BL_) {
-        kerr_cart_to_bl(met.a, met.M, px, pk, met.E, met.L);
+        kerr_cart_to_bl(met.a, met.M, A.mu2, px, pk, met.E, met.L);
     }
     const double r0 = (RHS == BHG_RHS_KERR_BL_)
                           ? px[0]
@@ -2612,7 +2614,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(const TraceArgs A)
 // Acceleration probe for the Boyer-Lindquist form: x = (r, theta, phi), k = d/dlambda of those; the Killing constants
 // E = -k_t, L = k_phi from the null condition AT THE POINT (the formula the prepare pass applies at the camera), then the
 // right-hand side the trace kernels run (accel_kerr_bl).  acc is d^2 (r, theta, phi) / dlambda^2.
-__global__ void accel_kerr_kernel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc)
+__global__ void accel_kerr_kernel(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2626,7 +2628,7 @@ __global__ void accel_kerr_kernel(const double *x, const double *k, double r_s, 
     const double Sig = r * r + a * a * c2, Del = r * r - 2.0 * M * r + a * a;
     const double gtt = -(1.0 - 2.0 * M * r / Sig), gtp = -2.0 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
     const double gpp = (r * r + a * a + 2.0 * M * a * a * r * s2 / Sig) * s2;
-    const double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+    const double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2] + mu2;
     const double B = gtp * u[2];
     const double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
     met.E = -(gtt * kt + gtp * u[2]);
@@ -2638,11 +2640,11 @@ __global__ void accel_kerr_kernel(const double *x, const double *k, double r_s, 
     acc[3 * i + 2] = a3[2];
 }
 
-hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, hipStream_t s)
+hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, hipStream_t s)
 {
     const int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(accel_kerr_kernel, dim3(grid), dim3(256), 0, s, x, k, r_s, spin, n, acc);
+    hipLaunchKernelGGL(accel_kerr_kernel, dim3(grid), dim3(256), 0, s, x, k, r_s, spin, mu2, n, acc);
     return hipGetLastError();
 }
 
@@ -2878,38 +2880,40 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
 // one wave per ray while the rays are too few to fill the chip's lanes anyway
 __host__ inline bool trajectory_wave_per_ray(uint64_t n) { return n <= 2048; }
 
-#ifdef BHG_TU_KERR
-hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+// prepare pass + sampled trajectories of one right-hand side
+template <int RHS>
+static void launch_trajectory_rhs(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
-    hipLaunchKernelGGL((prepare_kernel<BHG_RHS_KERR_BL_, true>), dim3(gp), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
     if (trajectory_wave_per_ray(a.n))
-        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_, true>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, true>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
     else
-        hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_KERR_BL_, false>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
-    hipLaunchKernelGGL(kerr_finalize_kernel, dim3(gp), dim3(256), 0, s, a, (double *)nullptr);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, false>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+}
+
+#if defined(BHG_TU_KERR)
+hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+{
+    launch_trajectory_rhs<BHG_RHS_KERR_BL_>(a, traj, n_valid, T, s);
+    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, (double *)nullptr);
+    return hipGetLastError();
+}
+#elif defined(BHG_TU_TIMELIKE)
+hipError_t launch_trajectory_timelike(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+{
+    launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_TL_>(a, traj, n_valid, T, s);
     return hipGetLastError();
 }
 #else
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     if (rhs == BHG_RHS_KERR_BL_) return launch_trajectory_kerr(a, traj, n_valid, T, s);
-    const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
-    const bool wave = trajectory_wave_per_ray(a.n);
-    const dim3 g(wave ? (unsigned)a.n : gt);
-    if (rhs == BHG_RHS_REDUCED_) {
-        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_REDUCED_, true>), dim3(gp), dim3(256), 0, s, a);
-        if (wave)
-            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_, true>), g, dim3(64), 0, s, a, traj, n_valid, T);
-        else
-            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_REDUCED_, false>), g, dim3(64), 0, s, a, traj, n_valid, T);
-    } else {
-        hipLaunchKernelGGL((prepare_kernel<BHG_RHS_CHRISTOFFEL_, true>), dim3(gp), dim3(256), 0, s, a);
-        if (wave)
-            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_, true>), g, dim3(64), 0, s, a, traj, n_valid, T);
-        else
-            hipLaunchKernelGGL((trajectory_dp54_kernel<BHG_RHS_CHRISTOFFEL_, false>), g, dim3(64), 0, s, a, traj, n_valid, T);
-    }
+    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return launch_trajectory_timelike(a, traj, n_valid, T, s);
+    if (rhs == BHG_RHS_REDUCED_)
+        launch_trajectory_rhs<BHG_RHS_REDUCED_>(a, traj, n_valid, T, s);
+    else
+        launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_>(a, traj, n_valid, T, s);
     return hipGetLastError();
 }
 #endif
@@ -3001,6 +3005,27 @@ hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu)
     default: return occupancy_variant<BHG_RHS_KERR_BL_, 3>(method, blocks_per_cu);
     }
 }
+#elif defined(BHG_TU_TIMELIKE)
+// time_like = True in the Cartesian Christoffel form (geodesic_kernels_timelike.hip): a translation unit of its own with ONE
+// event variant, 7 -- exit sphere, disk and object spheres all tested at run time.  Massive-particle orbits are the
+// plotting path (README Fig. 5/6 style curves), not the frame path: they need to be right, not to be tuned per event set.
+hipError_t launch_trace_timelike(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev)
+{
+    return launch_variant<BHG_RHS_CHRISTOFFEL_TL_, 7>(a, method, grid, s, ev);
+}
+
+hipError_t trace_occupancy_timelike(int method, int *blocks_per_cu)
+{
+    return occupancy_variant<BHG_RHS_CHRISTOFFEL_TL_, 7>(method, blocks_per_cu);
+}
+
+hipError_t launch_accel_timelike(const double *x, const double *k, double r_s, uint64_t n, double *acc, hipStream_t s)
+{
+    const int grid = (int)((n + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((accel_kernel<BHG_RHS_CHRISTOFFEL_TL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+    return hipGetLastError();
+}
 #else
 template <int RHS>
 static hipError_t launch_rhs(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev)
@@ -3031,6 +3056,7 @@ static hipError_t occupancy_rhs(int method, int evt, int *blocks_per_cu)
 hipError_t launch_trace(const TraceArgs &a, int method, int rhs, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
     if (rhs == BHG_RHS_KERR_BL_) return launch_trace_kerr(a, method, evt, grid, s, ev);
+    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return launch_trace_timelike(a, method, grid, s, ev);
     return rhs == BHG_RHS_REDUCED_ ? launch_rhs<BHG_RHS_REDUCED_>(a, method, evt, grid, s, ev)
                                    : launch_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, evt, grid, s, ev);
 }
@@ -3040,14 +3066,16 @@ bool needs_prepare_ws(int) { return !BHG_INLINE_PREPARE; }
 hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu)
 {
     if (rhs == BHG_RHS_KERR_BL_) return trace_occupancy_kerr(method, evt, blocks_per_cu);
+    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return trace_occupancy_timelike(method, blocks_per_cu);
     return rhs == BHG_RHS_REDUCED_ ? occupancy_rhs<BHG_RHS_REDUCED_>(method, evt, blocks_per_cu)
                                    : occupancy_rhs<BHG_RHS_CHRISTOFFEL_>(method, evt, blocks_per_cu);
 }
 
-hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, uint64_t n, double *acc, int rhs,
+hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, int rhs,
                         hipStream_t s)
 {
-    if (rhs == BHG_RHS_KERR_BL_) return launch_accel_kerr(x, k, r_s, spin, n, acc, s);
+    if (rhs == BHG_RHS_KERR_BL_) return launch_accel_kerr(x, k, r_s, spin, mu2, n, acc, s);
+    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return launch_accel_timelike(x, k, r_s, n, acc, s);
     int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
     if (rhs == BHG_RHS_REDUCED_)

@@ -23,20 +23,24 @@ _RHS = {"christoffel": _ffi.RHS_CHRISTOFFEL, "reduced": _ffi.RHS_REDUCED, "kerr_
 
 
 class GeodesicIntegratorSchwarzschild:
-    """Null-geodesic integrator around a Schwarzschild black hole of horizon radius 2*mass."""
+    """Geodesic integrator around a Schwarzschild black hole of horizon radius 2*mass: null rays (time_like=False, what
+    the engine asks for) or massive particles (time_like=True)."""
 
     def __init__(self, mass=1.0, time_like=False, verbose=False, *, device=0, rtol=1e-3, atol=1e-6,
                  method="RK45", rhs_form="christoffel", h_fixed=0.1, max_steps=0, context=None):
-        if time_like:
-            # the engine only ever passes time_like=False (RelativisticRenderEngine.py:134)
-            raise NotImplementedError("only null geodesics (time_like=False) are on the GPU path")
         if method not in _METHODS:
             raise ValueError(f"method must be one of {sorted(_METHODS)}")
         if rhs_form not in _RHS:
             raise ValueError(f"rhs_form must be one of {sorted(_RHS)}")
         self.mass = float(mass)
         self.r_s = 2.0 * self.mass  # R_horizon = 2*M in geometrized units (:95)
-        self.time_like = False
+        # time_like=True: massive particles, g(k, k) = -1, the curve parameter is the proper time -- the initial
+        # "direction" k0 is then dx/dtau (the engine only ever passes False, RelativisticRenderEngine.py:134).  The norm
+        # enters the Christoffel form through (k^t)^2 and the Boyer-Lindquist form through E and L at the start; the
+        # reduced form is the closed form for NULL rays and cannot be asked for it.
+        self.time_like = bool(time_like)
+        if self.time_like and rhs_form == "reduced":
+            raise ValueError("rhs_form='reduced' is the null closed form: time_like=True needs 'christoffel' or 'kerr_bl'")
         self.verbose = bool(verbose)
         self.rtol, self.atol = float(rtol), float(atol)
         self.method, self.rhs_form = method, rhs_form
@@ -56,7 +60,7 @@ class GeodesicIntegratorSchwarzschild:
                                 atol=self.atol, h_fixed=self.h_fixed, r_exit=r_exit,
                                 method=_METHODS[self.method], rhs_form=_RHS[self.rhs_form],
                                 max_steps=self.max_steps, disk_r_in=disk[0] if disk else 0.0,
-                                disk_r_out=disk[1] if disk else 0.0, spin=self.spin)
+                                disk_r_out=disk[1] if disk else 0.0, spin=self.spin, time_like=self.time_like)
 
     # ------------------------------------------------------------------------------------
     def trace(self, k0, x0, max_step=np.inf, curve_end=50.0, r_exit=0.0, disk=None, spheres=None):

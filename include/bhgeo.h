@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 6
+#define BHG_ABI_VERSION 6   /* 6: bhg_frame_* (library-owned frame, N devices), bhg_deal_tiles, bhg_params.time_like (104 bytes) */
 
 /* return codes */
 #define BHG_OK 0
@@ -105,6 +105,12 @@ typedef struct bhg_params {
                            BHG_RHS_KERR_BL: the equatorial plane theta = pi/2 (z = r cos theta = 0), the
                            annulus in the cylindrical radius sqrt(r^2 + a^2) */
     double spin;        /* Kerr a in length units, |a| < M = r_s/2 (BHG_RHS_KERR_BL only) */
+    int32_t time_like;  /* 0: null geodesics, g(k, k) = 0 -- what the engine asks for (time_like=False, :134); 1: the
+                           constructor argument's other value, massive particles: g(k, k) = -1, lambda is the proper time.
+                           With BHG_RHS_CHRISTOFFEL (the norm enters through (k^t)^2 = (|k|^2 + h (n.k)^2 + 1) / f) and
+                           BHG_RHS_KERR_BL (through E and L at the start); BHG_RHS_REDUCED is the null closed form and
+                           refuses it.  The plotting path (bhg_trajectory, bhg_trace): no frame pipeline asks for it. */
+    int32_t reserved0;  /* 0 */
 } bhg_params;
 
 typedef struct bhg_context bhg_context;

@@ -76,7 +76,8 @@ typedef struct {
     int32_t method;    /* BHGO_METHOD_* */
     int32_t rhs_form;  /* BHGO_RHS_* */
     uint32_t max_steps; /* cap on attempted steps per ray, 0 = no cap */
-    uint32_t reserved;
+    uint32_t time_like; /* 0: null geodesics, g(k, k) = 0 (time_like=False, RelativisticRenderEngine.py:134); 1: massive
+                           particles, g(k, k) = -1 with the proper time as parameter (the constructor's other value) */
     double disk_r_in;  /* thin disk in the plane z = 0: annulus R_in <= R <= R_out; off when R_out <= 0 */
     double disk_r_out; /* (LimitedRelativisticRenderEngine.py:283-286, :413-438) */
     double spin;       /* Kerr a (length units, |a| < M = r_s/2); used by BHGO_RHS_KERR_BL only */
@@ -103,8 +104,9 @@ typedef struct {
  * RHS: the spatial acceleration -Gamma^i_{mu nu} k^mu k^nu with k^t from the null condition
  * (README.md:198-209; time_like=False at RelativisticRenderEngine.py:134).
  * ------------------------------------------------------------------------------------- */
-static void acc_christoffel(const double x[3], const double k[3], double r_s, double a[3])
+static void acc_christoffel(const double x[3], const double k[3], double r_s, double mu2, double a[3])
 {
+    /* (mu2 = -g(k, k): 0 for the null rays of the engine, 1 for time_like=True -- the only place the norm enters) */
     /* a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ],
        f = 1 - r_s/r, f' = r_s/r^2, h = r_s/(r - r_s), h' = -r_s/(r - r_s)^2,
        (k^t)^2 = (|k|^2 + h (n.k)^2)/f.  Singular at r = r_s, like the lambdified contraction. */
@@ -116,7 +118,7 @@ static void acc_christoffel(const double x[3], const double k[3], double r_s, do
     double fp = r_s / r2;
     double h = r_s / (r - r_s);
     double hp = -r_s / ((r - r_s) * (r - r_s));
-    double kt2 = (kk + h * nk * nk) / f;
+    double kt2 = (kk + h * nk * nk + mu2) / f;
     double s = 0.5 * f * fp * kt2 + 0.5 * f * hp * nk * nk + (r_s / r2) * (kk - nk * nk);
     double c = -s / r;
     a[0] = c * x[0];
@@ -124,14 +126,15 @@ static void acc_christoffel(const double x[3], const double k[3], double r_s, do
     a[2] = c * x[2];
 }
 
-static void acc_reduced(const double x[3], const double k[3], double r_s, double a[3])
+static void acc_reduced(const double x[3], const double k[3], double r_s, double mu2, double a[3])
 {
-    /* algebraically identical for null rays: a = -(3/2) r_s |x cross k|^2 x / r^5 */
+    /* algebraically identical for null rays: a = -(3/2) r_s |x cross k|^2 x / r^5; a massive particle (mu2 = 1) feels
+       the Newtonian term as well: d^2 r / dtau^2 = -M / r^2 + L^2 / r^3 - 3 M L^2 / r^4, i.e. - (r_s / 2) mu2 x / r^3 */
     double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
     double xk = x[0] * k[0] + x[1] * k[1] + x[2] * k[2];
     double L2 = r2 * kk - xk * xk;
-    double c = -1.5 * r_s * L2 / (r2 * r2 * sqrt(r2));
+    double c = -1.5 * r_s * L2 / (r2 * r2 * sqrt(r2)) - 0.5 * r_s * mu2 / (r2 * sqrt(r2));
     a[0] = c * x[0];
     a[1] = c * x[1];
     a[2] = c * x[2];
@@ -174,9 +177,9 @@ static void rhs(const bhgo_params *p, const rayctx *rc, const double y[6], doubl
         return;
     }
     if (p->rhs_form == BHGO_RHS_REDUCED)
-        acc_reduced(x, k, p->r_s, a);
+        acc_reduced(x, k, p->r_s, p->time_like ? 1.0 : 0.0, a);
     else
-        acc_christoffel(x, k, p->r_s, a);
+        acc_christoffel(x, k, p->r_s, p->time_like ? 1.0 : 0.0, a);
     dy[0] = a[0];
     dy[1] = k[0];
     dy[2] = a[1];
@@ -822,12 +825,12 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
             memcpy(res->end + 3, k0, sizeof(double) * 3);
             return;
         }
-        /* E = -k_t, L = k_phi from the null condition at the camera (future-directed root, g_tt < 0) */
+        /* E = -k_t, L = k_phi from the norm condition g(k, k) = -mu2 at the camera (future-directed root, g_tt < 0) */
         double r = q[0], th = q[1], s2 = sin(th) * sin(th), c2 = cos(th) * cos(th);
         double Sig = r * r + a * a * c2, Del = r * r - 2 * M * r + a * a;
         double gtt = -(1 - 2 * M * r / Sig), gtp = -2 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
         double gpp = (r * r + a * a + 2 * M * a * a * r * s2 / Sig) * s2;
-        double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+        double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2] + (p->time_like ? 1.0 : 0.0);
         double B = gtp * u[2];
         double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
         rc.E = -(gtt * kt + gtp * u[2]);
@@ -976,16 +979,16 @@ int bhgo_acceleration(const bhgo_params *p, const double *x, const double *k, si
             double Sig = r * r + a * a * c2, Del = r * r - 2 * M * r + a * a;
             double gtt = -(1 - 2 * M * r / Sig), gtp = -2 * M * a * r * s2 / Sig, grr = Sig / Del, gthth = Sig;
             double gpp = (r * r + a * a + 2 * M * a * a * r * s2 / Sig) * s2;
-            double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2];
+            double S = grr * u[0] * u[0] + gthth * u[1] * u[1] + gpp * u[2] * u[2] + (p->time_like ? 1.0 : 0.0);
             double B = gtp * u[2];
             double kt = (-B - sqrt(B * B - gtt * S)) / gtt;
             rc.E = -(gtt * kt + gtp * u[2]);
             rc.L = gtp * kt + gpp * u[2];
             acc_kerr_bl(&rc, q, u, acc + 3 * i);
         } else if (p->rhs_form == BHGO_RHS_REDUCED)
-            acc_reduced(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);
+            acc_reduced(x + 3 * i, k + 3 * i, p->r_s, p->time_like ? 1.0 : 0.0, acc + 3 * i);
         else
-            acc_christoffel(x + 3 * i, k + 3 * i, p->r_s, acc + 3 * i);
+            acc_christoffel(x + 3 * i, k + 3 * i, p->r_s, p->time_like ? 1.0 : 0.0, acc + 3 * i);
     }
     return 0;
 }

@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("method", C.c_int32),
         ("rhs_form", C.c_int32),
         ("max_steps", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("time_like", C.c_uint32),
         ("disk_r_in", C.c_double),
         ("disk_r_out", C.c_double),
         ("spin", C.c_double),
@@ -58,9 +58,9 @@ class Params(C.Structure):
 
 def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, h_fixed=0.1,
                 r_exit=0.0, method=METHOD_DP54, rhs_form=RHS_CHRISTOFFEL, max_steps=0, disk_r_in=0.0,
-                disk_r_out=0.0, spin=0.0, spheres=None):
+                disk_r_out=0.0, spin=0.0, spheres=None, time_like=0):
     p = Params(r_s, lambda_end, max_step, rtol, atol, h_fixed, r_exit, method, rhs_form,
-               max_steps, 0, disk_r_in, disk_r_out, spin)
+               max_steps, int(time_like), disk_r_in, disk_r_out, spin)
     if spheres is not None:
         sp = np.asarray(spheres, dtype=np.float64).reshape(-1, 4)
         assert len(sp) <= MAX_SPHERES

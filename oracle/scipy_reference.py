@@ -95,8 +95,9 @@ def sympy_christoffel_rhs():
 # --------------------------------------------------------------------------------------
 # RHS form 2/3: hand-reduced forms, numpy scalar arithmetic
 # --------------------------------------------------------------------------------------
-def acc_christoffel(x, k, r_s):
-    """a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ]."""
+def acc_christoffel(x, k, r_s, mu2=0.0):
+    """a = -n [ 1/2 f f' (k^t)^2 + 1/2 f h' (n.k)^2 + (r_s/r^2)(|k|^2 - (n.k)^2) ]; mu2 = -g(k, k): 0 for the engine's
+    null rays (time_like=False), 1 for massive particles (time_like=True) -- it enters through (k^t)^2 only."""
     r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2]
     r = np.sqrt(r2)
     nk = (x[0] * k[0] + x[1] * k[1] + x[2] * k[2]) / r
@@ -105,25 +106,28 @@ def acc_christoffel(x, k, r_s):
     fp = r_s / r2
     h = r_s / (r - r_s)
     hp = -r_s / ((r - r_s) * (r - r_s))
-    kt2 = (kk + h * nk * nk) / f
+    kt2 = (kk + h * nk * nk + mu2) / f
     s = 0.5 * f * fp * kt2 + 0.5 * f * hp * nk * nk + (r_s / r2) * (kk - nk * nk)
     c = -s / r
     return np.array([c * x[0], c * x[1], c * x[2]])
 
 
-def acc_reduced(x, k, r_s):
-    """a = -(3/2) r_s |x cross k|^2 x / r^5, L^2 recomputed from the current state."""
+def acc_reduced(x, k, r_s, mu2=0.0):
+    """a = -(3/2) r_s |x cross k|^2 x / r^5, L^2 recomputed from the current state (+ the Newtonian term
+    -(r_s/2) mu2 x / r^3 for a massive particle: d^2 r/dtau^2 = -M/r^2 + L^2/r^3 - 3 M L^2/r^4)."""
     r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2]
     kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2]
     xk = x[0] * k[0] + x[1] * k[1] + x[2] * k[2]
     L2 = r2 * kk - xk * xk
-    c = -1.5 * r_s * L2 / (r2 * r2 * np.sqrt(r2))
+    c = -1.5 * r_s * L2 / (r2 * r2 * np.sqrt(r2)) - 0.5 * r_s * mu2 / (r2 * np.sqrt(r2))
     return np.array([c * x[0], c * x[1], c * x[2]])
 
 
-def make_rhs(r_s, form="christoffel"):
+def make_rhs(r_s, form="christoffel", time_like=False):
     """RHS f(t, y) on the 6-D state [k_x, x, k_y, y, k_z, z]."""
+    mu2 = 1.0 if time_like else 0.0
     if form == "sympy":
+        assert not time_like, "the sympy-derived contraction is the null one"
         fn = sympy_christoffel_rhs()
 
         def rhs(_t, y):
@@ -134,7 +138,7 @@ def make_rhs(r_s, form="christoffel"):
         acc = {"christoffel": acc_christoffel, "reduced": acc_reduced}[form]
 
         def rhs(_t, y):
-            a = acc((y[1], y[3], y[5]), (y[0], y[2], y[4]), r_s)
+            a = acc((y[1], y[3], y[5]), (y[0], y[2], y[4]), r_s, mu2)
             return np.array([a[0], y[0], a[1], y[2], a[2], y[4]])
 
     return rhs
@@ -155,8 +159,8 @@ FLAG_HIT_OBJECT = 0x88
 
 
 def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
-              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None, disk=None, spheres=None):
-    """Integrate one null geodesic with scipy.solve_ivp; returns a dict.
+              form="christoffel", method="RK45", r_exit=0.0, nr_points_curve=None, disk=None, spheres=None, time_like=False):
+    """Integrate one null (time_like=True: time-like, parameter = proper time) geodesic with scipy.solve_ivp; returns a dict.
 
     Events: horizon r - r_s = 0 (terminal, any direction); optional outward sphere exit
     r - r_exit = 0 (terminal, direction +1) as the Limited engine's ray_trace does
@@ -211,7 +215,7 @@ def trace_ray(k0, x0, r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol
     t_eval = None
     if nr_points_curve:
         t_eval = np.linspace(0.0, lambda_end, nr_points_curve)
-    sol = solve_ivp(make_rhs(r_s, form), (0.0, lambda_end), y0, method=method, events=events,
+    sol = solve_ivp(make_rhs(r_s, form, time_like), (0.0, lambda_end), y0, method=method, events=events,
                     max_step=max_step, rtol=rtol, atol=atol, t_eval=t_eval)
     flags = 0
     if sol.status == 1:
@@ -353,10 +357,10 @@ def bl_to_cart(q, u, a):
     return x, bl_jacobian(r, th, ph, a) @ np.asarray(u)
 
 
-def kerr_constants(q, u, M, a):
-    """E = -k_t, L = k_phi from the null condition at the start (future-directed root, g_tt < 0)."""
+def kerr_constants(q, u, M, a, mu2=0.0):
+    """E = -k_t, L = k_phi from the norm condition g(k, k) = -mu2 at the start (future-directed root, g_tt < 0)."""
     gtt, gtp, grr, gthth, gpp = kerr_metric(q[0], q[1], M, a)
-    S = grr * u[0] ** 2 + gthth * u[1] ** 2 + gpp * u[2] ** 2
+    S = grr * u[0] ** 2 + gthth * u[1] ** 2 + gpp * u[2] ** 2 + mu2
     B = gtp * u[2]
     kt = (-B - np.sqrt(B * B - gtt * S)) / gtt
     return -(gtt * kt + gtp * u[2]), gtp * kt + gpp * u[2], kt
@@ -366,7 +370,7 @@ KERR_HORIZON_MARGIN = 1e-3  # terminal event at r = r_plus (1 + margin): BL coor
 
 
 def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, method="RK45",
-                   disk=None):
+                   disk=None, time_like=False):
     """One null geodesic in Kerr; state y = [ur, r, uth, th, uph, ph]; Cartesian in, Cartesian out.
     disk=(R_in, R_out): thin disk in the equatorial plane z = r cos(th) = 0, annulus in the cylindrical
     radius sqrt(x^2 + y^2) = sqrt(r^2 + a^2) |sin th|; a NON-terminal event g = cos(th), the first crossing
@@ -379,7 +383,7 @@ def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol
     if q0[0] <= r_h:
         out.update(flags=FLAG_START_INSIDE | FLAG_HIT_HORIZON, end=np.concatenate([x0, k0]))
         return out
-    E, L, _ = kerr_constants(q0, u0, M, a)
+    E, L, _ = kerr_constants(q0, u0, M, a, 1.0 if time_like else 0.0)
 
     def rhs(_t, y):
         ar, ath, aph, _kt = fn(y[1], y[3], y[0], y[2], y[4], E, L, M, a)

@@ -242,8 +242,42 @@ def main_kerr_disk():
          n_accepted=np.array([r["n_accepted"] for r in res], np.uint32), t_end=np.array([r["t_end"] for r in res]))
 
 
+def main_timelike():
+    # ---- 13. time_like=True (the solver object's other constructor value, RelativisticRenderEngine.py:134): massive
+    # particles, g(k, k) = -1, parameter = proper time.  Orbits from four radii with a circular-orbit speed scaled by
+    # 0 (radial plunge) ... 1.6 (unbound), tilted out of the equatorial plane, some with a radial component; once through
+    # scipy on the Cartesian Christoffel form, once through the Boyer-Lindquist solve with a/M = 0.9 ----
+    M, a = 0.5, 0.45
+    ks, xs = [], []
+    rng = np.random.default_rng(13)
+    for r0 in (3.2, 4.0, 6.0, 10.0):
+        v_circ = math.sqrt(M / (r0 - 3 * M))                 # r dphi/dtau of the circular orbit at r0 (needs r0 > 3M)
+        for scale in (0.0, 0.6, 1.0, 1.25, 1.6):
+            ang = rng.uniform(0.0, 2 * math.pi)
+            inc = rng.uniform(0.2, 1.2)
+            pos = r0 * np.array([math.cos(ang) * math.sin(inc), math.sin(ang) * math.sin(inc), math.cos(inc)])
+            e_r = pos / r0
+            e_t = np.cross(e_r, np.array([0.3, -0.5, 0.8]))
+            e_t /= np.linalg.norm(e_t)
+            vr = rng.choice([0.0, 0.0, -0.15, 0.1])
+            ks.append(scale * v_circ * e_t + vr * e_r)
+            xs.append(pos)
+    k0, x0 = np.array(ks), np.array(xs)
+    rs = [sr.trace_ray(k0[i], x0[i], r_s=1.0, lambda_end=150.0, time_like=True) for i in range(len(k0))]
+    rk = [sr.trace_ray_kerr(k0[i], x0[i], M, a, lambda_end=150.0, time_like=True) for i in range(len(k0))]
+    save("timelike", k0=k0, x0=x0, r_s=1.0, spin=a, lambda_end=150.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
+         end=np.array([r["end"] for r in rs]), flags=np.array([r["flags"] for r in rs], np.uint8),
+         n_attempted=np.array([r["n_attempted"] for r in rs], np.uint32), n_accepted=np.array([r["n_accepted"] for r in rs], np.uint32),
+         t_end=np.array([r["t_end"] for r in rs]),
+         kerr_end=np.array([r["end"] for r in rk]), kerr_flags=np.array([r["flags"] for r in rk], np.uint8),
+         kerr_n_attempted=np.array([r["n_attempted"] for r in rk], np.uint32),
+         kerr_n_accepted=np.array([r["n_accepted"] for r in rk], np.uint32), kerr_t_end=np.array([r["t_end"] for r in rk]))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "timelike"):
+        main_timelike()
     if which in ("all",):
         main()
     if which in ("all", "disk"):

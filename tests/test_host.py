@@ -57,7 +57,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_params_struct_layout_and_defaults():
     from blackhole_geodesic_calculator_amd import _ffi
-    assert ctypes.sizeof(_ffi.Params) == 96
+    assert ctypes.sizeof(_ffi.Params) == 104
     p = _ffi.default_params()
     assert (p.r_s, p.lambda_end, p.rtol, p.atol) == (1.0, 50.0, 1e-3, 1e-6)
     assert p.max_step == float("inf") and p.method == _ffi.METHOD_DP54 and p.rhs_form == _ffi.RHS_CHRISTOFFEL
@@ -87,12 +87,14 @@ def test_product_never_imports_oracle():
 
 def test_integrator_argument_checks():
     from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
-    with pytest.raises(NotImplementedError):
-        GeodesicIntegratorSchwarzschild(mass=0.5, time_like=True, context=object())
+    with pytest.raises(ValueError):     # the reduced form is the null closed form
+        GeodesicIntegratorSchwarzschild(mass=0.5, time_like=True, rhs_form="reduced", context=object())
+    tl = GeodesicIntegratorSchwarzschild(mass=0.5, time_like=True, context=object())
+    assert tl.time_like is True and tl.params().time_like == 1
     with pytest.raises(ValueError):
         GeodesicIntegratorSchwarzschild(mass=0.5, method="LSODA", context=object())
     gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=object())
-    assert gi.r_s == 1.0
+    assert gi.r_s == 1.0 and gi.params().time_like == 0
     assert gi.params(max_step=-1).max_step == float("inf")
 
 
@@ -113,7 +115,7 @@ def test_public_header_is_plain_c(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-x", "c++",
                            "-fsyntax-only", str(src)])
     out = subprocess.check_output([str(exe)]).decode().split()
-    assert int(out[0]) == ctypes.sizeof(_ffi.Params) == 96
+    assert int(out[0]) == ctypes.sizeof(_ffi.Params) == 104
     assert int(out[1]) == ctypes.sizeof(_ffi.Scene)
     assert int(out[2]) == _ffi.ABI_VERSION and int(out[3]) == _ffi.MAX_SPHERES
     assert int(out[4]) == ctypes.sizeof(_ffi.FrameScene) and int(out[5]) == ctypes.sizeof(_ffi.Camera)

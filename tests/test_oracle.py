@@ -399,3 +399,61 @@ def test_kerr_acceleration_probe_against_hamiltonian_form(oracle):
         tol = 1e-9 + 1e-12 / ((q[:, 0] - r_plus) / r_plus) ** 2
         assert np.all(rel < tol), (M, a, float((rel / tol).max()))
         assert np.median(rel) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# time_like=True: the solver object's other constructor value (RelativisticRenderEngine.py:134) -- massive particles
+# ------------------------------------------------------------------------------------------------------------------------
+def test_oracle_timelike_matches_scipy_golden(oracle):
+    g = load_golden("timelike")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=float(g["lambda_end"]), time_like=1)
+    assert np.array_equal(o["flags"], g["flags"]) and set(o["flags"].tolist()) == {1, 4}
+    assert np.array_equal(o["n_attempted"], g["n_attempted"]) and np.array_equal(o["n_accepted"], g["n_accepted"])
+    assert np.abs(o["end"] - g["end"]).max() < 5e-10
+    k = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=float(g["lambda_end"]), time_like=1, rhs_form=oracle.RHS_KERR_BL,
+                     spin=float(g["spin"]))
+    assert np.array_equal(k["flags"], g["kerr_flags"])
+    assert np.array_equal(k["n_attempted"], g["kerr_n_attempted"]) and np.array_equal(k["n_accepted"], g["kerr_n_accepted"])
+    d = np.abs(k["end"] - g["kerr_end"]).max(1)
+    assert d[k["flags"] == 4].max() < 1e-9 and d.max() < 1e-6      # (horizon ends: k diverges at r_plus)
+
+
+def test_timelike_known_answers(oracle):
+    """Circular orbits of the Schwarzschild metric (r_s = 1, M = 1/2): r dphi/dtau = sqrt(M / (r - 3M)), proper period
+    2 pi r / that; stable above r = 6M = 3, so after one period the particle is back where it started -- in the Christoffel
+    form, in the reduced form (with its Newtonian term) and in Boyer-Lindquist coordinates with a = 0.  A particle dropped
+    from rest at r0 falls radially and crosses the horizon after tau = integral_{r_s}^{r0} dr / sqrt(r_s/r - r_s/r0)."""
+    M = 0.5
+    kw = dict(r_s=1.0, rtol=1e-11, atol=1e-13, time_like=1)
+    for r0 in (3.5, 4.0, 8.0):
+        v = math.sqrt(M / (r0 - 3 * M))
+        T = 2 * math.pi * r0 / v
+        x0 = np.array([r0, 0.0, 0.0]) @ np.array([[0.8, 0.0, 0.6], [0.0, 1.0, 0.0], [-0.6, 0.0, 0.8]])   # a tilted plane
+        e_t = np.array([0.0, 1.0, 0.0])
+        for rf in (0, 1, 2):
+            o = oracle.trace((v * e_t)[None], x0, lambda_end=T, rhs_form=rf, spin=0.0, **kw)
+            assert o["flags"][0] == 4
+            assert np.abs(o["end"][0, 0:3] - x0).max() < 2e-7 * r0 and np.abs(o["end"][0, 3:6] - v * e_t).max() < 1e-7, (r0, rf)
+    from scipy.integrate import quad
+    r0 = 6.0
+    tau, _ = quad(lambda r: 1.0 / math.sqrt(1.0 / r - 1.0 / r0), 1.0, r0, epsabs=1e-12, epsrel=1e-12, limit=200)
+    for rf in (0, 1):
+        o = oracle.trace(np.zeros((1, 3)), np.array([0.0, 0.0, r0]), lambda_end=2 * tau, rhs_form=rf, **kw)
+        assert o["flags"][0] == 1 and abs(o["t_end"][0] - tau) < 1e-6 * tau, (rf, o["t_end"][0], tau)
+    # the norm stays -1: -E^2 / f + |k|^2 + h (n.k)^2 with E = f k^t fixed at the start (f = 1 - r_s/r, h = r_s / (r - r_s))
+    rng = np.random.default_rng(3)
+    x0 = rng.normal(size=3); x0 *= 7.0 / np.linalg.norm(x0)
+    k0 = rng.normal(size=(30, 3)) * 0.25
+    def E2(x, k):
+        r = np.linalg.norm(x, axis=-1); f = 1 - 1 / r; h = 1 / (r - 1)
+        nk = (x * k).sum(-1) / r
+        return f * ((k * k).sum(-1) + h * nk * nk + 1.0)          # = (f k^t)^2 from g(k, k) = -1
+    o = oracle.trace(k0, x0, lambda_end=60.0, **kw)
+    esc = o["flags"] == 4
+    assert esc.sum() > 5
+    assert np.abs(E2(o["end"][esc, 0:3], o["end"][esc, 3:6]) - E2(x0[None], k0[esc])).max() < 1e-8   # E conserved <=> norm kept
+    Lv0, Lv1 = np.cross(x0[None], k0[esc]), np.cross(o["end"][esc, 0:3], o["end"][esc, 3:6])
+    assert np.abs(Lv1 - Lv0).max() < 1e-8
+    # and a null ray is NOT a time-like one: the flag changes the answer
+    n = oracle.trace(k0, x0, r_s=1.0, lambda_end=60.0, rtol=1e-11, atol=1e-13)
+    assert np.abs(n["end"] - o["end"])[esc & (n["flags"] == 4)].max() > 1e-2
