@@ -456,7 +456,6 @@ int validate_spheres(const bhg_params *p, const double *spheres, int32_t n_spher
     if (n_spheres < 0 || n_spheres > BHG_MAX_SPHERES) return fail(BHG_E_INVALID, "n_spheres must be in [0, BHG_MAX_SPHERES]");
     if (n_spheres == 0) return BHG_OK;
     if (!spheres) return fail(BHG_E_INVALID, "spheres is NULL");
-    if (p->rhs_form == BHG_RHS_KERR_BL) return fail(BHG_E_INVALID, "object spheres are not available with BHG_RHS_KERR_BL");
     for (int j = 0; j < n_spheres; j++) {
         const double *sp = spheres + 4 * j;
         if (!std::isfinite(sp[0]) || !std::isfinite(sp[1]) || !std::isfinite(sp[2]) || !std::isfinite(sp[3]) || !(sp[3] > 0.0))

@@ -651,6 +651,19 @@ __device__ __forceinline__ void entry_put(QEntry<RHS> &e, const double x[3], con
 constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 
+// Boyer-Lindquist position (r, theta, phi) -> Cartesian: x = sqrt(r^2 + a^2) sin th cos ph, y = ... sin ph, z = r cos th.
+// Object spheres live in the Cartesian frame the boundary speaks; a Kerr ray meets them through this (the RHS's own sincos).
+__device__ __forceinline__ void bl_position_to_cart(double a, const double q[3], double out[3])
+{
+    double st, ct, sp, cp;
+    sincos_pi4(q[1], st, ct);
+    sincos_pi4(q[2], sp, cp);
+    const double Rs = sqrt_nr(__builtin_fma(q[0], q[0], a * a)) * st;
+    out[0] = Rs * cp;
+    out[1] = Rs * sp;
+    out[2] = q[0] * ct;
+}
+
 // Does the accepted step x0 -> x1 possibly enter one of the object spheres?  A ray outside sphere j at the
 // step's start enters it if the step ends inside, or if the chord between the step ends passes through
 // (closest point of the chord at s* = b / cc in (0, 1) with squared distance d0 - b^2 / cc < rho^2, written
@@ -908,6 +921,18 @@ __device__ __forceinline__ bool any_sphere_candidate(const TraceArgs &A, const d
     bool any = false;
     for (int j = 0; j < A.n_spheres; j++) any |= sphere_maybe(A.spheres[j], x0, x1);
     return any;
+}
+
+// ... for a step in Boyer-Lindquist coordinates: the same test on the Cartesian images of the step's ends
+template <int RHS>
+__device__ __forceinline__ bool any_sphere_candidate_of(const TraceArgs &A, const double x0[3], const double x1[3])
+{
+    if (RHS != BHG_RHS_KERR_BL_) return any_sphere_candidate(A, x0, x1);
+    if (A.n_spheres == 0) return false;
+    double c0[3], c1[3];
+    bl_position_to_cart(A.spin, x0, c0);
+    bl_position_to_cart(A.spin, x1, c1);
+    return any_sphere_candidate(A, c0, c1);
 }
 // ray records in A.ws are A.ws_stride doubles apart: {a(3), w3, w4, w5} (+ {E, L} for Kerr, stride 8)  // template bitmask: which optional events are compiled in
 
@@ -1426,14 +1451,25 @@ __device__ __forceinline__ uint32_t settle_events(const TraceArgs &A, uint32_t k
         }
     }
     if ((EVT & EVT_OBJ) && (kind & EV_OBJ)) {
+        // (Boyer-Lindquist steps: the spheres are met in the Cartesian frame -- chord rule on the images of the step's
+        // ends, distance function on the image of the interpolated position)
+        double c0[3] = {x0[0], x0[1], x0[2]}, c1[3] = {x1[0], x1[1], x1[2]};
+        if (bl) {
+            bl_position_to_cart(A.spin, x0, c0);
+            bl_position_to_cart(A.spin, x1, c1);
+        }
         for (int j = 0; j < A.n_spheres; j++) {
             const double *sp = A.spheres[j];
             double bb, cc;
             bool inside;
-            if (!sphere_candidate(sp, x0, x1, bb, cc, inside)) continue;
+            if (!sphere_candidate(sp, c0, c1, bb, cc, inside)) continue;
             auto g_s = [&](double tt) {
                 double xe[3];
                 pos(tt, xe);
+                if (bl) {
+                    const double q[3] = {xe[0], xe[1], xe[2]};
+                    bl_position_to_cart(A.spin, q, xe);
+                }
                 const double dx = xe[0] - sp[0], dy = xe[1] - sp[1], dz = xe[2] - sp[2];
                 return sqrt_nr(dx * dx + dy * dy + dz * dz) - sp[3];
             };
@@ -2390,7 +2426,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
                     bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                 crossed_disk_plane<RHS>(L.x, xn);
-                    const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+                    const bool ev_o = (EVT & EVT_OBJ) && any_sphere_candidate_of<RHS>(A, L.x, xn);
                     // (whatever else the step holds: a plane crossing that cannot lie in the annulus is no event -- and
                     // a parked step with ONE candidate event takes the drain's short path)
                     if ((EVT & EVT_DISK) && ev_d &&
@@ -2514,7 +2550,7 @@ __global__ void __launch_bounds__(64) trace_rk4_kernel(const TraceArgs A)
             const bool ev_h = r_new <= r_s;     // (outside at every step's start, see the adaptive kernel; NaN: `bad` below)
             const bool ev_e = (EVT & EVT_EXIT) && (L.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
             bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(L.x, xn);
-            const bool ev_o = (EVT & EVT_OBJ) && RHS != BHG_RHS_KERR_BL_ && any_sphere_candidate(A, L.x, xn);
+            const bool ev_o = (EVT & EVT_OBJ) && any_sphere_candidate_of<RHS>(A, L.x, xn);
             // (the fixed-step kernels locate events on the step's cubic Hermite interpolant: no quartic term, and the
             // stage arguments are not read)
             if ((EVT & EVT_DISK) && ev_d &&
@@ -2987,9 +3023,10 @@ static hipError_t occupancy_variant(int method, int *blocks_per_cu)
 }
 
 #ifdef BHG_TU_KERR
-// Kerr: horizon, optional exit sphere, optional disk (no object spheres)
+// Kerr: horizon, optional exit sphere, optional disk; object spheres in the all-events variant
 hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev)
 {
+    if (evt & 4) return launch_variant<BHG_RHS_KERR_BL_, 7>(a, method, grid, s, ev);   // object spheres: the all-events variant
     switch (evt & 3) {
     case 0: return launch_variant<BHG_RHS_KERR_BL_, 0>(a, method, grid, s, ev);
     case 1: return launch_variant<BHG_RHS_KERR_BL_, 1>(a, method, grid, s, ev);
@@ -2999,6 +3036,7 @@ hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, 
 
 hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu)
 {
+    if (evt & 4) return occupancy_variant<BHG_RHS_KERR_BL_, 7>(method, blocks_per_cu);
     switch (evt & 3) {
     case 0: return occupancy_variant<BHG_RHS_KERR_BL_, 0>(method, blocks_per_cu);
     case 1: return occupancy_variant<BHG_RHS_KERR_BL_, 1>(method, blocks_per_cu);

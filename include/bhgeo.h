@@ -185,7 +185,8 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * exit sphere) yields n_valid[i] < n_points samples, the rest of its row is NaN.  traj [n][6][n_points]
  * (rows x, y, z, k_x, k_y, k_z).  end [n][6] / flags [n] (may be NULL): the same end state and flags
  * bhg_trace gives.  BHG_METHOD_DP54 only; the disk event is not available here.  Small-n path: one
- * lane per ray. */
+ * WAVE per ray up to 2048 rays (a step's samples are shared out over the 64 lanes: the engine's literal call, one ray
+ * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way. */
 int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
                    size_t n, uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags);
 
@@ -219,8 +220,9 @@ int bhg_trace_dir_device(bhg_context *ctx, const bhg_params *p, const double *x0
  * at the chord's closest point lies inside, enters the sphere in that step; the entry point is the root
  * of |x(lambda) - c_j| - radius_j on the dense output (Brent, like every other event).  Of all terminal
  * events of a step the earliest wins.  Such rays end with BHG_FLAG_HIT_OBJECT, end = entry point and
- * direction there, object_id = j; all other rays get object_id -1.  object_id may be NULL.  Not
- * available with BHG_RHS_KERR_BL.  The device-buffer form only enqueues (one launch), like bhg_trace_device.
+ * direction there, object_id = j; all other rays get object_id -1.  object_id may be NULL.  With
+ * BHG_RHS_KERR_BL the spheres are met in this same Cartesian frame (x = sqrt(r^2 + a^2) sin th cos ph, ...): chord rule on
+ * the images of the step's ends, root on the image of the dense output.  The device-buffer form only enqueues (one launch), like bhg_trace_device.
  * With n_spheres = 0 they are bhg_trace / bhg_trace_device. */
 int bhg_trace_objects(bhg_context *ctx, const bhg_params *p, const double *spheres, int32_t n_spheres,
                       const double *x0, int x0_is_shared, const double *k0, size_t n, double *end,

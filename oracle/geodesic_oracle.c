@@ -359,6 +359,22 @@ typedef struct {
     double c[3];
 } evfun_t;
 
+/* position of a state in the Cartesian frame the object spheres live in: the state's own x, y, z, or -- Boyer-Lindquist
+   states (r, theta, phi) -- x = sqrt(r^2 + a^2) sin th cos ph, y = ... sin ph, z = r cos th */
+static void cart_position(const rayctx *rc, const double y[6], double out[3])
+{
+    if (!rc->kerr) {
+        out[0] = y[1];
+        out[1] = y[3];
+        out[2] = y[5];
+        return;
+    }
+    const double R = sqrt(y[1] * y[1] + rc->a * rc->a), st = sin(y[3]);
+    out[0] = R * st * cos(y[5]);
+    out[1] = R * st * sin(y[5]);
+    out[2] = y[1] * cos(y[3]);
+}
+
 static double ev_eval(const evfun_t *e, double t)
 {
     double y[6];
@@ -368,7 +384,9 @@ static double ev_eval(const evfun_t *e, double t)
         hermite_eval(e->hm, t, y);
     if (e->zmode == 1) return e->rc->kerr ? cos(y[3]) : y[5]; /* z = r cos(theta), r > 0 */
     if (e->zmode == 2) {
-        double dx = y[1] - e->c[0], dy = y[3] - e->c[1], dz = y[5] - e->c[2];
+        double xc[3];
+        cart_position(e->rc, y, xc);
+        double dx = xc[0] - e->c[0], dy = xc[1] - e->c[1], dz = xc[2] - e->c[2];
         return sqrt(dx * dx + dy * dy + dz * dz) - e->R;
     }
     return radius(e->rc, y) - e->R;
@@ -487,11 +505,16 @@ static uint32_t check_events(const bhgo_params *p, double g_h, double g_h_new, d
         double R = e.rc->kerr ? sqrt(y[1] * y[1] + e.rc->a * e.rc->a) * fabs(sin(y[3])) : sqrt(y[1] * y[1] + y[3] * y[3]);
         if (R >= p->disk_r_in && R <= p->disk_r_out && r < best) { best = r; best_flag = BHGO_FLAG_HIT_DISK; }
     }
-    for (int j = 0; j < p->n_spheres && !e.rc->kerr; j++) {
+    double c_old[3], c_new[3]; /* the step's ends in the spheres' (Cartesian) frame */
+    if (p->n_spheres > 0) {
+        cart_position(e.rc, y_old, c_old);
+        cart_position(e.rc, y_new, c_new);
+    }
+    for (int j = 0; j < p->n_spheres; j++) {
         const double *sp = p->spheres[j];
         const double rho2 = sp[3] * sp[3];
-        double a0[3] = {y_old[1] - sp[0], y_old[3] - sp[1], y_old[5] - sp[2]};
-        double a1[3] = {y_new[1] - sp[0], y_new[3] - sp[1], y_new[5] - sp[2]};
+        double a0[3] = {c_old[0] - sp[0], c_old[1] - sp[1], c_old[2] - sp[2]};
+        double a1[3] = {c_new[0] - sp[0], c_new[1] - sp[1], c_new[2] - sp[2]};
         double d0 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2]; /* squared distances: no root needed to decide */
         double d1 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
         if (!(d0 > rho2)) continue; /* started inside (or on) this sphere: not an entry */
@@ -654,7 +677,7 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
         int any = (((g_h <= 0) && (g_h_new >= 0)) || ((g_h >= 0) && (g_h_new <= 0))) ||
                   ((p->r_exit > 0.0) && (g_e <= 0) && (g_e_new >= 0)) ||
                   ((p->disk_r_out > 0.0) && (((z_old <= 0) && (z_new >= 0)) || ((z_old >= 0) && (z_new <= 0)))) ||
-                  (p->n_spheres > 0 && !rc->kerr);
+                  (p->n_spheres > 0);
         if (any || sm) dense_build(&dn, t_old, t, y_old, K);
         if (any) {
             double t_root, y_root[6];

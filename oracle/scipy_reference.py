@@ -370,7 +370,7 @@ KERR_HORIZON_MARGIN = 1e-3  # terminal event at r = r_plus (1 + margin): BL coor
 
 
 def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6, method="RK45",
-                   disk=None, time_like=False):
+                   disk=None, time_like=False, spheres=None):
     """One null geodesic in Kerr; state y = [ur, r, uth, th, uph, ph]; Cartesian in, Cartesian out.
     disk=(R_in, R_out): thin disk in the equatorial plane z = r cos(th) = 0, annulus in the cylindrical
     radius sqrt(x^2 + y^2) = sqrt(r^2 + a^2) |sin th|; a NON-terminal event g = cos(th), the first crossing
@@ -394,6 +394,20 @@ def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol
 
     ev.terminal = True
     events = [ev]
+    n_obj = 0
+    if spheres is not None:
+        # object spheres (trace_ray's rule) met in the Cartesian frame: g_j = |x(r, th, ph) - c_j| - rho_j, entering only
+        def make_ev(c, rho):
+            def evs(_t, y):
+                R = np.sqrt(y[1] * y[1] + a * a)
+                x = np.array([R * np.sin(y[3]) * np.cos(y[5]), R * np.sin(y[3]) * np.sin(y[5]), y[1] * np.cos(y[3])])
+                return np.sqrt(((x - c) ** 2).sum()) - rho
+            evs.terminal = True
+            evs.direction = -1.0
+            return evs
+
+        events += [make_ev(np.asarray(sp[:3], float), float(sp[3])) for sp in spheres]
+        n_obj = len(spheres)
     if disk is not None:
         def ev_disk(_t, y):
             return np.cos(y[3])
@@ -403,13 +417,18 @@ def trace_ray_kerr(k0, x0, M=0.5, a=0.45, lambda_end=50.0, max_step=np.inf, rtol
     sol = solve_ivp(rhs, (0.0, lambda_end), y0, method=method, events=events, max_step=max_step, rtol=rtol, atol=atol)
     n_acc_disk = None
     if sol.status == 1:
-        flags, te, ye = FLAG_HIT_HORIZON, sol.t_events[0][-1], sol.y_events[0][-1]
+        cands = [(sol.t_events[i][-1], i) for i in range(1 + n_obj) if len(sol.t_events[i]) > 0]
+        te, i_ev = min(cands)
+        ye = sol.y_events[i_ev][-1]
+        flags = FLAG_HIT_HORIZON if i_ev == 0 else FLAG_HIT_OBJECT
+        if i_ev > 0:
+            out["object_id"] = i_ev - 1
     elif sol.status == 0:
         flags, te, ye = FLAG_REACHED_END, sol.t[-1], sol.y[:, -1]
     else:
         flags, te, ye = FLAG_STEP_TOO_SMALL, sol.t[-1], sol.y[:, -1]
     if disk is not None:
-        for td, yd in zip(sol.t_events[1], sol.y_events[1]):
+        for td, yd in zip(sol.t_events[-1], sol.y_events[-1]):
             R = np.sqrt(yd[1] * yd[1] + a * a) * abs(np.sin(yd[3]))
             if disk[0] <= R <= disk[1] and td <= te:
                 flags, te, ye = FLAG_HIT_DISK, td, yd

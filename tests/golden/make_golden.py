@@ -242,6 +242,25 @@ def main_kerr_disk():
          n_accepted=np.array([r["n_accepted"] for r in res], np.uint32), t_end=np.array([r["t_end"] for r in res]))
 
 
+def main_kerr_objects():
+    # ---- 14. object spheres in Kerr (a/M = 0.9): met in the Cartesian frame by the Boyer-Lindquist solve; max_step 0.5 as for
+    # the Schwarzschild object set (scipy only sees sign changes between step ends) ----
+    M, a = 0.5, 0.45
+    spheres = np.array([[6.0, 0.0, 0.0, 1.5], [0.0, -5.0, 1.0, 1.0], [-3.0, 4.0, -2.0, 1.2]])
+    cam = np.array([2.0, -24.0, 14.0])
+    rng = np.random.default_rng(14)
+    aim = rng.normal(size=(60, 3)) * np.array([5.0, 5.0, 3.0])
+    aim[:30] = spheres[rng.integers(0, 3, 30), :3] + rng.normal(size=(30, 3)) * 1.0     # half of them at the spheres
+    k0 = aim - cam
+    k0 /= np.linalg.norm(k0, axis=1)[:, None]
+    res = [sr.trace_ray_kerr(k0[i], cam, M, a, lambda_end=60.0, max_step=0.5, spheres=spheres) for i in range(len(k0))]
+    save("kerr_objects", k0=k0, x0=np.tile(cam, (len(k0), 1)), r_s=1.0, spin=a, lambda_end=60.0, max_step=0.5, rtol=1e-3, atol=1e-6,
+         spheres=spheres, end=np.array([r["end"] for r in res]), flags=np.array([r["flags"] for r in res], np.uint8),
+         object_id=np.array([r.get("object_id", -1) for r in res], np.int8),
+         n_attempted=np.array([r["n_attempted"] for r in res], np.uint32),
+         n_accepted=np.array([r["n_accepted"] for r in res], np.uint32), t_end=np.array([r["t_end"] for r in res]))
+
+
 def main_timelike():
     # ---- 13. time_like=True (the solver object's other constructor value, RelativisticRenderEngine.py:134): massive
     # particles, g(k, k) = -1, parameter = proper time.  Orbits from four radii with a circular-orbit speed scaled by
@@ -278,6 +297,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "timelike"):
         main_timelike()
+    if which in ("all", "kerr_objects"):
+        main_kerr_objects()
     if which in ("all",):
         main()
     if which in ("all", "disk"):

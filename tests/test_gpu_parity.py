@@ -500,8 +500,6 @@ def test_kerr_seeded_rays_and_rk4(ctx, oracle):
     from blackhole_geodesic_calculator_amd import _ffi
     with pytest.raises(_ffi.BhgError):
         ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, spin=0.5))          # |a| must stay below M
-    with pytest.raises(_ffi.BhgError):
-        ctx.trace(k[:4], cam, _params(r_s=1.0, rhs_form=2, spin=0.45), spheres=[[0, 0, 5, 1.0]])   # no objects in Kerr
 
 
 def test_kerr_integrator_and_camera_adaptors(ctx, oracle):
@@ -680,8 +678,9 @@ def test_objects_host_api_and_validation(ctx):
     for bad in ([[0, 0, 5, 0.0]], [[0, 0, 5, -1.0]], [[np.nan, 0, 5, 1.0]], [[0, 0, 5, 1.0]] * 9):
         with pytest.raises(_ffi.BhgError):
             gi.trace(k, CAM, spheres=bad)
-    with pytest.raises(_ffi.BhgError):
-        GeodesicIntegratorKerr(mass=0.5, a=0.3).trace(k, CAM, spheres=[[0, 0, 5, 1.0]])
+    # (Kerr takes object spheres since round 4: test_kerr_object_spheres_golden_and_oracle)
+    kerr = GeodesicIntegratorKerr(mass=0.5, a=0.3, context=ctx).trace(k, CAM + np.array([0.0, 0.3, 0.0]), spheres=[[0.0, 0.0, 12.0, 1.0]])
+    assert (kerr["flags"] == _ffi.FLAG_HIT_OBJECT).sum() > 0
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(__import__("os").environ.get("BHG_FUZZ", "48")) // 3)))
@@ -1067,3 +1066,32 @@ def test_timelike_adaptor_orbits(ctx, oracle):
     pro = g9.trace(np.array([[0.0, 0.3, 0.0]]), xe, curve_end=80.0)["ray_end"]
     ret = g9.trace(np.array([[0.0, -0.3, 0.0]]), xe, curve_end=80.0)["ray_end"]
     assert np.abs(pro[0, 0] - ret[0, 0]) > 1e-3 or np.abs(pro[0, 1] + ret[0, 1]) > 1e-3
+
+
+def test_kerr_object_spheres_golden_and_oracle(ctx, oracle):
+    """Object spheres with the Boyer-Lindquist form (round 4): the spheres live in the Cartesian frame, the chord rule runs on
+    the images of a step's ends, the root search on the image of the dense output.  scipy golden (terminal events on the
+    Cartesian image of the Kerr solve), then seeded rays against the checker incl. exit sphere + disk, RK4 and a sphere
+    that straddles the rotation axis."""
+    g = load_golden("kerr_objects")
+    kw = dict(r_s=1.0, lambda_end=60.0, max_step=0.5, rhs_form=2, spin=float(g["spin"]))
+    end, flags, steps, acc, obj = ctx.trace(g["k0"], g["x0"], _params(**kw), spheres=g["spheres"])
+    assert np.array_equal(flags, g["flags"]) and np.array_equal(obj, g["object_id"]) and np.array_equal(acc, g["n_accepted"])
+    assert (flags == 0x88).sum() >= 15 and np.abs(end - g["end"]).max() < 1e-6
+    hit = flags == 0x88
+    c = g["spheres"][obj[hit]]
+    assert np.abs(np.linalg.norm(end[hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9     # the ray ends ON its sphere
+    cam = np.array([4.0, -24.0, 13.0])
+    rng = np.random.default_rng(43)
+    k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(6000, 3)) * 0.2
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    spheres = [[5.0, 0.0, 0.0, 1.5], [0.0, -6.0, 2.0, 1.2], [0.2, 0.1, 7.0, 1.0], [-4.0, 3.0, -3.0, 1.3]]
+    _, f1, _, _ = _compare(ctx, oracle, k, cam, r_s=1.0, lambda_end=60.0, rhs_form=2, spin=0.45, spheres=spheres, step_flips=4)
+    assert 0.02 < (f1 == 0x88).mean() < 0.6
+    _compare(ctx, oracle, k[:3000], cam, r_s=1.0, lambda_end=60.0, rhs_form=2, spin=-0.3, spheres=spheres, r_exit=30.0,
+             disk_r_in=2.0, disk_r_out=9.0, step_flips=4)
+    _compare(ctx, oracle, k[:1500], cam, r_s=1.0, lambda_end=40.0, rhs_form=2, spin=0.45, spheres=spheres, method=1, h_fixed=0.1,
+             allow_flips=0.15)
+    # time-like as well: a massive particle stopped by a sphere
+    k0, x0 = _orbits(1500, 92)
+    _compare(ctx, oracle, k0, x0, r_s=1.0, lambda_end=100.0, rhs_form=2, spin=0.45, time_like=1, spheres=spheres, step_flips=4)
