@@ -120,8 +120,6 @@ def parse(argv=None):
     a.width = a.width or dw
     a.height = a.height or a.width
     a.samples = a.samples or ds
-    if a.workload == "orbit" and a.rhs == "kerr":
-        ap.error("object spheres are Schwarzschild-only")
     return a
 
 

@@ -457,3 +457,19 @@ def test_timelike_known_answers(oracle):
     # and a null ray is NOT a time-like one: the flag changes the answer
     n = oracle.trace(k0, x0, r_s=1.0, lambda_end=60.0, rtol=1e-11, atol=1e-13)
     assert np.abs(n["end"] - o["end"])[esc & (n["flags"] == 4)].max() > 1e-2
+
+
+def test_oracle_kerr_objects_match_scipy_golden(oracle):
+    """Object spheres met by the Boyer-Lindquist solve in the Cartesian frame (round 4): the checker against scipy's terminal
+    events on the Cartesian image of the Kerr state."""
+    g = load_golden("kerr_objects")
+    o = oracle.trace(g["k0"], g["x0"], r_s=1.0, lambda_end=60.0, max_step=0.5, rhs_form=oracle.RHS_KERR_BL, spin=float(g["spin"]),
+                     spheres=g["spheres"])
+    assert np.array_equal(o["flags"], g["flags"]) and np.array_equal(o["object_id"], g["object_id"])
+    assert np.array_equal(o["n_accepted"], g["n_accepted"]) and (o["flags"] == 0x88).sum() >= 15
+    assert np.abs(o["t_end"] - g["t_end"]).max() < 1e-9
+    d = np.abs(o["end"] - g["end"]).max(1)
+    assert d[o["flags"] != 1].max() < 1e-9 and d.max() < 1e-6
+    hit = o["flags"] == 0x88
+    c = g["spheres"][o["object_id"][hit]]
+    assert np.abs(np.linalg.norm(o["end"][hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9
