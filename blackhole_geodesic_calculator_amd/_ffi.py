@@ -46,7 +46,7 @@ EXPORTS = (
     "bhg_trace_objects_device", "bhg_shade_scene_device", "bhg_shade_scene_f32_device",
     "bhg_assemble_frame_f32_device", "bhg_host_alloc", "bhg_host_free", "bhg_rays_create", "bhg_rays_count",
     "bhg_rays_destroy", "bhg_rays_trace", "bhg_trace_dir_device", "bhg_shade_dir_device",
-    "bhg_frame_create", "bhg_frame_destroy", "bhg_frame_set_scene", "bhg_frame_render", "bhg_frame_synchronize",
+    "bhg_frame_create", "bhg_frame_destroy", "bhg_frame_set_scene", "bhg_frame_set_camera", "bhg_frame_render", "bhg_frame_synchronize",
     "bhg_frame_device_image", "bhg_frame_rebalance", "bhg_frame_stats", "bhg_frame_info", "bhg_frame_set_profiling",
     "bhg_frame_last_ms", "bhg_deal_tiles",
 )
@@ -262,6 +262,8 @@ def load():
     L.bhg_frame_destroy.argtypes = [C.c_void_p]
     L.bhg_frame_set_scene.restype = C.c_int
     L.bhg_frame_set_scene.argtypes = [C.c_void_p, C.POINTER(FrameScene)]
+    L.bhg_frame_set_camera.restype = C.c_int
+    L.bhg_frame_set_camera.argtypes = [C.c_void_p, C.POINTER(Camera)]
     L.bhg_frame_render.restype = C.c_int
     L.bhg_frame_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p]
     L.bhg_frame_synchronize.restype = C.c_int
@@ -467,12 +469,7 @@ class Frame:
 
     def __init__(self, devices, width, height, samples, *, fov_x=1.0, fov_y=1.0, origin=(1e-4, 0.0, 30.0), rot=None,
                  jitter=None, tile=32, gather=GATHER_AUTO):
-        cam = Camera()
-        cam.width, cam.height, cam.samples = int(width), int(height), int(samples)
-        cam.fov_x, cam.fov_y = float(fov_x), float(fov_y)
-        r = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
-        cam.rot[:] = [float(v) for v in r.reshape(9)]
-        cam.origin[:] = [float(v) for v in np.asarray(origin, dtype=np.float64).reshape(3)]
+        cam = self._camera(width, height, samples, fov_x, fov_y, origin, rot)
         devs = [int(d) for d in (devices if hasattr(devices, "__len__") else [devices])]
         jit = None if jitter is None else np.ascontiguousarray(jitter, dtype=np.float64).reshape(-1)
         need = 2 * cam.samples * cam.width * cam.height
@@ -485,6 +482,22 @@ class Frame:
         self.devices, self.W, self.H, self.S = devs, cam.width, cam.height, cam.samples
         self._scene = FrameScene()
         self._scene.disk_mean, self._scene.disk_stddev, self._scene.disk_intensity = 0.2, 0.3, 1.0
+
+    @staticmethod
+    def _camera(width, height, samples, fov_x, fov_y, origin, rot):
+        cam = Camera()
+        cam.width, cam.height, cam.samples = int(width), int(height), int(samples)
+        cam.fov_x, cam.fov_y = float(fov_x), float(fov_y)
+        r = np.eye(3) if rot is None else np.asarray(rot, dtype=np.float64).reshape(3, 3)
+        cam.rot[:] = [float(v) for v in r.reshape(9)]
+        cam.origin[:] = [float(v) for v in np.asarray(origin, dtype=np.float64).reshape(3)]
+        return cam
+
+    def set_camera(self, *, fov_x, fov_y, origin, rot=None):
+        """Move the camera (bhg_frame_set_camera): the frame, its jitter stream and its buffers stay.  A new origin is free;
+        a new rotation / field of view regenerates the rays on the devices at the next render."""
+        cam = self._camera(self.W, self.H, self.S, fov_x, fov_y, origin, rot)
+        _check(load().bhg_frame_set_camera(self._h, C.byref(cam)))
 
     def close(self):
         if getattr(self, "_h", None):

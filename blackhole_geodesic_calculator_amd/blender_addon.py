@@ -252,10 +252,23 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
             # an explicit device list, e.g. "2,3" or -- several contexts of ONE GPU, the N > 1 code path on a one-GPU
             # machine (tests) -- "0,0"
             devices = [int(v) for v in os.environ["BHGEO_DEVICES"].split(",")]
-        jitter = python_random_stream(self.sampling_seed, 2 * samples * width * height)          # :189
-        fr = _ffi.Frame(devices, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
-                        origin=np.asarray(origin, dtype=np.float64) - self.bh_loc,               # :278
-                        rot=euler_xyz_matrix(rotation), jitter=jitter)
+        # The frame object outlives the render: Blender makes a new engine instance for every frame of an animation, and
+        # creating the frame (the MT19937 stream, the buffers, the first launch of every kernel) costs 100 ms where a render
+        # costs 2.4 -- so it is kept at module level and only its camera and scene move (bhg_frame_set_camera / _set_scene).
+        # Anything that changes the rays' layout (resolution, samples, seed, device list) makes a new one.
+        key = (tuple(devices), int(width), int(height), int(samples), float(self.sampling_seed))
+        cam_origin = np.asarray(origin, dtype=np.float64) - self.bh_loc                          # :278
+        fr = _DEVICE_FRAMES.get(key)
+        if fr is None:
+            release_device_frames()
+            jitter = python_random_stream(self.sampling_seed, 2 * samples * width * height)      # :189
+            fr = _ffi.Frame(devices, width, height, samples, fov_x=self.field_of_view_x, fov_y=self.field_of_view_y,
+                            origin=cam_origin, rot=euler_xyz_matrix(rotation), jitter=jitter)
+            _DEVICE_FRAMES[key] = fr
+            self.device_frame_reused = False
+        else:
+            fr.set_camera(fov_x=self.field_of_view_x, fov_y=self.field_of_view_y, origin=cam_origin, rot=euler_xyz_matrix(rotation))
+            self.device_frame_reused = True
         try:
             sp, lamps = None, None
             if len(spheres) > 0:
@@ -273,8 +286,9 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
             rgba = fr.render(self.GeoInt.params(self.max_integration_step, self.int_depth_curve_end))
             buf[:, :, :] = rgba.reshape(height, width, 4)
             self.last_device_frame = fr.info()
-        finally:
-            fr.close()
+        except BaseException:
+            release_device_frames()      # (a frame that failed is not kept)
+            raise
         n = samples * height
         for i in range(n):       # progress: the frame is one launch per device, reported after the fact at ray_trace's cadence
             yield (i + 1) / n
@@ -336,6 +350,20 @@ EXTRA_PROPS = [
     ("render_devices", bpy.props.FloatProperty(name="render_devices", default=1)),
 ]
 
+# the library-owned frame of the device path, kept across renders (see ray_trace_device): at most one
+_DEVICE_FRAMES = {}
+
+
+def release_device_frames():
+    """Free the GPU buffers the device path keeps between renders (called by unregister(), and when the frame's shape changes)."""
+    for fr in list(_DEVICE_FRAMES.values()):
+        try:
+            fr.close()
+        except Exception:
+            pass
+    _DEVICE_FRAMES.clear()
+
+
 _EXCLUDED_PANELS = {"VIEWLAYER_PT_filter", "VIEWLAYER_PT_layer_passes"}
 
 
@@ -366,6 +394,7 @@ def register():
 
 
 def unregister():
+    release_device_frames()
     bpy.utils.unregister_class(RelativisticRenderEngine)
     bpy.utils.unregister_class(CUSTOM_RENDER_PT_blackhole)
     for name, _ in PROPS + EXTRA_PROPS:

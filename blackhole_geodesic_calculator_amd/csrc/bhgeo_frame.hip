@@ -517,6 +517,19 @@ void bhg_frame_destroy(bhg_frame *f)
     destroy_frame(f);
 }
 
+int bhg_frame_set_camera(bhg_frame *f, const bhg_camera *cam)
+{
+    if (!f || !cam) return fail(BHG_E_INVALID, "frame / camera is NULL");
+    if (cam->width != f->cam.width || cam->height != f->cam.height || cam->samples != f->cam.samples)
+        return fail(BHG_E_INVALID, "width, height and samples are fixed at bhg_frame_create (the jitter stream and the tile dealing belong to them)");
+    // the rays are directions only (the origin is handed to every trace call): they are regenerated when what shapes them changes
+    const bool dirs_change = cam->fov_x != f->cam.fov_x || cam->fov_y != f->cam.fov_y || std::memcmp(cam->rot, f->cam.rot, sizeof(cam->rot)) != 0;
+    f->cam = *cam;
+    if (dirs_change)
+        for (auto &s : f->sh) s.rays_ready = false;
+    return BHG_OK;
+}
+
 int bhg_frame_set_scene(bhg_frame *f, const bhg_frame_scene *sc)
 {
     if (!f || !sc) return fail(BHG_E_INVALID, "frame / scene is NULL");

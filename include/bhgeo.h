@@ -347,6 +347,11 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
                      int32_t gather, bhg_frame **out);
 void bhg_frame_destroy(bhg_frame *frame);
 int bhg_frame_set_scene(bhg_frame *frame, const bhg_frame_scene *scene);
+/* Move the camera of an existing frame (an animation: the frame object, its jitter stream, tile dealing and device
+ * buffers stay): origin, rotation and field of view may change, width / height / samples may not.  A new origin costs
+ * nothing (rays are directions; the origin goes into every trace call); a new rotation or field of view regenerates the
+ * rays on the devices at the next render. */
+int bhg_frame_set_camera(bhg_frame *frame, const bhg_camera *cam);
 /* One frame.  rgba_host [height][width][4] float (pageable or page-locked): blocking, the image is there on return.
  * rgba_host = NULL: the render is only enqueued and the image stays on the first device (bhg_frame_device_image;
  * bhg_frame_synchronize waits) -- an animation loop that consumes frames on the GPU, and what bench.py times.

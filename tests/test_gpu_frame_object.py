@@ -127,6 +127,38 @@ def test_disk_and_object_frames_are_bit_identical_to_device_frame(ctx, devices):
     fr.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0]])
+def test_set_camera_moves_an_existing_frame(ctx, devices):
+    """bhg_frame_set_camera: an animation keeps ONE frame object and moves its camera.  After a move (origin only: the rays
+    stay; rotation + field of view: the rays are regenerated from the kept jitter stream) the frame renders bit for bit
+    what a frame created at that camera renders; the image size is fixed at creation."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    from blackhole_geodesic_calculator_amd.raygen import euler_xyz_matrix
+    W, H, S = 96, 64, 2
+    sky = synthetic_sky(128, 64)
+    p = _params(r_s=1.0, lambda_end=60.0)
+    fr = _frame(devices, W, H, S)
+    fr.set_scene(sky, spheres=[[1.0, 0.5, 9.0, 1.2]], lamps=[[5.0, 5.0, 30.0, 1.0]])
+    first = fr.render(p)
+    for cam, euler, fov in (((0.5, -1.0, 28.0), (0.0, 0.0, 0.0), 0.6),          # origin only
+                            ((3.0, -20.0, 18.0), (0.9, 0.0, 0.1), 0.6),          # origin + rotation
+                            ((3.0, -20.0, 18.0), (0.9, 0.0, 0.1), 0.45)):        # field of view
+        fr.set_camera(fov_x=fov, fov_y=fov, origin=np.array(cam), rot=euler_xyz_matrix(euler))
+        moved = fr.render(p)
+        fresh = _frame(devices, W, H, S, cam=np.array(cam), euler=euler, fov=fov)
+        fresh.set_scene(sky, spheres=[[1.0, 0.5, 9.0, 1.2]], lamps=[[5.0, 5.0, 30.0, 1.0]])
+        want = fresh.render(p)
+        fresh.close()
+        assert np.array_equal(moved, want) and not np.array_equal(moved, first)
+    # back where it started: the first image again
+    fr.set_camera(fov_x=0.6, fov_y=0.6, origin=CAM, rot=None)
+    assert np.array_equal(fr.render(p), first)
+    cam = _ffi.Frame._camera(W + 1, H, S, 0.6, 0.6, CAM, None)
+    assert _ffi.load().bhg_frame_set_camera(fr._h, __import__("ctypes").byref(cam)) != 0       # the size is fixed at creation
+    fr.close()
+
+
 def test_peer_store_frame_end_is_bit_identical(ctx):
     """BHG_FRAME_GATHER_PEER: every context's shade kernel stores its pixels straight into the first device's image (no
     slab, no gather, no assembly) -- here with three contexts of the one GPU; sky and scene frames, the same images."""
@@ -213,7 +245,7 @@ def test_rccl_gather_path_on_one_gpu():
     gather path of the N-GPU frame on the single GPU of this box.  In a child process (a hang must not take the suite
     down), without torch."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _RCCL_LOOPBACK % dict(root=ROOT)], capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([sys.executable, "-c", _RCCL_LOOPBACK % dict(root=ROOT)], capture_output=True, text=True, timeout=150, env=env)
     assert r.returncode == 0 and "RCCL loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
