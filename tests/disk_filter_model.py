@@ -166,3 +166,81 @@ def dense_plane_crossings(y_old, h, Q):
         r = r[np.abs(r.imag) < 1e-9].real
         out.append(np.sort(r[(r >= -1e-12) & (r <= 1.0 + 1e-12)]).clip(0.0, 1.0))
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The Boyer-Lindquist forms (Kerr): disk_crossing_may_hit_bl (chord bound in (r, theta)) and, for what it lets through,
+# disk_crossing_may_hit_sharp<BL> (the crossing of the cubic Hermite interpolant H + the exact D - H relation).
+# State of a step end here: q = (r, theta, phi), u = d q / d lambda; hq3 = h * (column 3 of Q) for the three positions.
+# ------------------------------------------------------------------------------------------------------------------
+HALF_PI = 1.5707963267948966
+
+
+def bl_plane_index(th):
+    return np.floor((th - HALF_PI) * 0.3183098861837907)
+
+
+def bl_chord_bound(q0, u0, q1, u1, h, hq3):
+    """(crossed_one, th_star, r_lin, eps): the chord's r where it meets the plane theta* it crosses and the bound on
+    |r_dense - r_lin| at ANY crossing of the dense output with that plane; crossed_one False = more than one plane (or
+    none) between the step's ends: the device says "may hit" without looking further."""
+    k0, k1 = bl_plane_index(q0[..., 1]), bl_plane_index(q1[..., 1])
+    one = np.abs(k1 - k0) == 1.0
+    th_star = np.pi * np.maximum(k0, k1) + HALF_PI
+    dth, dr = q1[..., 1] - q0[..., 1], q1[..., 0] - q0[..., 0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = (th_star - q0[..., 1]) / dth
+        r_lin = q0[..., 0] + s * dr
+        d = component_bound(q0, u0, q1, u1, h, hq3)
+        eps = d[..., 0] + np.abs(dr) * d[..., 1] / np.abs(dth)
+    return one, th_star, r_lin, eps
+
+
+def may_hit_bl(q0, u0, q1, u1, h, hq3, a, r_in, r_out, slack=1.0 + 1e-9, fuzz=1e-11):
+    """The device decision of disk_crossing_may_hit_bl (annulus in sqrt(r^2 + a^2), compared in squares)."""
+    one, _, r_lin, eps = bl_chord_bound(q0, u0, q1, u1, h, hq3)
+    eps = eps * slack * (1.0 + 1e-12) + fuzz
+    r_lo, r_hi = np.maximum(r_lin - eps, 0.0), r_lin + eps
+    with np.errstate(invalid="ignore"):
+        out = (r_hi * r_hi + a * a < r_in * r_in) | (r_lo * r_lo + a * a > r_out * r_out)
+    return ~one | ~out
+
+
+def sharp_bl(q0, u0, q1, u1, h, hq3):
+    """disk_crossing_may_hit_sharp in Boyer-Lindquist coordinates: (decides, r_h, er) -- where `decides`, every crossing of
+    the dense output with the plane lies at an r within er of r_h; elsewhere the device function returns "may hit"
+    (several planes, H_theta not safely monotone)."""
+    ce = 1
+    k0, k1 = bl_plane_index(q0[..., 1]), bl_plane_index(q1[..., 1])
+    one = np.abs(k1 - k0) == 1.0
+    target = np.pi * np.maximum(k0, k1) + HALF_PI
+    e4 = np.abs(hq3) * 0.0625
+    d = q1 - q0
+    m0, m1 = h[..., None] * u0, h[..., None] * u1
+    b1, b2, b3 = m0, 3.0 * d - (2.0 * m0 + m1), -2.0 * d + (m0 + m1)
+    z0, dz = q0[..., ce] - target, q1[..., ce] - q0[..., ce]
+    g0, g1 = b1[..., ce], 3.0 * b3[..., ce] + (2.0 * b2[..., ce] + b1[..., ce])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        the = -b2[..., ce] / (3.0 * b3[..., ce])
+        ge = np.where((the > 0.0) & (the < 1.0), b2[..., ce] * the + b1[..., ce], g0)
+        sgn = np.where(dz < 0.0, -1.0, 1.0)
+        gmin = np.minimum(np.minimum(g0 * sgn, g1 * sgn), ge * sgn)
+        decides = one & (gmin > 0.125 * np.abs(dz))
+        th = np.clip(-z0 / dz, 0.0, 1.0)
+        for _ in range(2):
+            f = ((b3[..., ce] * th + b2[..., ce]) * th + b1[..., ce]) * th + z0
+            df = (3.0 * b3[..., ce] * th + 2.0 * b2[..., ce]) * th + b1[..., ce]
+            th = np.clip(th - f / df, 0.0, 1.0)
+        f = ((b3[..., ce] * th + b2[..., ce]) * th + b1[..., ce]) * th + z0
+        dth = (1.5 * e4[..., ce] + np.abs(f)) / gmin
+        r_h = ((b3[..., 0] * th + b2[..., 0]) * th + b1[..., 0]) * th + q0[..., 0]
+        er = ((np.abs(b1[..., 0]) + (2.0 * np.abs(b2[..., 0]) + 3.0 * np.abs(b3[..., 0]))) * dth + e4[..., 0]) * (1.0 + 1e-6)
+    return decides, r_h, er
+
+
+def may_hit_sharp_bl(q0, u0, q1, u1, h, hq3, a, r_in, r_out):
+    decides, r_h, er = sharp_bl(q0, u0, q1, u1, h, hq3)
+    r_lo, r_hi = np.maximum(r_h - er, 0.0), r_h + er
+    with np.errstate(invalid="ignore"):
+        out = (r_hi * r_hi + a * a < r_in * r_in) | (r_lo * r_lo + a * a > r_out * r_out)
+    return ~decides | ~out

@@ -102,3 +102,81 @@ def test_round3_delta_was_not_a_bound():
     Rd, Rc, eps, old = (np.array([r[j] for r in rows]) for j in range(4))
     assert (np.abs(Rd - Rc) / old).max() > 1.0
     assert (np.abs(Rd - Rc) / eps).max() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The Boyer-Lindquist forms of the filter (Kerr + thin disk): the chord bound in (r, theta) and the sharp test that follows it
+# ------------------------------------------------------------------------------------------------------------------------
+def _kerr_crossings(n, seed, rtol, M=0.5, a=0.45):
+    """Every crossing of the equatorial plane by the dense output of scipy-RK45 steps on the Boyer-Lindquist Kerr system
+    (the lambdified right-hand side the goldens were made with), from near-equatorial cameras: one row per crossing."""
+    from oracle import scipy_reference as sr
+    fn = sr.kerr_rhs_lambdified()
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        inc = np.deg2rad(rng.uniform(89.0, 89.99) if rng.random() < 0.5 else rng.uniform(70.0, 89.99))
+        cam = CAM_R * np.array([np.sin(inc), 0.0, np.cos(inc)]) + np.array([0.0, 3.0, 0.0])
+        aim = rng.normal(0.0, 1.0, 3) * np.array([9.0, 9.0, 0.1])
+        k = (aim - cam) / np.linalg.norm(aim - cam)
+        q0, u0 = sr.cart_to_bl(cam, k, a)
+        E, L, _ = sr.kerr_constants(q0, u0, M, a)
+
+        def rhs(_t, y):
+            ar, ath, aph, _kt = fn(y[1], y[3], y[0], y[2], y[4], E, L, M, a)
+            return np.array([ar, y[0], ath, y[2], aph, y[4]])
+
+        sol = RK45(rhs, 0.0, np.array([u0[0], q0[0], u0[1], q0[1], u0[2], q0[2]]), 90.0, rtol=rtol, atol=rtol * 1e-3)
+        r_h = (M + np.sqrt(M * M - a * a)) * 1.02
+        while sol.status == "running":
+            y_old = sol.y.copy()
+            sol.step()
+            if sol.status == "failed" or sol.y[1] <= r_h:
+                break
+            if dfm.bl_plane_index(np.array(y_old[3])) == dfm.bl_plane_index(np.array(sol.y[3])):
+                continue
+            dn = sol.dense_output()
+            h, Q = dn.h, dn.Q
+            qa, ua = y_old[[1, 3, 5]], y_old[[0, 2, 4]]
+            qb, ub = sol.y[[1, 3, 5]], sol.y[[0, 2, 4]]
+            hq3 = h * Q[[1, 3, 5], 3]
+            for kk in range(int(min(dfm.bl_plane_index(qa[1]), dfm.bl_plane_index(qb[1]))) + 1,
+                            int(max(dfm.bl_plane_index(qa[1]), dfm.bl_plane_index(qb[1]))) + 1):
+                th_star = np.pi * kk + dfm.HALF_PI
+                c = np.array([h * Q[3, 3], h * Q[3, 2], h * Q[3, 1], h * Q[3, 0], y_old[3] - th_star])
+                roots = np.roots(c)
+                roots = roots[np.abs(roots.imag) < 1e-9].real
+                for th in roots[(roots >= -1e-12) & (roots <= 1.0 + 1e-12)].clip(0.0, 1.0):
+                    p = th ** np.arange(1, 5)
+                    r_d = y_old[1] + h * (Q[1] @ p)
+                    rows.append((r_d, qa, ua, qb, ub, h, hq3))
+    return rows
+
+
+@pytest.mark.parametrize("rtol", [1e-3, 1e-2])
+def test_boyer_lindquist_filters_are_bounds(rtol):
+    a = 0.45
+    rows = _kerr_crossings(1500, 40 + int(rtol * 1e4), rtol, a=a)
+    assert len(rows) >= 1300, len(rows)
+    r_d = np.array([r[0] for r in rows])
+    q0, u0, q1, u1 = (np.array([r[j] for r in rows]) for j in (1, 2, 3, 4))
+    h, hq3 = np.array([r[5] for r in rows]), np.array([r[6] for r in rows])
+    one, _, r_lin, eps = dfm.bl_chord_bound(q0, u0, q1, u1, h, hq3)
+    ratio = np.abs(r_d - r_lin)[one] / eps[one]
+    assert one.mean() > 0.9 and ratio.max() <= 1.0, (rtol, ratio.max())
+    decides, r_h, er = dfm.sharp_bl(q0, u0, q1, u1, h, hq3)
+    sratio = np.abs(r_d - r_h)[decides] / er[decides]
+    assert decides.mean() > 0.5 and sratio.max() <= 1.0, (rtol, sratio.max())
+    print(f"rtol {rtol:g}: {len(rows)} Kerr crossings; chord bound: worst uses {ratio.max():.3f} of eps (median {np.median(ratio):.3f}); "
+          f"sharp test decides {decides.mean():.2f} of them, worst uses {sratio.max():.3f} of its margin (median {np.median(sratio):.4f})")
+    # the device decisions: a crossing inside the annulus (in sqrt(r^2 + a^2)) is never filtered out, by either test
+    R_d = np.sqrt(r_d * r_d + a * a)
+    rng = np.random.default_rng(6)
+    for _ in range(8):
+        edge = R_d + rng.normal(0.0, 1.0, len(R_d)) * np.maximum(np.where(decides, er, eps), 1e-9)
+        inner = rng.random(len(R_d)) < 0.5
+        r_in = np.where(inner, np.maximum(edge, 0.0), np.maximum(R_d - rng.uniform(0.5, 5.0, len(R_d)), 0.0))
+        r_out = np.where(inner, R_d + rng.uniform(0.5, 5.0, len(R_d)), edge)
+        inside = (R_d >= r_in) & (R_d <= r_out)
+        assert not (inside & ~dfm.may_hit_bl(q0, u0, q1, u1, h, hq3, a, r_in, r_out)).any()
+        assert not (inside & ~dfm.may_hit_sharp_bl(q0, u0, q1, u1, h, hq3, a, r_in, r_out)).any()
