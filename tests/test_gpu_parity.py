@@ -559,6 +559,10 @@ def test_randomised_configurations(ctx, oracle, seed, record_property):
         kw.update(rtol=rtol, atol=rtol * 1e-3, disk_r_in=a, disk_r_out=a * float(rng.uniform(2.0, 10.0)),
                   lambda_end=3.0 * dist_cam)
         kw.pop("max_step", None)
+    if seed % 5 == 4 and kw["rhs_form"] == 0:
+        # massive particles (time_like=True): the same draw with g(k, k) = -1 and speeds 0.05 ... 1.5 (drawn last again)
+        kw["time_like"] = 1
+        k = k * rng.uniform(0.05, 1.5, (n, 1))
     tight = kw.get("rtol", 1e-3) <= 1e-6 and kw["rhs_form"] == 0
     _compare(ctx, oracle, k, x0, allow_flips=(0.02 if tight else False), outliers=2e-3, **kw)
     # on record per draw (junit property / -rA): how many rays needed the sensitivity-scaled term at all, how many it let through
@@ -746,6 +750,9 @@ def test_randomised_kerr(ctx, oracle, seed):
     if rng.random() < 0.35:
         rin = float(rng.uniform(1.5, 5.0)) * r_s
         kw.update(disk_r_in=rin, disk_r_out=rin * float(rng.uniform(1.2, 3.0)))
+    if seed % 5 == 4:
+        kw["time_like"] = 1       # massive particles, speeds 0.05 ... 1.5
+        k = k * rng.uniform(0.05, 1.5, (len(k), 1))
     # Boyer-Lindquist coordinates are singular on the horizon (1/Delta) and on the polar axis (cot theta):
     # rays that end on the horizon or pass close to the axis (small L_z) have rounding-sensitive step
     # sequences in the oracle and on the GPU alike.  Everything else must agree step for step.
@@ -754,7 +761,7 @@ def test_randomised_kerr(ctx, oracle, seed):
     assert (flags != o["flags"]).mean() <= 0.002
     same = (steps == o["n_attempted"]) & (acc == o["n_accepted"]) & (flags == o["flags"])
     from oracle import scipy_reference as sr
-    Lz = np.array([sr.kerr_constants(*sr.cart_to_bl(cam, kk, spin), 0.5 * r_s, spin)[1] for kk in k[~same]])
+    Lz = np.array([sr.kerr_constants(*sr.cart_to_bl(cam, kk, spin), 0.5 * r_s, spin, float(kw.get("time_like", 0)))[1] for kk in k[~same]])
     touchy = ((flags[~same] & (1 | 64)) != 0) | (np.abs(Lz) < 0.3 * r_s)
     assert (~same).mean() <= 0.08 and touchy.mean() >= 0.9 if len(Lz) else True
     d = np.abs(end - o["end"]).max(1)
