@@ -133,8 +133,10 @@ class GeodesicIntegratorSchwarzschild:
         traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end), n_pts)
         m = int(nv[0])
         fl = int(flags[0])
-        x_xyz = traj[0, 0:3, :m].copy()
-        k_xyz = traj[0, 3:6, :m].copy()
+        # (views of this call's own result block -- nothing else refers to it: two 240-kB copies less per call at the
+        # engine's nr_points_curve = 10000)
+        x_xyz = traj[0, 0:3, :m]
+        k_xyz = traj[0, 3:6, :m]
         result = {
             "start_inside_hole": bool(fl & _ffi.FLAG_START_INSIDE),
             "hit_blackhole": bool(fl & _ffi.FLAG_HIT_HORIZON),

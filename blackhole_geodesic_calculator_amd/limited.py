@@ -116,7 +116,7 @@ class SchwarzschildGeodesic:
         mes = {"hit_blackhole": bool(fl & _ffi.FLAG_HIT_HORIZON), "start_inside_hole": bool(fl & _ffi.FLAG_START_INSIDE), "flags": fl}
         if verbose:
             print("ray_trace:", mes)
-        return traj[0, 0, :m].copy(), traj[0, 1, :m].copy(), traj[0, 2, :m].copy(), end[0, 0:3].copy(), end[0, 3:6].copy(), mes
+        return traj[0, 0, :m], traj[0, 1, :m], traj[0, 2, :m], end[0, 0:3].copy(), end[0, 3:6].copy(), mes   # (views of this call's own block)
 
 
 class ApproxSchwarzschildGeodesic:
