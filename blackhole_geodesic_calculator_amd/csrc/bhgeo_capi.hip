@@ -1233,21 +1233,32 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     if (rc != BHG_OK) return rc;
     rc = ensure(&c->d_out, &c->d_out_bytes, off_flags + n + 64);
     if (rc != BHG_OK) return rc;
-    rc = ensure(&c->d_ws, &c->d_ws_bytes, n * 8 * sizeof(double) + 64);
-    if (rc != BHG_OK) return rc;
-    double *d_k0 = (double *)c->d_in, *d_x0 = x0_is_shared ? nullptr : d_k0 + n * 3;
+    // up to 2048 rays the kernel runs one wave per ray, prepares the ray itself and fills what it never reaches with NaN:
+    // no prepare records, no memset; the direction of a ONE-ray call (the engine's literal call) rides in the kernel arguments
+    const bool wave = bhg::trajectory_wave_per_ray(n);
+    const bool one = n == 1 && x0_is_shared;
+    if (!wave) {
+        rc = ensure(&c->d_ws, &c->d_ws_bytes, n * 8 * sizeof(double) + 64);
+        if (rc != BHG_OK) return rc;
+    }
+    double *d_k0 = one ? nullptr : (double *)c->d_in, *d_x0 = x0_is_shared ? nullptr : (double *)c->d_in + n * 3;
     char *o = (char *)c->d_out;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    if (d_k0) HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(o, 0xFF, sz_traj, s));  // samples a ray never reaches read back as NaN
+    if (!wave) HIP_TRY(hipMemsetAsync(o, 0xFF, sz_traj, s));  // samples a ray never reaches read back as NaN
 
     bhg::TraceArgs a;
     std::memset(&a, 0, sizeof(a));
     a.k0 = d_k0;
     a.x0 = d_x0;
     a.end = (double *)(o + off_end);
-    a.ws = (double *)c->d_ws;
+    a.ws = wave ? nullptr : (double *)c->d_ws;
+    if (one) {
+        a.k0s[0] = k0[0];
+        a.k0s[1] = k0[1];
+        a.k0s[2] = k0[2];
+    }
     a.flags = (uint8_t *)(o + off_flags);
     a.n_steps = (uint32_t *)(o + off_steps);
     a.n_accepted = (uint32_t *)(o + off_acc);

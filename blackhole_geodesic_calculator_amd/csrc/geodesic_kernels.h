@@ -60,6 +60,7 @@ struct TraceArgs {
     unsigned long long *counter; // 8 slice counters (256 B apart), zero at launch
     unsigned long long *counter_next; // the set the NEXT launch of this context will use: this launch zeroes it
     uint64_t n;                  // rays in the call
+    double k0s[3];               // the direction of a ONE-ray trajectory call (k0 == nullptr)
     double x0s[3];
     int32_t inline_prepare;      // set by the launcher: no prepare launch, the trace waves work the start records out (Schwarzschild forms)
     int32_t order_blocks;        // work-order hint: n = order_blocks * order_block_len, batches are
@@ -132,6 +133,8 @@ hipError_t launch_trajectory_timelike(const TraceArgs &a, double *traj, uint32_t
 hipError_t launch_accel_timelike(const double *x, const double *k, double r_s, uint64_t n, double *acc, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
 hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+// does a trajectory call of n rays run one wave per ray (the kernel then prepares the ray itself and NaN-fills the tail)?
+bool trajectory_wave_per_ray(uint64_t n);
 // rhs = Kerr: x, k and acc are Boyer-Lindquist (r, theta, phi) triples, E and L fixed by the null condition at each point
 hipError_t launch_accel(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, int rhs,
                         hipStream_t s);

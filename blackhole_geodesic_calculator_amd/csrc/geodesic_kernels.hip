@@ -2753,31 +2753,60 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
     met.M = 0.5 * A.r_s;
     met.a = A.spin;
     met.E = met.L = 0.0;
-    const double *w = A.ws + i * (uint64_t)A.ws_stride;
-    a1[0] = w[0];
-    a1[1] = w[1];
-    a1[2] = w[2];
-    h_abs = w[3];
-    r_cur = w[4];
-    if (h_abs < 0.0) {  // start inside: the prepare pass has written the result
-        n_valid[i] = 0;
-        return;
-    }
-    if (RHS == BHG_RHS_KERR_BL_) {
-        const double *e = A.end + i * 6;
+    double *out = traj + i * 6 * (uint64_t)T;
+    if (WAVE) {
+        // one wave per ray: the wave works out the ray's start record itself -- the prepare pass's own functions, on the same
+        // bits, every lane alike -- and fills what the ray never reaches with NaN at the end: no prepare launch, no record
+        // round trip, no memset in front of a call that is one ray long (k0 of a ONE-ray call rides in the kernel arguments)
         for (int c = 0; c < 3; c++) {
-            x[c] = e[c];
-            v[c] = e[3 + c];
-        }
-        met.E = w[6];
-        met.L = w[7];
-    } else {
-        for (int c = 0; c < 3; c++) {
-            v[c] = A.k0[i * 3 + c];
+            v[c] = A.k0 ? A.k0[i * 3 + c] : A.k0s[c];
             x[c] = A.x0 ? A.x0[i * 3 + c] : A.x0s[c];
         }
+        const double cx[3] = {x[0], x[1], x[2]}, ck[3] = {v[0], v[1], v[2]};
+        double r0;
+        if (RHS == BHG_RHS_KERR_BL_) {
+            kerr_cart_to_bl(met.a, met.M, A.mu2, x, v, met.E, met.L);
+            r0 = x[0];
+        } else {
+            r0 = sqrt(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0])));
+        }
+        if (r0 <= A.r_hor) {    // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
+            for (uint32_t j = lane; j < 6 * T; j += 64) out[j] = __builtin_nan("");
+            if (lane == 0) {
+                n_valid[i] = 0;
+                store_result(A, (uint32_t)i, cx, ck, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
+            }
+            return;
+        }
+        h_abs = 0.0;
+        r_cur = 0.0;
+        initial_record<RHS, true>(A, met, x, v, a1, r_cur, h_abs);
+    } else {
+        const double *w = A.ws + i * (uint64_t)A.ws_stride;
+        a1[0] = w[0];
+        a1[1] = w[1];
+        a1[2] = w[2];
+        h_abs = w[3];
+        r_cur = w[4];
+        if (h_abs < 0.0) {  // start inside: the prepare pass has written the result
+            n_valid[i] = 0;
+            return;
+        }
+        if (RHS == BHG_RHS_KERR_BL_) {
+            const double *e = A.end + i * 6;
+            for (int c = 0; c < 3; c++) {
+                x[c] = e[c];
+                v[c] = e[3 + c];
+            }
+            met.E = w[6];
+            met.L = w[7];
+        } else {
+            for (int c = 0; c < 3; c++) {
+                v[c] = A.k0[i * 3 + c];
+                x[c] = A.x0 ? A.x0[i * 3 + c] : A.x0s[c];
+            }
+        }
     }
-    double *out = traj + i * 6 * (uint64_t)T;
     const double dt = t_bound / (double)(T - 1);
     double t = 0.0;
     uint32_t n_att = 0, n_acc = 0, next = 0, flags = 0;
@@ -2908,24 +2937,34 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             ve[c] = v[c];
         }
     }
-    if (WAVE && lane != 0) return;
+    if (WAVE) {     // samples the ray never reached read back as NaN
+        for (uint32_t j = next + lane; j < T; j += 64)
+            for (int c = 0; c < 6; c++) out[(uint64_t)c * T + j] = __builtin_nan("");
+        if (lane != 0) return;
+    }
     n_valid[i] = next;
     store_result(A, (uint32_t)i, xe, ve, flags, n_att, n_acc);  // Kerr: still Boyer-Lindquist, finalised next
 }
 
-// one wave per ray while the rays are too few to fill the chip's lanes anyway
-__host__ inline bool trajectory_wave_per_ray(uint64_t n) { return n <= 2048; }
+// one wave per ray while the rays are too few to fill the chip's lanes anyway (the C-ABI layer asks too: such a call needs
+// no memset of the sample block, no prepare records, and -- one ray -- no upload of k0)
+#ifndef BHG_TU_KERR
+#ifndef BHG_TU_TIMELIKE
+bool trajectory_wave_per_ray(uint64_t n) { return n <= 2048; }
+#endif
+#endif
 
 // prepare pass + sampled trajectories of one right-hand side
 template <int RHS>
 static void launch_trajectory_rhs(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
-    hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
-    if (trajectory_wave_per_ray(a.n))
+    if (trajectory_wave_per_ray(a.n)) {
         hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, true>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
-    else
+    } else {
+        hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
         hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, false>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+    }
 }
 
 #if defined(BHG_TU_KERR)
