@@ -105,7 +105,7 @@ typedef struct bhg_params {
                            BHG_RHS_KERR_BL: the equatorial plane theta = pi/2 (z = r cos theta = 0), the
                            annulus in the cylindrical radius sqrt(r^2 + a^2) */
     double spin;        /* Kerr a in length units, |a| < M = r_s/2 (BHG_RHS_KERR_BL only) */
-    int32_t time_like;  /* 0: null geodesics, g(k, k) = 0 -- what the engine asks for (time_like=False, :134); 1: the
+    int32_t time_like;  /* 0: null geodesics, g(k, k) = 0 -- what the engine asks for (time_like=False, RelativisticRenderEngine.py:134); 1: the
                            constructor argument's other value, massive particles: g(k, k) = -1, lambda is the proper time.
                            With BHG_RHS_CHRISTOFFEL (the norm enters through (k^t)^2 = (|k|^2 + h (n.k)^2 + 1) / f) and
                            BHG_RHS_KERR_BL (through E and L at the start); BHG_RHS_REDUCED is the null closed form and
@@ -347,8 +347,9 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
                      int32_t gather, bhg_frame **out);
 void bhg_frame_destroy(bhg_frame *frame);
 int bhg_frame_set_scene(bhg_frame *frame, const bhg_frame_scene *scene);
-/* Move the camera of an existing frame (an animation: the frame object, its jitter stream, tile dealing and device
- * buffers stay): origin, rotation and field of view may change, width / height / samples may not.  A new origin costs
+/* Move the camera of an existing frame -- what the engine reads anew on every render, origin and rotation of
+ * depsgraph.scene.camera.matrix_world (RelativisticRenderEngine.py:182-183), field of view (:87-88) -- while the frame object,
+ * its jitter stream (re-seeded identically every render, :189), tile dealing and device buffers stay: origin, rotation and field of view may change, width / height / samples may not.  A new origin costs
  * nothing (rays are directions; the origin goes into every trace call); a new rotation or field of view regenerates the
  * rays on the devices at the next render. */
 int bhg_frame_set_camera(bhg_frame *frame, const bhg_camera *cam);
