@@ -348,7 +348,7 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
 void bhg_frame_destroy(bhg_frame *frame);
 int bhg_frame_set_scene(bhg_frame *frame, const bhg_frame_scene *scene);
 /* Move the camera of an existing frame -- what the engine reads anew on every render, origin and rotation of
- * depsgraph.scene.camera.matrix_world (RelativisticRenderEngine.py:182-183), field of view (:87-88) -- while the frame object,
+ * depsgraph.scene.camera.matrix_world (RelativisticRenderEngine.py:182-183), field of view (:72-73) -- while the frame object,
  * its jitter stream (re-seeded identically every render, :189), tile dealing and device buffers stay: origin, rotation and field of view may change, width / height / samples may not.  A new origin costs
  * nothing (rays are directions; the origin goes into every trace call); a new rotation or field of view regenerates the
  * rays on the devices at the next render. */
