@@ -461,9 +461,11 @@ def main_single_process(a):
                 shares.append(rho)
         return frames, W, H, S
 
-    def timed(frames):
+    def timed(frames, frames_b=None):
+        """frames_b: a second set of frame objects (their own contexts, streams and work counters) -- consecutive steps
+        alternate between the two sets, so that step i + 1 starts while step i's last waves drain (two frames in flight)."""
         def step(i, profile):
-            for f in frames:
+            for f in (frames if (frames_b is None or i % 2 == 0) else frames_b):
                 if a.workload == "orbit":
                     sp, rgb, lamps = wl.orbit_scene(i)
                     f.set_scene(None, spheres=sp, sphere_rgb=rgb, lamps=lamps)
@@ -471,7 +473,7 @@ def main_single_process(a):
                 f.render(wl.params, to_host=False)
 
         def sync():
-            for f in frames:
+            for f in frames + (frames_b or []):
                 f.synchronize()
         if a.ramp_seconds > 0:
             t = time.perf_counter()
@@ -493,6 +495,11 @@ def main_single_process(a):
             tr, rm = f.last_ms()
             call_ms += np.array(tr)
             root_ms += rm
+        for f in (frames_b or []):
+            try:
+                f.last_ms()    # (returns the second lane's event pairs to its pool; it may not have had a profiled step)
+            except _ffi.BhgError:
+                pass
         st = [f.stats() for f in frames]
         return dict(dt=dt, call_ms=call_ms, root_ms=root_ms, rays=sum(s["rays"] for s in st), steps=sum(s["attempted_steps"] for s in st),
                     info=frames[0].info())
@@ -500,17 +507,31 @@ def main_single_process(a):
     nx, ny = grid_for(N) if a.workload != "orbit" else (1, 1)
     frames, W, H, S = build(nx, ny)
     m = timed(frames)
+    pipelined = None
+    if not a.lean:
+        # two frames in flight: a second set of frame objects, steps alternating between the sets
+        fb, _, _, _ = build(nx, ny)
+        p_ = timed(frames, fb)
+        for f in fb:
+            f.close()
+        pipelined = {"value": p_["rays"] / (p_["dt"] / a.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": p_["dt"] / a.steps * 1e3,
+                     "what": "the same steps alternating between TWO frame objects (each with its own contexts and streams): "
+                             "a frame starts while the previous one's last waves drain; never `value`"}
     for f in frames:
         f.close()
     strong = None
     if N > 1 and a.workload != "orbit":
         fs, Ws, Hs, _ = build(1, 1)
         s_ = timed(fs)
-        for f in fs:
+        fb, _, _, _ = build(1, 1)
+        s2 = timed(fs, fb)
+        for f in fs + fb:
             f.close()
         strong = {"value": s_["rays"] / (s_["dt"] / a.steps) / 1e6, "unit": "Mrays/s", "ms_per_step": s_["dt"] / a.steps * 1e3,
                   "ray_steps_per_s": s_["steps"] / (s_["dt"] / a.steps), "scaling": "strong", "trace_call_ms_per_device": [float(v) for v in s_["call_ms"]],
                   "root_gather_assembly_ms": s_["root_ms"],
+                  "two_frames_in_flight": {"value": s2["rays"] / (s2["dt"] / a.steps) / 1e6, "ms_per_step": s2["dt"] / a.steps * 1e3,
+                                           "what": "steps alternating between two frame objects"},
                   "workload": f"ONE {Ws}x{Hs} x{S} frame sharded over {N} device(s) of one process"}
     # the dominant kernel: the slowest device's trace call (for the Schwarzschild forms the call IS the one trace kernel; Kerr
     # adds its prepare and finalize passes -- the call time is then an upper bound of the kernel's)
@@ -551,6 +572,8 @@ def main_single_process(a):
                                    (traffic_source or "none") + " (replayed: the single-process mode does not start counter passes)" if N == 1 else None,
                                    None if not valu else valu * 64.0 / per_dev_steps),
     }
+    if pipelined is not None:
+        out["pipelined"] = pipelined
     if strong is not None:
         out["strong"] = strong
     emit(out)
