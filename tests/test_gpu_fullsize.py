@@ -134,7 +134,8 @@ def test_config5_kerr_frame_full_size(ctx, oracle):
     # EVERY ray of the frame, asserted with a margin over what was measured (round 3, DESIGN.md section 2:
     # 21 rays of 5,242,880 differ in flag, 5,082 (0.097 %) in step count only -- 3,257 of them horizon rays --; of the
     # shaded 1024 x 1024 image 285 pixels (0.027 %) differ by more than 1e-3, 4,746 (0.45 %) by more than 1e-6, the
-    # largest single difference 0.18 in one channel of one pixel):
+    # largest single difference 0.18 in one channel of one pixel; round 4, with the start conversion inside the trace kernel:
+    # 20 / 5,146 (0.098 %) / 278 / 4,751 / 0.14 -- the same census):
     from oracle import shade_reference as sh
     from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
     o = oracle.trace(fr.d_k0.cpu().numpy(), CAM, **kw)
