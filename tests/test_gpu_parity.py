@@ -903,6 +903,9 @@ def test_device_buffer_entry_point_matches_host_entry_point(ctx, full_frame):
     e2, f2, s2, a2 = ctx.trace(k0[:m], CAM, _params(r_s=1.0, lambda_end=50.0), want_steps=False, want_accepted=False,
                                pinned_results=False)
     assert s2 is None and a2 is None and np.array_equal(e2, end[:m]) and np.array_equal(f2, flags[:m])
+    # (the whole set through the pageable form too: five chunks, the last one ragged)
+    e4, f4, s4, a4 = ctx.trace(k0, CAM, _params(r_s=1.0, lambda_end=50.0), pinned_results=False)
+    assert np.array_equal(e4, end) and np.array_equal(f4, flags) and np.array_equal(s4, steps) and np.array_equal(a4, acc)
     # per-ray origins take the same road
     x0 = np.broadcast_to(CAM, (m, 3)).copy()
     e3, f3, s3, a3 = ctx.trace(k0[:m], x0, _params(r_s=1.0, lambda_end=50.0), pinned_results=False)
