@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -49,7 +49,10 @@ EXPORTS = (
     "bhg_frame_create", "bhg_frame_destroy", "bhg_frame_set_scene", "bhg_frame_set_camera", "bhg_frame_render", "bhg_frame_synchronize",
     "bhg_frame_device_image", "bhg_frame_rebalance", "bhg_frame_stats", "bhg_frame_info", "bhg_frame_set_profiling",
     "bhg_frame_last_ms", "bhg_deal_tiles",
+    "bhg_params_size", "bhg_camera_size", "bhg_scene_size", "bhg_frame_scene_size", "bhg_abi_check",
+    "bhg_default_params_sized", "bhg_peak_probe",
 )
+PROBE_FMA, PROBE_STEP_MIX = 0, 1
 
 GATHER_AUTO, GATHER_COPY, GATHER_RCCL, GATHER_PEER = 0, 1, 2, 3
 
@@ -283,8 +286,20 @@ def load():
     L.bhg_deal_tiles.restype = C.c_int
     L.bhg_deal_tiles.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_double, C.c_int32,
                                  C.POINTER(C.c_int64), C.c_size_t, C.POINTER(C.c_size_t)]
-    if L.bhg_version() != ABI_VERSION:
-        raise ImportError(f"libbhgeo ABI {L.bhg_version()} != expected {ABI_VERSION}")
+    if L.bhg_version() != ABI_VERSION or not hasattr(L, "bhg_abi_check"):
+        raise ImportError(f"libbhgeo ABI {L.bhg_version()} != expected {ABI_VERSION}: rebuild {LIB_PATH}")
+    for name in ("bhg_params_size", "bhg_camera_size", "bhg_scene_size", "bhg_frame_scene_size"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = []
+    L.bhg_abi_check.restype = C.c_int
+    L.bhg_abi_check.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.bhg_default_params_sized.restype = C.c_int
+    L.bhg_default_params_sized.argtypes = [C.POINTER(Params), C.c_size_t]
+    L.bhg_peak_probe.restype = C.c_int
+    L.bhg_peak_probe.argtypes = [C.c_void_p, C.c_int32, C.c_double, _dp]
+    # the handshake include/bhgeo.h asks of every binding: ABI version and the layout of every struct declared above
+    if L.bhg_abi_check(ABI_VERSION, C.sizeof(Params), C.sizeof(Camera), C.sizeof(Scene), C.sizeof(FrameScene)) != OK:
+        raise ImportError("libbhgeo: " + L.bhg_last_error().decode())
     _lib = L
     return L
 
@@ -296,7 +311,7 @@ def _check(rc):
 
 def default_params() -> Params:
     p = Params()
-    load().bhg_default_params(C.byref(p))
+    _check(load().bhg_default_params_sized(C.byref(p), C.sizeof(p)))
     return p
 
 
@@ -648,6 +663,14 @@ class Context:
 
     def synchronize(self):
         _check(load().bhg_synchronize(self._h))
+
+    def peak_probe(self, kind=PROBE_FMA, target_ms=1.0):
+        """bhg_peak_probe: the fp64 VALU rate THIS device sustains, in the trace kernels' launch geometry.  kind
+        PROBE_FMA: nothing but v_fma_f64; PROBE_STEP_MIX: the DP5(4) step loop's mix (16 quarter-rate ops per 503)."""
+        out = (C.c_double * 6)()
+        _check(load().bhg_peak_probe(self._h, int(kind), float(target_ms), out))
+        return {"tflops": out[0], "ms": out[1], "valu_wave_insts": out[2], "quarter_rate_wave_insts": out[3],
+                "ms_fastest": out[4], "fp64_full_rate_clock_mhz": out[5]}
 
     # -- host buffers -------------------------------------------------------------------
     def trace(self, k0, x0, params: Params, want_accepted=True, spheres=None, want_steps=True, pinned_results=True):

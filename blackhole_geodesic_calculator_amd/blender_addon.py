@@ -209,6 +209,18 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         return color
 
     # ---- the whole frame on the device (opt-in, scene.device_shading) ------------------------------------------------
+    def _sky_identity(self):
+        """What tells one sky image from another WITHOUT reading its pixels: name, size, file -- and None while the image
+        has unsaved edits (`is_dirty`: its pixels may differ from render to render, so it is read and uploaded each time)."""
+        name = os.path.basename(getattr(self, "sky_image_path", "") or "")
+        if not name or name not in bpy.data.images:
+            return ("<none>",)
+        img = bpy.data.images[name]
+        if getattr(img, "is_dirty", False):
+            return None
+        size = getattr(img, "size", None) or (0, 0)
+        return (name, int(size[0]), int(size[1]), str(getattr(img, "filepath", "")))
+
     def _sky_pixels(self):
         """The sky image as float32 [h, w, 4], rows bottom-up as Blender stores them -- which is the library's
         convention too (texture coordinate v = -1 is row 0).  None when there is no readable image."""
@@ -238,9 +250,6 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         process, :152-168; its commented-out mp.Pool, :210-216, is where the author wanted the parallelism)."""
         from . import _ffi
         from .raygen import euler_xyz_matrix, python_random_stream
-        sky = self._sky_pixels()
-        if sky is None:
-            sky = np.zeros((2, 2, 4), dtype=np.float32)     # no sky image: black, as background_hit returns (:369-370)
         n_dev = max(1, int(getattr(self, "render_devices", 1) or 1))
         avail = _ffi.device_count()
         if n_dev > avail:
@@ -282,7 +291,17 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
                                   "(scene.device_shading = 0 sums over all of them)", RuntimeWarning)
                 lamps = [[*(np.array(list(l.location), dtype=np.float64) - self.bh_loc), self.LAMP_INTENSITY]
                          for l in all_lamps][:4]
+            # The sky image is read (33 MB of float RGBA for a 2k x 1k image) and uploaded to every device only when it is
+            # another image than the frame already holds: an animation renders hundreds of frames against one sky.
+            sky_id = self._sky_identity()
+            sky = None
+            if sky_id is None or getattr(fr, "sky_identity", None) != sky_id:
+                sky = self._sky_pixels()
+                if sky is None:
+                    sky = np.zeros((2, 2, 4), dtype=np.float32)     # no sky image: black, as background_hit returns (:369-370)
+            self.device_sky_uploaded = sky is not None
             fr.set_scene(sky, spheres=sp, sphere_rgb=None if sp is None else np.ones((len(sp), 3)), lamps=lamps)
+            fr.sky_identity = sky_id
             rgba = fr.render(self.GeoInt.params(self.max_integration_step, self.int_depth_curve_end))
             buf[:, :, :] = rgba.reshape(height, width, 4)
             self.last_device_frame = fr.info()

@@ -36,6 +36,8 @@ static_assert(BHG_RHS_CHRISTOFFEL == bhg::BHG_RHS_CHRISTOFFEL_ && BHG_RHS_REDUCE
                   BHG_RHS_KERR_BL == bhg::BHG_RHS_KERR_BL_,
               "rhs mismatch");
 static_assert(sizeof(bhg_params) == 104, "bhg_params layout is part of the ABI");
+static_assert(sizeof(bhg_camera) == 128, "bhg_camera layout is part of the ABI");
+static_assert(sizeof(bhg_scene) == 664 && sizeof(bhg_frame_scene) == 664, "scene layouts are part of the ABI");
 static_assert(BHG_FLAG_HIT_DISK == bhg::BHG_FLAG_HIT_DISK_, "flag mismatch");
 
 namespace {
@@ -315,6 +317,42 @@ int bhg_device_count(void)
 
 const char *bhg_last_error(void) { return g_err.c_str(); }
 
+// the binder's handshake: struct sizes as THIS build of the library lays them out
+size_t bhg_params_size(void) { return sizeof(bhg_params); }
+size_t bhg_camera_size(void) { return sizeof(bhg_camera); }
+size_t bhg_scene_size(void) { return sizeof(bhg_scene); }
+size_t bhg_frame_scene_size(void) { return sizeof(bhg_frame_scene); }
+
+int bhg_abi_check(int abi_version, size_t params_size, size_t camera_size, size_t scene_size, size_t frame_scene_size)
+{
+    if (abi_version != BHG_ABI_VERSION)
+        return fail(BHG_E_INVALID, "ABI mismatch: the binding was written for ABI " + std::to_string(abi_version) + ", this libbhgeo.so is ABI " +
+                                       std::to_string(BHG_ABI_VERSION) + " (include/bhgeo.h)");
+    const struct {
+        const char *name;
+        size_t theirs, ours;
+    } t[] = {{"bhg_params", params_size, sizeof(bhg_params)},
+             {"bhg_camera", camera_size, sizeof(bhg_camera)},
+             {"bhg_scene", scene_size, sizeof(bhg_scene)},
+             {"bhg_frame_scene", frame_scene_size, sizeof(bhg_frame_scene)}};
+    for (const auto &e : t)
+        if (e.theirs != 0 && e.theirs != e.ours)   // (0: the binding does not declare that struct)
+            return fail(BHG_E_INVALID, std::string("ABI mismatch: the binding's ") + e.name + " is " + std::to_string(e.theirs) +
+                                           " bytes, the library's is " + std::to_string(e.ours) + " (include/bhgeo.h, ABI " +
+                                           std::to_string(BHG_ABI_VERSION) + ")");
+    return BHG_OK;
+}
+
+int bhg_default_params_sized(bhg_params *p, size_t params_size)
+{
+    if (!p) return fail(BHG_E_INVALID, "params is NULL");
+    if (params_size != sizeof(bhg_params))
+        return fail(BHG_E_INVALID, "ABI mismatch: the caller's bhg_params is " + std::to_string(params_size) + " bytes, the library's is " +
+                                       std::to_string(sizeof(bhg_params)) + " -- nothing was written");
+    bhg_default_params(p);
+    return BHG_OK;
+}
+
 void bhg_default_params(bhg_params *p)
 {
     if (!p) return;
@@ -488,8 +526,15 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     // overlap the previous call, but it cannot corrupt it either (two traces that are to overlap need two contexts).
     if (c->launched && s != c->last_stream) {
         if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c->ev_order, c->last_stream));
-        HIP_TRY(hipStreamWaitEvent(s, c->ev_order, 0));
+        // The previous call's stream is a handle the CALLER owns; the header asks that it outlive the next call on the
+        // context.  If it has been destroyed all the same (the runtime then refuses the handle), wait for the whole device
+        // instead: slow, but the previous launch is then certainly behind us and the context stays usable.
+        if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_order, 0));
+        } else {
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     c->last_stream = s;
     c->launched = true;
@@ -1223,7 +1268,8 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     if (n_points < 2) return fail(BHG_E_INVALID, "n_points must be >= 2");
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !traj || !n_valid) return fail(BHG_E_INVALID, "x0 / k0 / traj / n_valid is NULL");
-    if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "n must be < 2^32 per call");
+    // (the kernels form a ray's byte offsets in 32 bits -- store_result: idx * 48 -- and this call is ONE launch)
+    if (n > bhg::BHG_MAX_RAYS_PER_LAUNCH) return fail(BHG_E_INVALID, "bhg_trajectory takes at most 2^26 rays per call");
     ENTER_DEVICE(c->device);
     const size_t in_bytes = n * 3 * sizeof(double) * (x0_is_shared ? 1 : 2);
     const size_t sz_traj = n * 6 * (size_t)n_points * sizeof(double);
@@ -1334,6 +1380,66 @@ int bhg_acceleration(bhg_context *c, const bhg_params *p, const double *x, const
                               (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form, c->stream));
     HIP_TRY(hipMemcpyAsync(acc, c->d_out, n * 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return BHG_OK;
+}
+
+int bhg_peak_probe(bhg_context *c, int32_t kind, double target_ms, double out[6])
+{
+    if (!c || !out) return fail(BHG_E_INVALID, "bad argument");
+    if (kind != BHG_PROBE_FMA && kind != BHG_PROBE_STEP_MIX) return fail(BHG_E_INVALID, "unknown probe kind");
+    if (!(target_ms >= 0.0) || target_ms > 100.0) return fail(BHG_E_INVALID, "target_ms must be in [0, 100] (0 = 1 ms)");
+    if (target_ms == 0.0) target_ms = 1.0;
+    ENTER_DEVICE(c->device);
+    const int per_cu = 12;                       // the Schwarzschild trace kernels' residency (3 waves per SIMD)
+    const int grid = per_cu * c->num_cus;
+    int rc = ensure(&c->d_out, &c->d_out_bytes, (size_t)grid * 64 * sizeof(double));
+    if (rc != BHG_OK) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    hipError_t he = hipEventCreate(&e1);
+    if (he != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail_hip(he, "hipEventCreate");
+    }
+    auto timed = [&](uint32_t iters, float *ms) -> hipError_t {
+        hipError_t e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) e = bhg::launch_probe(kind, grid, iters, (double *)c->d_out, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+        return e;
+    };
+    // size the loop for the asked duration from a short launch, then take the median of five
+    uint32_t iters = 64;
+    float ms = 0.0f;
+    he = timed(iters, &ms);
+    if (he == hipSuccess) he = timed(iters, &ms);
+    float runs[5] = {0, 0, 0, 0, 0};
+    if (he == hipSuccess) {
+        const double scale = target_ms / std::fmax((double)ms, 1e-3);
+        iters = (uint32_t)std::fmin(std::fmax(64.0 * scale, 16.0), 4.0e6);
+        he = timed(iters, &ms);   // (one untimed launch at the final size)
+        for (int i = 0; i < 5 && he == hipSuccess; i++) he = timed(iters, &runs[i]);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (he != hipSuccess) return fail_hip(he, "bhg_peak_probe");
+    std::sort(runs, runs + 5);
+    uint32_t valu = 0, quarter = 0;
+    bhg::probe_shape(kind, &valu, &quarter);
+    const double waves = (double)grid;
+    const double wave_insts = waves * (double)iters * (double)valu;
+    // flops under SURVEY section 8d's counting rule: an FMA is 2, a reciprocal / reciprocal square root 1
+    const double flops = waves * 64.0 * (double)iters * (2.0 * (double)(valu - quarter) + (double)quarter);
+    const double sec = (double)runs[2] * 1e-3;
+    out[0] = flops / sec * 1e-12;
+    out[1] = (double)runs[2];
+    out[2] = wave_insts;
+    out[3] = waves * (double)iters * (double)quarter;
+    out[4] = (double)runs[0];
+    // the clock a full-rate fp64 pipe (128 flop per clock and CU) would need for that figure: for the pure-FMA probe the
+    // sustained shader clock itself
+    out[5] = out[0] * 1e12 / (128.0 * (double)c->num_cus) * 1e-6;
     return BHG_OK;
 }
 

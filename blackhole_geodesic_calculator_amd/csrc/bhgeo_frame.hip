@@ -84,12 +84,9 @@ struct Rccl {
 };
 constexpr int NCCL_FLOAT32 = 7;   // ncclFloat32 (rccl.h)
 
-Rccl &rccl()
+Rccl load_rccl()
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    Rccl r;
     // by SONAME first: a host process that already carries RCCL (PyTorch-ROCm bundles one) keeps ONE copy
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
@@ -106,6 +103,12 @@ Rccl &rccl()
     t.Recv = (decltype(t.Recv))dlsym(h, "ncclRecv");
     t.GetErrorString = (decltype(t.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (t.CommInitAll && t.CommDestroy && t.GroupStart && t.GroupEnd && t.Send && t.Recv && t.GetErrorString) r = t;
+    return r;
+}
+
+Rccl &rccl()
+{
+    static Rccl r = load_rccl();   // (a function-local static: initialised once, also when two threads create frames at once)
     return r;
 }
 
@@ -156,6 +159,7 @@ struct Shard {
     DevBuf pixels_d, jitter_d, k0, end, dir, flags, steps, acc, obj, slab, sky, disk_tex;
     hipEvent_t done = nullptr;
     bool rays_ready = false;
+    bool jitter_ready = false;      // jitter_d holds the draws of THIS pixel list (kept: a rotating camera regenerates the rays from it)
     bool scene_ready = false;
     bool dir_traced = false;
     nccl_comm_t comm = nullptr;
@@ -245,8 +249,12 @@ void deal_tiles(bhg_frame *f)
         s.P = s.pixels.size();
         s.n = s.P * (size_t)f->cam.samples;
         s.rays_ready = false;
+        s.jitter_ready = false;
         f->pmax = std::max(f->pmax, s.P);
     }
+    // the devices' steps / flags arrays still hold the PREVIOUS pixel lists' rays (and may be smaller than the new shards):
+    // nothing may read them by the new lists until the next render
+    f->rendered = false;
 }
 
 int upload_shard_geometry(bhg_frame *f, Shard &s)
@@ -265,7 +273,7 @@ int upload_shard_geometry(bhg_frame *f, Shard &s)
     }
     HIP_TRY(hipMemcpyAsync(s.pixels_d.p, s.pixels.data(), s.P * sizeof(int64_t), hipMemcpyHostToDevice, s.stream));
     std::vector<double> jc;
-    if (!f->jitter.empty()) {
+    if (!f->jitter.empty() && !s.jitter_ready) {
         jc.resize(2 * S * s.P);
         for (size_t sm = 0; sm < S; sm++)
             for (size_t p = 0; p < s.P; p++) {
@@ -293,7 +301,9 @@ int upload_shard_geometry(bhg_frame *f, Shard &s)
     std::memcpy(a.rot, f->cam.rot, sizeof(a.rot));
     HIP_TRY(bhg::launch_raygen(a, s.stream));
     HIP_TRY(hipStreamSynchronize(s.stream));   // (jc and the pixel list are host temporaries of this call)
-    s.jitter_d.release();                      // the stream is only needed to generate the rays
+    // the shard's draws stay on the device (16 B per ray): a camera that rotates from frame to frame regenerates its rays
+    // with one raygen launch, no host-side gather of the stream and no upload
+    s.jitter_ready = !f->jitter.empty();
     s.rays_ready = true;
     return BHG_OK;
 }
@@ -469,7 +479,8 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
     }
     // gather mode: RCCL when asked for, or (AUTO) when there is something to gather between distinct devices
     f->gather = BHG_FRAME_GATHER_COPY;
-    if (rc == BHG_OK && n_devices > 1 && distinct && gather != BHG_FRAME_GATHER_COPY && rccl().ok()) f->gather = BHG_FRAME_GATHER_RCCL;
+    if (rc == BHG_OK && n_devices > 1 && distinct && gather != BHG_FRAME_GATHER_COPY && gather != BHG_FRAME_GATHER_PEER && rccl().ok())
+        f->gather = BHG_FRAME_GATHER_RCCL;
     if (rc == BHG_OK && n_devices == 1 && gather == BHG_FRAME_GATHER_RCCL) f->gather = BHG_FRAME_GATHER_RCCL;   // (a 1-rank group: tests)
     if (rc == BHG_OK && f->gather == BHG_FRAME_GATHER_RCCL) {
         std::vector<nccl_comm_t> comms((size_t)n_devices, nullptr);
@@ -660,11 +671,19 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
                 HIP_TRY(hipEventRecord(f->ev_root[0], root.stream));
             }
             NCCL_TRY(rccl().GroupStart());
-            for (size_t r = loopback ? 0 : 1; r < world; r++) {
-                NCCL_TRY(rccl().Send(f->sh[r].slab.p, slab_floats, NCCL_FLOAT32, 0, f->sh[r].comm, f->sh[r].stream));
-                NCCL_TRY(rccl().Recv(f->recv.as<float>() + r * slab_floats, slab_floats, NCCL_FLOAT32, (int)r, root.comm, root.stream));
+            int ne = 0;
+            const char *what = "";
+            for (size_t r = loopback ? 0 : 1; r < world && ne == 0; r++) {
+                ne = rccl().Send(f->sh[r].slab.p, slab_floats, NCCL_FLOAT32, 0, f->sh[r].comm, f->sh[r].stream);
+                what = "ncclSend";
+                if (ne != 0) break;
+                ne = rccl().Recv(f->recv.as<float>() + r * slab_floats, slab_floats, NCCL_FLOAT32, (int)r, root.comm, root.stream);
+                what = "ncclRecv";
             }
-            NCCL_TRY(rccl().GroupEnd());
+            // (the group is closed on the error path too: a group left open would swallow the next frame's calls)
+            const int ge = rccl().GroupEnd();
+            if (ne != 0) return fail_nccl(ne, what);
+            NCCL_TRY(ge);
         } else {
             for (size_t r = 1; r < world; r++) {
                 Shard &s = f->sh[r];

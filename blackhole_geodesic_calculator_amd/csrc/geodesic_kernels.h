@@ -140,4 +140,8 @@ hipError_t launch_accel(const double *x, const double *k, double r_s, double spi
                         hipStream_t s);
 hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, double spin, double mu2, uint64_t n, double *acc, hipStream_t s);
 
+// roofline calibration probes (probe_kernels.hip): kind 0 = pure v_fma_f64, 1 = the DP5(4) step loop's instruction mix
+hipError_t launch_probe(int kind, int grid, uint32_t iters, double *out, hipStream_t s);
+void probe_shape(int kind, uint32_t *valu_per_iter, uint32_t *quarter_per_iter);
+
 }  // namespace bhg

@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 6   /* 6: bhg_frame_* (library-owned frame, N devices), bhg_deal_tiles, bhg_params.time_like (104 bytes) */
+#define BHG_ABI_VERSION 7   /* 7: the binder's handshake -- bhg_abi_check, bhg_*_size, bhg_default_params_sized; bhg_peak_probe.
+                               6: bhg_frame_* (library-owned frame, N devices), bhg_deal_tiles, bhg_params.time_like (104 bytes) */
 
 /* return codes */
 #define BHG_OK 0
@@ -121,7 +122,26 @@ int bhg_device_count(void);           /* number of HIP devices, 0 if none, never
 const char *bhg_last_error(void);     /* thread-local, never NULL */
 void bhg_default_params(bhg_params *p); /* engine defaults: r_s=1 (mass 0.5), lambda_end=50,
                                            max_step=inf, rtol=1e-3, atol=1e-6, DP54, Christoffel
-                                           (RelativisticRenderEngine.py:506-508; scipy rk.py:85-87) */
+                                           (RelativisticRenderEngine.py:506-508; scipy rk.py:85-87).
+                                           Writes sizeof(bhg_params) bytes AS THE LIBRARY LAYS THE STRUCT OUT:
+                                           a binding checks its own layout first (below) */
+
+/* --- the binder's handshake ---------------------------------------------------------------
+ * The reference-side caller is a Python file (raytracer/RelativisticRenderEngine.py:134, :293-294): its binding declares
+ * these structs by hand (ctypes), and a struct that grew between library versions (bhg_params: 96 bytes in ABI 5, 104
+ * since ABI 6) is then written and read past its end without any error.  A binding therefore calls, once after loading,
+ *
+ *     bhg_abi_check(<the BHG_ABI_VERSION it was written for>, sizeof its bhg_params, bhg_camera, bhg_scene, bhg_frame_scene)
+ *
+ * -> BHG_OK, or BHG_E_INVALID with a bhg_last_error() message that names both figures.  A size of 0 = "this binding does
+ * not declare that struct".  bhg_*_size() give the library's own sizes; bhg_default_params_sized() is bhg_default_params
+ * for a caller that passes its struct's size along and gets BHG_E_INVALID -- and not one byte written -- on a mismatch. */
+size_t bhg_params_size(void);
+size_t bhg_camera_size(void);
+size_t bhg_scene_size(void);
+size_t bhg_frame_scene_size(void);
+int bhg_abi_check(int abi_version, size_t params_size, size_t camera_size, size_t scene_size, size_t frame_scene_size);
+int bhg_default_params_sized(bhg_params *p, size_t params_size);
 
 /* --- context ----------------------------------------------------------------------------
  * Every entry point makes the context's device current for its own HIP calls and restores the calling
@@ -184,7 +204,7 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * are produced from the step's dense output, as solve_ivp does with t_eval; a ray that ends early (horizon,
  * exit sphere) yields n_valid[i] < n_points samples, the rest of its row is NaN.  traj [n][6][n_points]
  * (rows x, y, z, k_x, k_y, k_z).  end [n][6] / flags [n] (may be NULL): the same end state and flags
- * bhg_trace gives.  BHG_METHOD_DP54 only; the disk event is not available here.  Small-n path: one
+ * bhg_trace gives.  BHG_METHOD_DP54 only; the disk event is not available here; at most 2^26 rays per call.  Small-n path: one
  * WAVE per ray up to 2048 rays (a step's samples are shared out over the 64 lanes: the engine's literal call, one ray
  * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way. */
 int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
@@ -196,7 +216,9 @@ int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int 
  * returns without synchronising -- with or without a disk or objects: ONE persistent launch finishes
  * every ray (events are located and rays that carry on are resumed inside the trace kernel).  Two calls
  * on one context never overlap: they share the context's work counters and workspace, so a call issued on another
- * stream than the previous one is ordered behind it by the library (an event + a stream wait; calls that are to run
+ * stream than the previous one is ordered behind it by the library (an event recorded on the PREVIOUS call's stream + a
+ * wait on the new one: a stream handed to a call must therefore stay alive until the next call on the context has been
+ * issued -- if it was destroyed all the same, the library falls back to a device-wide wait; calls that are to run
  * concurrently need a context each).  The launch is not graph-replayable (it consumes and re-arms those counters). */
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,
@@ -417,6 +439,20 @@ int bhg_last_pass_ms(bhg_context *ctx, float out_ms[3]);
  *          event are resumed inside the same launch -- unless the call holds more than 2^26 rays (a launch takes at
  *          most that many; BASELINE's largest frame, 2048 x 2048 x 16, is exactly one). */
 int bhg_last_launch(bhg_context *ctx, int32_t out[4]);
+
+/* Roofline calibration on THIS device, in the trace kernels' own launch geometry (one wave64 per workgroup, 12 resident
+ * waves per CU; no memory traffic inside the loop) -- bench.py's `roofline.calibration` block, so that two bench lines
+ * from two boxes of a pool can be compared (SURVEY.md section 8d prices against the vendor's 78.6 TFLOP/s):
+ *   BHG_PROBE_FMA       nothing but v_fma_f64, eight independent chains per lane: the fp64 vector rate this box sustains;
+ *   BHG_PROBE_STEP_MIX  the DP5(4) step loop's mix -- per 503 VALU instructions 8 v_rcp_f64 + 8 v_rsq_f64 (quarter rate)
+ *                       among 487 v_fma_f64: the issue-bound ceiling of a kernel with that mix.
+ * target_ms: duration of one probe launch (0 = 1 ms); the loop is sized from a short launch, then the MEDIAN of five
+ * launches is reported.  out = {TFLOP/s (FMA = 2 flop, rcp / rsq = 1), ms per launch (median), VALU wave-instructions
+ * per launch, quarter-rate ones among them, fastest of the five launches in ms, the shader clock in MHz that a full-rate
+ * fp64 pipe (128 flop per clock and CU) needs for that TFLOP/s figure}.  Blocking; runs on the context's own stream. */
+#define BHG_PROBE_FMA 0
+#define BHG_PROBE_STEP_MIX 1
+int bhg_peak_probe(bhg_context *ctx, int32_t kind, double target_ms, double out[6]);
 
 #ifdef __cplusplus
 }

@@ -209,7 +209,7 @@ def test_addon_keeps_its_device_frame_across_renders(ctx, oracle):
     new frame; unregister() frees it."""
     from oracle import shade_reference as sh
     from blackhole_geodesic_calculator_amd import camera_directions
-    reused = []
+    reused, uploaded = [], []
     bpy, depsgraph = fake_bpy.install(width=48, height=48, samples=2, device_shading=1.0)
     addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
     addon.register()
@@ -220,6 +220,7 @@ def test_addon_keeps_its_device_frame_across_renders(ctx, oracle):
         eng = addon.RelativisticRenderEngine()          # (a new engine instance per frame, as Blender does)
         eng.render(depsgraph)
         reused.append(eng.device_frame_reused)
+        uploaded.append(eng.device_sky_uploaded)
         rect = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(size, size, 4)
         d = camera_directions(size, size, 2, 0.6, 0.6, 42.0, rotation_euler=euler).reshape(-1, 3)
         o = oracle.trace(d, np.array(cam), r_s=1.0, lambda_end=50.0)
@@ -227,6 +228,19 @@ def test_addon_keeps_its_device_frame_across_renders(ctx, oracle):
         assert np.abs(rect - want).max() < 1e-6
         assert len(addon._DEVICE_FRAMES) == 1
     assert reused == [False, True, True, False]
+    # the sky image crosses PCIe once per frame OBJECT, not once per render (every render re-uploaded 33 MB per device)
+    assert uploaded == [True, False, False, True]
+    # ... unless it has unsaved edits: another image under the same name is read and uploaded again
+    img = bpy.data.images["sky.png"]
+    img.array = np.ascontiguousarray(img.array[:, ::-1])
+    img.pixels = img.array.reshape(-1).tolist()
+    img.is_dirty = True
+    eng = addon.RelativisticRenderEngine()
+    eng.render(depsgraph)
+    assert eng.device_frame_reused and eng.device_sky_uploaded
+    rect2 = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(size, size, 4)
+    want2 = sh.shade_reduce(o["end"], o["flags"], size * size, 2, img.array).reshape(size, size, 4)
+    assert np.abs(rect2 - want2).max() < 1e-6 and np.abs(rect2 - rect).max() > 1e-3
     addon.unregister()
     assert len(addon._DEVICE_FRAMES) == 0
 
