@@ -43,8 +43,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bench_common import (BYTES_PER_RAY, BYTES_PER_RAY_DIR, CAM, DISK, EV_EVERY, PEAK_FP64_VALU_TFLOPS, Lanes, Runtime, Workload,  # noqa: F401
-                          emit, grid_for, roofline_block, traced_with_events)
+from bench_common import (BYTES_PER_RAY, BYTES_PER_RAY_DIR, CAM, DISK, EV_EVERY, PEAK_FP64_VALU_TFLOPS, ClockSampler, Lanes, Runtime,  # noqa: F401
+                          Workload, emit, grid_for, roofline_block, run_probes, traced_with_events)
 from bench_figures import (counters_for, host_buffer_figures, live_pmc, main_single_process, pipelined_figure,  # noqa: F401
                            pmc_traffic, strong_predicted, time_frame)
 
@@ -72,8 +72,11 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--full-records", action="store_true",
-                    help="frame workload: have the trace write whole end states (48 B/ray) instead of the exit directions a sky frame reads")
+    ap.add_argument("--dir-only", action="store_true",
+                    help="frame workload: have the trace write only the exit directions a sky frame reads (24 B/ray) instead of whole "
+                         "end states (x and k, 48 B/ray: spacetime_ray_cast's return values, RelativisticRenderEngine.py:307-308 -- the "
+                         "default and the headline since round 5; the direction-only form is reported beside it as sky_frame_dir_only)")
+    ap.add_argument("--full-records", action="store_true", help="(the default since round 5; accepted for older scripts)")
     ap.add_argument("--lpt", type=int, default=1, help="1: visit tiles in order of decreasing expected cost")
     ap.add_argument("--visit", choices=["auto", "cost", "row"], default="auto",
                     help="order in which a rank visits its tiles: by decreasing cost (shortens the wave-drain tail: what a "
@@ -167,10 +170,10 @@ def build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky):
         for f in frames:
             f.set_disk(DISK[0], DISK[1], disk_tex)
     else:
-        # a sky frame reads only the exit directions of its rays (background_hit, :366-378): the trace writes those
-        # alone (bhg_trace_dir_device) unless --full-records asks for whole end states
+        # the trace writes what spacetime_ray_cast returns -- exit position AND direction (:307-308; north_star: "exit
+        # position/direction written back"); --dir-only: only the directions a sky frame reads (background_hit, :366-378)
         frames.append(DeviceFrame(rt.ctx, W, H, S, fov_x=fov_x, fov_y=fov_y, sampling_seed=42.0, origin=CAM, pixels=pixels,
-                                  jitter=jitter, directions_only=(a.workload == "frame" and not a.full_records)))
+                                  jitter=jitter, directions_only=(a.workload == "frame" and a.dir_only)))
     for f in frames:
         f.set_sky(sky)
         f.generate_rays()
@@ -336,11 +339,22 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
     for i in range(a.warmup):
         step(i, False)
     barrier()
+    # roofline calibration (bhg_peak_probe: the fp64 rate THIS box sustains), right before and right after the timed
+    # region -- the headline's region only, outside its clock -- and the shader clock sampled from sysfs while it runs
+    calibrate = not overlap and not whole_frames and not a.lean
+    calibration, sampler = {}, None
+    if calibrate:
+        calibration["before"] = run_probes(rt.ctx)
+        barrier()
+        sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
     barrier(final=True)
     dt = time.perf_counter() - t0
+    sclk = sampler.stop() if sampler is not None else None
+    if calibrate:
+        calibration["after"] = run_probes(rt.ctx)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -384,7 +398,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
         lanes.close()
     return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                 steps_all=float(tot[1].item()), launch=rt.ctx.last_launch(), fr=fr, tcost=tcost,
-                visit=tile_cost.visit, root_share=root_share)
+                visit=tile_cost.visit, root_share=root_share, calibration=calibration, sclk=sclk)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -528,26 +542,36 @@ def main():
                 "root_share": m["root_share"],
                 "launch": m["launch"],
             },
-            "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64),
+            "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64,
+                                       calibration=m["calibration"], sclk=m["sclk"]),
         }
+        if a.workload == "frame":
+            out["config"]["north_star_output"] = ("exit directions only (--dir-only)" if getattr(fr, "_dir_traced", False) else
+                                                  "full_records: exit position and direction (x, k: 48 B/ray), flags, step counts -- what "
+                                                  "spacetime_ray_cast returns (RelativisticRenderEngine.py:307-308)")
         if strong is not None:
             out["strong"] = strong
         if frames_sharded is not None:
             out["frames_sharded"] = frames_sharded
         t1 = None
-        if world == 1 and a.workload == "frame" and getattr(fr, "_dir_traced", False) and not a.lean:
-            # what north_star names -- "exit position/direction written back": the same frame with whole end states
-            # (81 B/ray) instead of the exit directions a sky frame reads (57 B/ray); same K / W, same clock
-            frf = DeviceFrame(rt.ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=CAM,
-                              pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=False)
-            frf.d_k0 = fr.d_k0
-            frf.set_sky(sky)
-            ms_f, call_f, steps_f = time_frame(frf, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
-            out["full_records"] = {"value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
-                                   "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                                   "algorithmic_bytes_per_ray": BYTES_PER_RAY,
-                                   "what": "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them"}
-            del frf
+        if world == 1 and a.workload == "frame" and not a.lean:
+            # the other output form of the same frame, same K / W, same clock: whole end states (81 B/ray: what north_star
+            # names -- "exit position/direction written back" -- and the headline) against the exit directions alone that a
+            # sky frame reads (57 B/ray; background_hit, :366-378)
+            other_dir = not getattr(fr, "_dir_traced", False)
+            fro = DeviceFrame(rt.ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=CAM,
+                              pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=other_dir)
+            fro.d_k0 = fr.d_k0
+            fro.set_sky(sky)
+            ms_f, call_f, steps_f = time_frame(fro, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
+            out["sky_frame_dir_only" if other_dir else "full_records"] = {
+                "value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
+                "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "algorithmic_bytes_per_ray": BYTES_PER_RAY_DIR if other_dir else BYTES_PER_RAY,
+                "what": ("the same frame and K / W with only the exit directions written (24 B/ray: all a sky frame reads of its rays) and "
+                         "shaded from them" if other_dir else
+                         "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them")}
+            del fro
         if world == 1 and a.workload == "frame" and a.emulate_shards.strip():
             t1_ms, t1_call, _ = time_frame(fr, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
             out["strong_predicted"] = strong_predicted(rt, wl, sky, m, (t1_ms, t1_call))

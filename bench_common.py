@@ -236,8 +236,118 @@ def traced_with_events(f, params, stream, sink):
     sink.append((e0, e1))
 
 
-def roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64):
+class ClockSampler:
+    """The shader clock while the timed region runs, if the box exposes it WITHOUT a subprocess (a child process after
+    this one has initialised the GPU is what the pool forbids; reading a sysfs file is not): hwmon's freq1_input (Hz) of
+    the card whose unique_id / index matches, sampled every few milliseconds from a thread -- the main thread sits in a
+    blocking synchronise for nearly all of the region, so the sampler costs it nothing.  None where nothing is readable."""
+
+    def __init__(self, device_index=0, period_s=0.004):
+        import glob
+        self.period = period_s
+        self.samples = []
+        self.path = None
+        self._stop = False
+        self._t = None
+        # the card of THIS device: by PCI address (a box shows all eight cards of its node in sysfs, one of them is ours)
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/freq1_input"))
+        for c in cards:
+            dev = os.path.realpath(c.split("/hwmon/")[0])
+            if want is not None and os.path.basename(dev).lower() == want.lower():
+                self.path = c
+        self.pci = want
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                return float(f.read().strip()) * 1e-6     # Hz -> MHz
+        except Exception:
+            return None
+
+    def start(self):
+        if self.path is None or self._read() is None:
+            self.path = None
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                v = self._read()
+                if v is not None:
+                    self.samples.append(v)
+                time.sleep(self.period)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._t is not None:
+            self._t.join(timeout=1.0)
+        if not self.samples:
+            return None
+        v = np.array(self.samples)
+        return {"mean_mhz": float(v.mean()), "min_mhz": float(v.min()), "max_mhz": float(v.max()), "samples": int(len(v)),
+                "source": self.path, "pci": self.pci}
+
+
+def run_probes(ctx):
+    """bhg_peak_probe, both kinds (2-ms launches, median of five each): what THIS box's fp64 pipe delivers."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    fma = ctx.peak_probe(_ffi.PROBE_FMA, 2.0)
+    mix = ctx.peak_probe(_ffi.PROBE_STEP_MIX, 2.0)
+    return {"fp64_fma_tflops": fma["tflops"], "fp64_fma_clock_mhz": fma["fp64_full_rate_clock_mhz"],
+            "fma_wave_insts_per_s": fma["valu_wave_insts"] / (fma["ms"] * 1e-3),
+            "step_mix_tflops": mix["tflops"], "step_mix_wave_insts_per_s": mix["valu_wave_insts"] / (mix["ms"] * 1e-3)}
+
+
+def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
+    """roofline.calibration: the box's own peak beside the vendor's.  cal = {"before": run_probes(), "after": run_probes()}
+    around the timed region."""
+    if not cal or "before" not in cal:
+        return None
+    b, a_ = cal["before"], cal.get("after") or cal["before"]
+    fma = 0.5 * (b["fp64_fma_tflops"] + a_["fp64_fma_tflops"])
+    mix_rate = 0.5 * (b["step_mix_wave_insts_per_s"] + a_["step_mix_wave_insts_per_s"])
+    out = {
+        "fp64_fma_tflops_measured": fma,
+        "fp64_fma_tflops_before_after": [b["fp64_fma_tflops"], a_["fp64_fma_tflops"]],
+        "fp64_fma_frac_of_vendor_peak": fma / PEAK_FP64_VALU_TFLOPS,
+        "sclk_mhz_implied_by_fma_probe": 0.5 * (b["fp64_fma_clock_mhz"] + a_["fp64_fma_clock_mhz"]),
+        # the issue ceiling of a kernel with the step loop's instruction mix (16 quarter-rate v_rcp_f64 / v_rsq_f64 per 503):
+        # wave-level VALU instructions per second the box sustains on that mix, and the same as TFLOP/s under SURVEY's
+        # counting rule (FMA 2, rcp / rsq 1)
+        "issue_bound_wave_insts_per_s": mix_rate,
+        "issue_bound_tflops": 0.5 * (b["step_mix_tflops"] + a_["step_mix_tflops"]),
+        "frac_of_measured_peak": achieved_tf / fma,
+        "sclk_mhz_timed_region": sclk if sclk is not None else "omitted: no hwmon freq1_input readable for this device on this box",
+        "method": "bhg_peak_probe (include/bhgeo.h) in this process, right before and right after the timed region, in the trace "
+                  "kernels' launch geometry (1 wave64 per workgroup, 12 waves per CU, no memory traffic): 2-ms launches, median of 5; "
+                  "figures are the mean of the two probes",
+    }
+    if valu_per_64:
+        # how much of that ceiling the trace kernel's own instruction stream uses: its wave-level VALU instructions per second
+        out["trace_kernel_wave_insts_per_s"] = valu_per_64 * (ray_steps / 64.0) / (k_ms * 1e-3)
+        out["valu_issue_utilisation"] = out["trace_kernel_wave_insts_per_s"] / mix_rate
+    return out
+
+
+def roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, calibration=None,
+                   sclk=None):
     achieved_tf = ray_steps * wl.flop / (k_ms * 1e-3) / 1e12
+    cal = calibration_block(calibration, sclk, achieved_tf, valu_per_64, ray_steps, k_ms)
+    extra = {} if cal is None else {"frac_of_measured_peak": cal["frac_of_measured_peak"], "calibration": cal}
+    return {**_roofline_core(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, achieved_tf), **extra}
+
+
+def _roofline_core(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, achieved_tf):
     return {
         "bound": "valu_fp64",
         "kernel": f"trace_{wl.method}_kernel<{wl.a.rhs}>: ONE launch per trace call integrates every ray to its end "

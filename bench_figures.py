@@ -40,8 +40,8 @@ def live_pmc(a, deadline_s=300.0):
     for flag, val in (("--width", a.width), ("--height", a.height), ("--samples", a.samples)):
         if val is not None:
             child += [flag, str(val)]
-    if a.full_records:
-        child.append("--full-records")
+    if a.dir_only:
+        child.append("--dir-only")
     out, child_steps = {}, None
     t_end = time.monotonic() + deadline_s
     tmp = tempfile.mkdtemp(prefix="bhg_pmc_", dir="/tmp")

@@ -18,6 +18,12 @@
 int main(int argc, char **argv)
 {
     enum { W = 160, H = 96, S = 2, SKY_W = 64, SKY_H = 32 };
+    /* the binder's handshake: this program was compiled against include/bhgeo.h of ABI BHG_ABI_VERSION; a library of
+     * another version (other struct sizes) says so here instead of writing past a struct */
+    if (bhg_abi_check(BHG_ABI_VERSION, sizeof(bhg_params), sizeof(bhg_camera), sizeof(bhg_scene), sizeof(bhg_frame_scene)) != BHG_OK) {
+        fprintf(stderr, "%s\n", bhg_last_error());
+        return 9;
+    }
     int32_t devices[16];
     int n_dev = 0;
     char list[256];

@@ -16,6 +16,11 @@
 int main(void)
 {
     const int W = 96, H = 64;
+    /* the binder's handshake (include/bhgeo.h): header and library must agree on the ABI and on sizeof(bhg_params) */
+    if (bhg_abi_check(BHG_ABI_VERSION, sizeof(bhg_params), 0, 0, 0) != BHG_OK) {
+        fprintf(stderr, "%s\n", bhg_last_error());
+        return 9;
+    }
     const size_t n = (size_t)W * H;
     const double cam[3] = {1e-4, 0.0, 30.0}; /* BH-centred camera position, looking down -z */
     double *k0 = malloc(n * 3 * sizeof(double)), *end = malloc(n * 6 * sizeof(double));

@@ -197,3 +197,24 @@ def test_bench_measures_traffic_live_with_rocprofv3_child_runs():
     assert 0.5 * n * 57 < r["traffic"] < 4.0 * n * 57            # HBM bytes per launch: around the algorithmic 57 B/ray
     assert 400 < r["valu_insts_per_64_ray_steps"] < 1200
     assert line["cpu_baseline"]["value"] > 0
+
+
+def test_first_node_run_script_works_with_one_gpu_stand_ins(tmp_path):
+    """scripts/first_node_run.sh -- the one command for the first multi-GPU lease -- run here with its stand-ins for a
+    one-GPU box (--standin: torch.distributed ranks over gloo sharing the GPU, device lists that repeat device 0), so that
+    the script itself is known to work before a node is spent on it: every step ends with rc 0, the two-rank line carries
+    the strong block with a measured efficiency next to the prediction of the one-rank line, the sharded images equal the
+    one-device image bit for bit."""
+    out = tmp_path / "node_run.jsonl"
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "first_node_run.sh"), "--standin", "--quick", "--gpus", "2", "--steps", "8",
+                        "--warmup", "2", "--out", str(out), "--timeout", "300"], capture_output=True, text=True, timeout=1200)
+    recs = {x["step"]: x for x in (json.loads(l) for l in open(out))}
+    assert r.returncode == 0 and recs["summary"]["failed"] == [], (r.stdout[-2000:], r.stderr[-2000:])
+    want = ["dist_n1", "dist_n2", "single_n1_auto", "single_n2_copy", "build_render_frame", "c_example_n1", "c_example_n2", "bit_identity_n2_copy"]
+    assert [k for k in recs if k != "summary"] == want and all(recs[k]["rc"] == 0 for k in want)
+    assert recs["dist_n1"]["strong_predicted_rank0"].get("2") is not None and recs["dist_n1"]["frac_of_measured_peak"] > 0.3
+    st = recs["dist_n2"]["strong"]
+    assert recs["dist_n2"]["n_gpus"] == 2 and st["efficiency_measured"] > 0.2 and st["efficiency_rank0_predicted"] is not None
+    assert recs["single_n2_copy"]["n_gpus"] == 2 and "copy" in recs["single_n2_copy"]["collective"]
+    assert recs["c_example_n1"]["signature"] == recs["c_example_n2"]["signature"]
+    assert recs["bit_identity_n2_copy"]["bit_identical"] is True and recs["bit_identity_n2_copy"]["images"] == 3

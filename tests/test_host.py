@@ -2,9 +2,11 @@
 exports every symbol include/bhgeo.h declares, argument validation, loud failure without a GPU.
 No compute call is made here."""
 import ctypes
+import json
 import os
 import random
 import re
+import subprocess
 import sys
 import time
 
@@ -296,3 +298,70 @@ def test_bench_live_pmc_kills_the_whole_process_group_on_timeout(tmp_path, monke
     time.sleep(0.3)
     alive = os.path.exists(f"/proc/{pid}") and "Z" not in open(f"/proc/{pid}/stat").read().split(")")[1].split()[0]
     assert not alive, "the profiler's descendant survived the timeout"
+
+
+def _gpu_visible():
+    from blackhole_geodesic_calculator_amd import _ffi
+    return _ffi.device_count() > 0
+
+
+# ---- scripts/first_node_run.py: the one-command run for the first multi-GPU lease -------------------------------------
+def _node_run():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("first_node_run", os.path.join(ROOT, "scripts", "first_node_run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_first_node_run_plan_covers_every_form_and_device_count():
+    nr = _node_run()
+    import argparse
+    names = [s["name"] for s in nr.plan(argparse.Namespace(gpus=8, steps=100, warmup=10, standin=False, quick=False))]
+    for n in (1, 2, 4, 8):
+        assert f"dist_n{n}" in names and f"c_example_n{n}" in names
+    for n in (2, 4, 8):
+        for mode in ("rccl", "copy", "peer"):
+            assert f"single_n{n}_{mode}" in names and f"bit_identity_n{n}_{mode}" in names
+    assert names.index("build_render_frame") < names.index("c_example_n1")
+    # the stand-in plan for a one-GPU box: gloo ranks sharing the GPU, repeated device indices, copies only
+    st = nr.plan(argparse.Namespace(gpus=2, steps=5, warmup=1, standin=True, quick=True))
+    by = {s["name"]: s for s in st}
+    assert by["dist_n2"]["env"] == {"BHGEO_BENCH_BACKEND": "gloo"} and by["single_n2_copy"]["env"] == {"BHGEO_DEVICES": "0,0"}
+    assert "single_n2_rccl" not in by and by["c_example_n2"]["cmd"][-1] == "0,0"
+
+
+def test_first_node_run_records_and_compares_with_the_prediction():
+    nr = _node_run()
+    pred = {}
+    line1 = {"metric": "m", "n_gpus": 1, "value": 4000.0, "ms_per_step": 1.25, "scaling": "weak", "config": {"collective": "none (single rank)"},
+             "roofline": {"frac": 0.46, "frac_of_measured_peak": 0.5},
+             "strong_predicted": {"T1_ms_per_step": 1.2, "T1_ms_per_step_two_in_flight": 1.19,
+                                  "shards": {"8": {"efficiency_rank0": 0.81, "efficiency_two_in_flight": 0.8}}}}
+    r1 = nr.summarise(dict(name="dist_n1", kind="bench", n=1, cmd=["python", "bench.py"], env={}), 0, "banner\n" + json.dumps(line1) + "\n", "", 30.0, pred)
+    assert r1["rc"] == 0 and r1["strong_predicted_rank0"] == {"8": 0.81} and pred["T1_ms_per_step"] == 1.2
+    line8 = {"metric": "m", "n_gpus": 8, "value": 30000.0, "ms_per_step": 1.4, "scaling": "weak",
+             "config": {"collective": "rccl gather, 8 rank(s)", "root_share": 0.7}, "roofline": {"frac": 0.45},
+             "strong": {"value": 25000.0, "ms_per_step": 0.19, "root_share": 0.7, "frames_in_flight": 2}}
+    r8 = nr.summarise(dict(name="dist_n8", kind="bench", n=8, cmd=["python", "bench.py"], env={}), 0, json.dumps(line8), "", 60.0, pred)
+    assert r8["rccl_ranks_seen"] == 8 and r8["root_share"] == 0.7
+    assert abs(r8["strong"]["efficiency_measured"] - 1.19 / (8 * 0.19)) < 1e-12 and r8["strong"]["efficiency_rank0_predicted"] == 0.81
+    # a run that printed no line, or the line of another device count, is a failure even with exit code 0
+    assert nr.summarise(dict(name="dist_n2", kind="bench", n=2, cmd=["x"], env={}), 0, "no json here", "", 1.0, pred)["rc"] == 1
+    assert nr.summarise(dict(name="dist_n2", kind="bench", n=2, cmd=["x"], env={}), 0, json.dumps(line8), "", 1.0, pred)["rc"] == 1
+
+
+def test_first_node_run_continues_past_failures_and_exits_nonzero(tmp_path):
+    """On this CPU box every GPU step fails (no device): the script must still run all of them, write one record per step
+    and a summary, and exit 1.  (The C example is built by the script itself -- that step succeeds.)"""
+    out = tmp_path / "node_run.jsonl"
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "first_node_run.sh"), "--standin", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--only", "c_example,bit_identity", "--out", str(out), "--timeout", "120"], capture_output=True, text=True, timeout=600)
+    recs = [json.loads(l) for l in open(out)]
+    if _gpu_visible():
+        pytest.skip("a GPU is visible: the steps succeed here (tests/test_gpu_rccl.py runs the stand-in plan on it)")
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert [x["step"] for x in recs] == ["build_render_frame", "c_example_n1", "c_example_n2", "bit_identity_n2_copy", "summary"]
+    assert recs[0]["rc"] == 0 and all(x["rc"] != 0 for x in recs[1:4])
+    assert recs[-1]["failed"] == ["c_example_n1", "c_example_n2", "bit_identity_n2_copy"] and recs[-1]["rc"] == 1
+    assert "no HIP device" in recs[1]["stderr_tail"]
