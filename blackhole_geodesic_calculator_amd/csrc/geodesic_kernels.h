@@ -121,8 +121,8 @@ hipError_t trace_occupancy(int method, int rhs, int evt, int *blocks_per_cu);
 bool needs_prepare_ws(int rhs);
 // Kerr: after the last pass of a call, Boyer-Lindquist end states -> Cartesian
 hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t s);
-// the Kerr instantiations live in their own translation unit (geodesic_kernels_kerr.hip: same source, built with
-// machine LICM on, which suits the big Kerr kernels; the Schwarzschild unit is built with it off)
+// the Kerr instantiations live in their own translation unit (geodesic_kernels_kerr.hip: same source, same flags --
+// machine LICM off, see the Makefile -- compiled on its own)
 hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu);
 hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);

@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgeodesic_oracle.so")
+# BHG_ORACLE_LIB: another build of the same source, e.g. the sanitizer build (`make -C oracle asan`)
+_LIB_PATH = os.environ.get("BHG_ORACLE_LIB") or os.path.join(_HERE, "libgeodesic_oracle.so")
 
 FLAG_HIT_HORIZON = 1
 FLAG_START_INSIDE = 2
@@ -73,6 +74,8 @@ def make_params(r_s=1.0, lambda_end=50.0, max_step=np.inf, rtol=1e-3, atol=1e-6,
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("geodesic_oracle.c", "kerr_rhs.inc")]
+    if os.environ.get("BHG_ORACLE_LIB"):
+        return _LIB_PATH          # (a build of the caller's own making)
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH

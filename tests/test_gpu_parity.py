@@ -829,8 +829,7 @@ def full_frame(ctx):
 def test_full_frame_every_ray_matches_oracle(full_frame, oracle):
     """EVERY ray of the headline frame (1024 x 1024 x 5 = 5,242,880) against the oracle -- not a strided subsample (the
     oracle takes about a second for the frame on the box's cores): flags, attempted and accepted step counts identical
-    ray for ray; end states within the stated per-class bound (STATED), and for the rays beyond it within
-    bound + COND x the ray's own measured sensitivity to a 1-ulp change of its direction."""
+    ray for ray; end states of the escaping rays within the stated bound (STATED: 1e-8), horizon rays by quantiles."""
     k0, end, flags, steps, acc = full_frame
     o = oracle.trace(k0, CAM, r_s=1.0, lambda_end=50.0)
     nf, ns, na = int((flags != o["flags"]).sum()), int((steps != o["n_attempted"]).sum()), int((acc != o["n_accepted"]).sum())
@@ -838,19 +837,12 @@ def test_full_frame_every_ray_matches_oracle(full_frame, oracle):
     assert np.all(flags != 0) and np.all((flags & ~np.uint8(5)) == 0)  # every ray ended: horizon or lambda_end
     d = np.abs(end - o["end"]).max(1)
     assert np.median(d) <= 1e-11
-    total_over = 0
-    for cls in ("escaped", "horizon"):
-        m = CLASS_OF[cls](flags)
-        bound = STATED[cls][0]
-        over = np.nonzero(m & ~(d <= bound))[0]
-        total_over += len(over)
-        if len(over):
-            S = _sensitivity(oracle, k0[over], CAM, o["end"][over], r_s=1.0, lambda_end=50.0)
-            lim = bound + COND * np.nan_to_num(S, nan=np.inf, posinf=np.inf)
-            assert np.all(d[over] <= lim), (cls, len(over), float(d[over].max()), float((d[over] / lim).max()))
-        print(f"config 2, every ray: {cls}: {int(m.sum())} rays, worst |gpu - oracle| {d[m].max():.3g}, {len(over)} beyond the stated {bound:g}")
-    # (measured: see DESIGN.md section 2 -- a handful of rays next to the photon sphere out of 5.24 M)
-    assert total_over <= 2000, total_over
+    # escaped rays: the stated bound or the ray's own sensitivity (measured, round 5: worst 3.7e-9 of 5,000,441 -- not one ray
+    # beyond the stated 1e-8); horizon rays (242,439): quantiles, see _horizon_class_ok
+    from test_gpu_fullsize import _within_stated_or_sensitivity
+    _within_stated_or_sensitivity(oracle, k0, None, flags, d, o["end"], dict(r_s=1.0, lambda_end=50.0), "config 2, every ray")
+    esc = CLASS_OF["escaped"](flags)
+    assert d[esc].max() <= STATED["escaped"][0]
 
 
 def test_full_frame_order_independence(ctx, full_frame):

@@ -365,3 +365,49 @@ def test_first_node_run_continues_past_failures_and_exits_nonzero(tmp_path):
     assert recs[0]["rc"] == 0 and all(x["rc"] != 0 for x in recs[1:4])
     assert recs[-1]["failed"] == ["c_example_n1", "c_example_n2", "bit_identity_n2_copy"] and recs[-1]["rc"] == 1
     assert "no HIP device" in recs[1]["stderr_tail"]
+
+
+# ---- host logic under sanitizers (GPU sanitizers are not available on the pool; the host side is) ----------------------
+def test_tile_dealing_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/tile_dealing.h -- the host logic behind bhg_deal_tiles and bhg_frame_* -- compiled with g++ under
+    -fsanitize=address,undefined and driven over ragged edges, one-pixel tiles, more devices than tiles, tied and extreme
+    costs and every root share (tests/deal_tiles_driver.cpp checks: every pixel dealt exactly once, tiles never split);
+    its shard sizes and checksums must be what the LIBRARY's bhg_deal_tiles (hipcc build, no sanitizer) deals."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    exe = tmp_path / "deal_asan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-fno-omit-frame-pointer", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "deal_tiles_driver.cpp"), "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1"))
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 8 * 5 * 10
+    lib = _ffi.load()
+    checked = 0
+    for line in lines[:: 7]:
+        f = line.split()
+        W, H, T, world, has_cost, visit = (int(v) for v in f[:6])
+        share, want_sum, sizes = float(f[6]), int(f[7]), [int(v) for v in f[8:]]
+        if has_cost:
+            nt = ((W + T - 1) // T) * ((H + T - 1) // T)
+            c1 = np.array([float((t * 7919) % 13) for t in range(nt)])
+            c2 = np.array([1e300 if t % 2 else -1e300 for t in range(nt)])
+            costs = [c1, c2]
+        else:
+            costs = [None]
+        ok = False
+        for cost in costs:      # (the driver's last case per shape uses the extreme costs: try both)
+            got_sizes, h = [], 1469598103934665603
+            for rank in range(world):
+                n = ctypes.c_size_t()
+                cp = None if cost is None else cost.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+                assert lib.bhg_deal_tiles(W, H, T, world, cp, visit, share, rank, None, 0, ctypes.byref(n)) == 0
+                px = np.empty(n.value, np.int64)
+                assert lib.bhg_deal_tiles(W, H, T, world, cp, visit, share, rank, px.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n.value, ctypes.byref(n)) == 0
+                got_sizes.append(int(n.value))
+                for p in px.tolist():
+                    h = ((h ^ ((p * 31 + rank) & 0xFFFFFFFFFFFFFFFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            ok = ok or (got_sizes == sizes and h == want_sum)
+        assert ok, line
+        checked += 1
+    assert checked >= 50

@@ -473,3 +473,36 @@ def test_oracle_kerr_objects_match_scipy_golden(oracle):
     hit = o["flags"] == 0x88
     c = g["spheres"][o["object_id"][hit]]
     assert np.abs(np.linalg.norm(o["end"][hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9
+
+
+def test_oracle_suite_under_sanitizers():
+    """The checker is what every parity claim rests on: its C restatement built with -fsanitize=address,undefined
+    (`make -C oracle asan`) must pass THIS file's tests in a child process with the sanitizer runtimes preloaded (a finding
+    aborts the child).  OpenMP paths, the Brent searches, dense-output sampling and the Kerr right-hand side all run."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("BHG_ORACLE_LIB"):
+        pytest.skip("already the child run")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "asan"])
+    lib = os.path.join(root, "oracle", "libgeodesic_oracle_asan.so")
+    rts = []
+    for name in ("libasan.so", "libubsan.so"):
+        p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+        if not os.path.isabs(p) or not os.path.exists(p):
+            pytest.skip(f"{name} not found next to gcc")
+        rts.append(p)
+    env = dict(os.environ, BHG_ORACLE_LIB=lib, LD_PRELOAD=" ".join(rts), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    # the child really runs the sanitizer build ...
+    probe = ("import sys; sys.path.insert(0, %r); from oracle import oracle as oc; import numpy as np; "
+             "oc.trace(np.array([[0.05, 0.02, -1.0]]), np.array([1e-4, 0.0, 30.0])); m = open('/proc/self/maps').read(); "
+             "assert 'libgeodesic_oracle_asan.so' in m and 'libasan' in m and 'libgeodesic_oracle.so' not in m") % root
+    subprocess.check_call([sys.executable, "-c", probe], env=env)
+    # ... and this file's tests pass against it
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
