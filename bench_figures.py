@@ -40,7 +40,7 @@ def live_pmc(a, deadline_s=300.0):
     for flag, val in (("--width", a.width), ("--height", a.height), ("--samples", a.samples)):
         if val is not None:
             child += [flag, str(val)]
-    if a.dir_only:
+    if getattr(a, "dir_only", False):
         child.append("--dir-only")
     out, child_steps = {}, None
     t_end = time.monotonic() + deadline_s

@@ -134,7 +134,12 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and "row-major" in line["config"]["tile_order"]
     assert line["roofline"]["frac"] > 0 and line["roofline"]["kernel_ms"] < line["ms_per_step"]
-    assert line["full_records"]["value"] > 0 and line["full_records"]["algorithmic_bytes_per_ray"] == 81
+    # the headline writes whole end states (x and k, what spacetime_ray_cast returns); the sky frame's direction-only form beside it
+    assert "full_records" in line["config"]["north_star_output"] and line["roofline"]["algorithmic_bytes_per_ray"] == 81
+    assert line["sky_frame_dir_only"]["value"] > 0 and line["sky_frame_dir_only"]["algorithmic_bytes_per_ray"] == 57
+    cal = line["roofline"]["calibration"]
+    assert 30.0 < cal["fp64_fma_tflops_measured"] < 90.0 and 0.0 < line["roofline"]["frac_of_measured_peak"] < 1.0
+    assert cal["issue_bound_wave_insts_per_s"] > 1e11
     sh = line["strong_predicted"]["shards"]["2"]
     assert sh["rays"] * 2 == 256 * 256 * 2 and 0.2 < sh["efficiency"] < 1.5 and sh["ms_per_step_two_in_flight"] > 0
     # rank 0's step: the shard's slab through a 1-rank gather + the root's assembly of the whole 2-rank frame
