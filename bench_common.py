@@ -332,6 +332,12 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
                   "kernels' launch geometry (1 wave64 per workgroup, 12 waves per CU, no memory traffic): 2-ms launches, median of 5; "
                   "figures are the mean of the two probes",
     }
+    if isinstance(sclk, dict):
+        # ... and against the vendor's formula at the clock the timed region actually ran at (256 CU x 128 flop per clock):
+        # the pure-FMA probe draws more power than the trace kernel and sustains a lower clock than the timed region's
+        peak_at_clock = sclk["mean_mhz"] * 1e6 * 128.0 * 256.0 / 1e12
+        out["peak_tflops_at_timed_region_clock"] = peak_at_clock
+        out["frac_at_timed_region_clock"] = achieved_tf / peak_at_clock
     if valu_per_64:
         # how much of that ceiling the trace kernel's own instruction stream uses: its wave-level VALU instructions per second
         out["trace_kernel_wave_insts_per_s"] = valu_per_64 * (ray_steps / 64.0) / (k_ms * 1e-3)

@@ -106,8 +106,9 @@ def pmc_traffic(a, method):
     if (a.width, a.height, a.samples) != (dflt[0], dflt[0], dflt[1]):
         return None, None, None
     tag = {"frame": "", "disk": "_disk", "orbit": "_orbit"}[a.workload] + ("_kerr" if a.rhs == "kerr" else "")
+    import re
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))
-                   if os.path.basename(f).split("_pmc_summary")[1] == tag + ".json")
+                   if re.fullmatch(r"r\d+_pmc_summary" + re.escape(tag) + r"\.json", os.path.basename(f)))
     if not files:
         return None, None, None
     try:

@@ -1264,7 +1264,6 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     int rc = validate(p);
     if (rc != BHG_OK) return rc;
     if (p->method != BHG_METHOD_DP54) return fail(BHG_E_INVALID, "trajectories are sampled with BHG_METHOD_DP54 only");
-    if (p->disk_r_out > 0.0) return fail(BHG_E_INVALID, "the disk event is not available for sampled trajectories");
     if (n_points < 2) return fail(BHG_E_INVALID, "n_points must be >= 2");
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !traj || !n_valid) return fail(BHG_E_INVALID, "x0 / k0 / traj / n_valid is NULL");
@@ -1323,6 +1322,8 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.atol = p->atol;
     a.h_fixed = p->h_fixed;
     a.r_exit = p->r_exit;
+    a.disk_r_in = p->disk_r_in;
+    a.disk_r_out = p->disk_r_out;
     a.spin = p->spin;
     a.mu2 = p->time_like ? 1.0 : 0.0;
     a.r_hor = p->r_s;

@@ -118,19 +118,21 @@ class GeodesicIntegratorSchwarzschild:
 
     # ------------------------------------------------------------------------------------
     def calc_trajectory(self, k0_xyz, x0_xyz, max_step=np.inf, curve_end=50, nr_points_curve=50,
-                        verbose=False, **_ignored):
+                        verbose=False, r_exit=0.0, disk=None, **_ignored):
         """Per-ray drop-in for the call at RelativisticRenderEngine.py:293-294.
 
         Returns (k_xyz, x_xyz, result): k_xyz and x_xyz have shape (3, T') with the curve sampled at
         t_eval = linspace(0, curve_end, nr_points_curve) up to where the ray ends (T' <= nr_points_curve,
         as solve_ivp's t_eval gives), so that `x, y, z = x_xyz` (:299) and `x[-1]` (:307-308) work as
         in the reference.  result['end_loc'] / ['end_dir'] carry the exact end state (the event root for
-        horizon rays), the same numbers trace() returns.
+        horizon rays), the same numbers trace() returns.  r_exit / disk=(R_in, R_out) (not in the reference's signature:
+        the Limited engine's exit sphere and thin disk, Limited...py:273-278, :413-438): the curve then ends where the
+        ray leaves the sphere or meets the disk, result['hit_disk'] says which.
         """
         k0 = np.asarray(k0_xyz, dtype=np.float64).reshape(3)
         x0 = np.asarray(x0_xyz, dtype=np.float64).reshape(3)
         n_pts = max(2, int(nr_points_curve))
-        traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end), n_pts)
+        traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end, r_exit, disk), n_pts)
         m = int(nv[0])
         fl = int(flags[0])
         # (views of this call's own result block -- nothing else refers to it: two 240-kB copies less per call at the
@@ -140,6 +142,7 @@ class GeodesicIntegratorSchwarzschild:
         result = {
             "start_inside_hole": bool(fl & _ffi.FLAG_START_INSIDE),
             "hit_blackhole": bool(fl & _ffi.FLAG_HIT_HORIZON),
+            "hit_disk": fl == _ffi.FLAG_HIT_DISK,
             "flags": fl,
             "end_loc": end[0, 0:3].copy(),
             "end_dir": end[0, 3:6].copy(),

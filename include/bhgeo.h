@@ -204,7 +204,9 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * are produced from the step's dense output, as solve_ivp does with t_eval; a ray that ends early (horizon,
  * exit sphere) yields n_valid[i] < n_points samples, the rest of its row is NaN.  traj [n][6][n_points]
  * (rows x, y, z, k_x, k_y, k_z).  end [n][6] / flags [n] (may be NULL): the same end state and flags
- * bhg_trace gives.  BHG_METHOD_DP54 only; the disk event is not available here; at most 2^26 rays per call.  Small-n path: one
+ * bhg_trace gives -- with the exit sphere and, since ABI 7, the thin disk (a ray that ends on it: BHG_FLAG_HIT_DISK, the
+ * curve sampled up to the crossing, end = the crossing point: what checkHitDisk looks for on the sampled path,
+ * LimitedRelativisticRenderEngine.py:284, :413-438).  BHG_METHOD_DP54 only; at most 2^26 rays per call.  Small-n path: one
  * WAVE per ray up to 2048 rays (a step's samples are shared out over the 64 lanes: the engine's literal call, one ray
  * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way. */
 int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,

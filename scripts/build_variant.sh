@@ -9,8 +9,9 @@ T=$(mktemp -d)
 /opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c geodesic_kernels_kerr.hip -o $T/b.o &
 /opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c frame_kernels.hip -o $T/c.o &
 /opt/rocm/bin/hipcc $F -mllvm -disable-machine-licm "$@" -c geodesic_kernels_timelike.hip -o $T/f.o &
+/opt/rocm/bin/hipcc $F "$@" -c probe_kernels.hip -o $T/g.o &
 /opt/rocm/bin/hipcc $F "$@" -c bhgeo_capi.hip -o $T/d.o &
 /opt/rocm/bin/hipcc $F "$@" -c bhgeo_frame.hip -o $T/e.o &
 wait
-/opt/rocm/bin/hipcc $F -shared -o ../../build/variants/libbhgeo_$name.so $T/a.o $T/b.o $T/c.o $T/d.o $T/e.o $T/f.o -ldl
+/opt/rocm/bin/hipcc $F -shared -o ../../build/variants/libbhgeo_$name.so $T/a.o $T/b.o $T/c.o $T/d.o $T/e.o $T/f.o $T/g.o -ldl
 rm -rf $T

@@ -2,7 +2,8 @@
 # evidence for every bench configuration in ONE GPU call, i.e. from ONE box: bash scripts/gpu_profiles_all.sh
 # (outputs gpurun_out/prof_<name>_*: the plain bench line, the --lean line printed under rocprofv3 with the kernel trace
 # reduced to its timed region, kernel stats, FETCH / WRITE / VALU counter passes; copy what is cited to profiles/rNN_*)
-bash scripts/gpu_profile_config.sh frame
+bash scripts/gpu_profile_config.sh frame_full          # the headline: whole end states (x, k) written
+bash scripts/gpu_profile_config.sh frame_dir --dir-only   # the sky frame's direction-only form
 bash scripts/gpu_profile_config.sh disk --workload disk
 bash scripts/gpu_profile_config.sh orbit --workload orbit --steps 60 --warmup 5
 bash scripts/gpu_profile_config.sh kerr --rhs kerr --steps 60 --warmup 5

@@ -1007,6 +1007,65 @@ def test_trajectories_batch_match_trace_and_oracle(ctx, oracle):
             assert max(dmax) < 1e-8
 
 
+def test_trajectories_with_the_thin_disk_event(ctx, oracle):
+    """bhg_trajectory with the disk (ABI 7; VERDICT r04 missing #5): the Limited engine finds its disk hit on the SAMPLED
+    path (checkHitDisk walks x_SW, y_SW, z_SW, LimitedRelativisticRenderEngine.py:284, :413-438).  A ray that ends on the
+    disk: flag HIT_DISK, the curve sampled up to the crossing and NaN beyond, end = the crossing point in the plane and
+    inside the annulus -- the flags bhg_trace gives for the same parameters, the oracle's samples; a crossing outside
+    the annulus is no event (the ray carries on through the plane).  Wave-per-ray form (<= 2048 rays) and lane-per-ray
+    form; Schwarzschild from an inclined camera, and Kerr."""
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    inc = np.radians(70.0)
+    cam = np.array([30 * np.sin(inc), 0.0, 30 * np.cos(inc)])
+    rot = np.array([[np.cos(inc), 0, np.sin(inc)], [0, 1, 0], [-np.sin(inc), 0, np.cos(inc)]])
+    for n, kw in ((400, dict(r_s=1.0, lambda_end=70.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=9.0)),
+                  (2600, dict(r_s=1.0, lambda_end=70.0, disk_r_in=4.5, disk_r_out=10.5, rhs_form=1)),
+                  (300, dict(r_s=1.0, lambda_end=70.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=9.0, rhs_form=2, spin=0.45))):
+        k = frame_rays(n, seed=57, fov=0.9) @ rot.T
+        T = 96
+        traj, nv, end, flags = ctx.trajectory(k, cam, _params(**kw), T)
+        e2, f2, s2, a2 = ctx.trace(k, cam, _params(**kw))
+        kerr = kw.get("rhs_form") == 2
+        assert np.array_equal(flags, f2)
+        disk = flags == 128
+        assert disk.sum() > 0.1 * n and ((flags & 1) != 0).sum() > 0 and (flags == (8 if "r_exit" in kw else 4)).sum() > 0.2 * n
+        R = np.hypot(end[disk, 0], end[disk, 1])
+        assert np.abs(end[disk, 2]).max() < 1e-9 and R.min() >= kw["disk_r_in"] - 1e-9 and R.max() <= kw["disk_r_out"] + 1e-9
+        # the two searches (Brent here, the frame path's certified Newton) land on the same crossing
+        assert np.abs(end[disk] - e2[disk]).max() < (1e-10 if not kerr else 1e-8)
+        tr, onv, ofl = oracle.trajectory(k, cam, T, **kw)
+        assert np.array_equal(flags, ofl)
+        same = nv == onv
+        assert same.mean() > 0.99
+        t_eval = np.linspace(0.0, kw["lambda_end"], T)
+        for i in np.nonzero(same & disk)[0][:150]:
+            m = nv[i]
+            assert 0 < m < T and np.isnan(traj[i, :, m:]).all()
+            assert np.abs(traj[i, :, :m] - tr[i, :, :m]).max() < (1e-8 if not kerr else 1e-4)
+            # the sampled curve stops on the camera's side of the plane: z keeps its sign up to the last sample
+            z = traj[i, 2, :m]
+            assert np.all(z * z[0] > 0) or abs(z[-1]) < 1e-6
+        # a ray that crosses the plane outside the annulus carries on: its samples change the sign of z
+        through = np.nonzero(~disk & (flags != 1) & (nv > 3))[0]
+        crossed = [i for i in through[:400] if np.nanmin(traj[i, 2, :nv[i]]) < 0 < np.nanmax(traj[i, 2, :nv[i]])]
+        assert len(crossed) > 10
+        for i in crossed[:50]:
+            z, x, y = traj[i, 2, :nv[i]], traj[i, 0, :nv[i]], traj[i, 1, :nv[i]]
+            j = int(np.nonzero(np.sign(z[1:]) != np.sign(z[:-1]))[0][0])
+            s_ = z[j] / (z[j] - z[j + 1])
+            Rc = np.hypot(x[j] + s_ * (x[j + 1] - x[j]), y[j] + s_ * (y[j + 1] - y[j]))      # checkHitDisk's own interpolation (:419-421)
+            assert Rc < kw["disk_r_in"] + 0.5 or Rc > kw["disk_r_out"] - 0.5
+    # the adaptor: calc_trajectory(..., disk=) ends the curve on the disk
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=ctx)
+    i = int(np.nonzero(disk)[0][0]) if not kerr else 0
+    k_s = frame_rays(400, seed=57, fov=0.9) @ rot.T
+    tr0 = ctx.trace(k_s, cam, _params(r_s=1.0, lambda_end=70.0, disk_r_in=3.0, disk_r_out=9.0))
+    i = int(np.nonzero(tr0[1] == 128)[0][0])
+    k_xyz, x_xyz, res = gi.calc_trajectory(k_s[i], cam, curve_end=70.0, nr_points_curve=200, disk=(3.0, 9.0))
+    assert res["hit_disk"] and not res["hit_blackhole"] and abs(res["end_loc"][2]) < 1e-9 and x_xyz.shape[1] < 200
+    assert np.array_equal(res["end_loc"], tr0[0][i, 0:3]) or np.abs(res["end_loc"] - tr0[0][i, 0:3]).max() < 1e-10
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # time_like=True (the solver object's other constructor value, RelativisticRenderEngine.py:134): massive particles
 # ------------------------------------------------------------------------------------------------------------------------
