@@ -227,6 +227,43 @@ def test_frame_argument_checks(ctx):
     fr.close()
 
 
+def test_stats_and_rebalance_between_a_redeal_and_the_next_render_are_refused(ctx):
+    """after a re-deal the shards' pixel lists are new while the devices' steps / flags arrays still hold
+    the PREVIOUS lists' rays (and may be smaller than the new shards, root_share < 1 grows the others) -- a second
+    bhg_frame_stats / bhg_frame_rebalance before the next render read out of bounds and binned old steps by new pixels.  Both
+    now return BHG_E_INVALID until the frame has been rendered again; a rotating camera regenerates its rays from the
+    shard's RESIDENT draws of the jitter stream (no host-side gather, no upload) and gives the image a new frame gives."""
+    from blackhole_geodesic_calculator_amd import _ffi
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    from blackhole_geodesic_calculator_amd.raygen import euler_xyz_matrix
+    W, H, S = 160, 96, 2
+    sky = synthetic_sky(64, 32)
+    p = _params(r_s=1.0, lambda_end=50.0)
+    fr = _frame([0, 0, 0], W, H, S)
+    fr.set_scene(sky)
+    a = fr.render(p)
+    st = fr.stats()
+    fr.rebalance(root_share=0.5)              # the first device's shard shrinks, the others' grow
+    for call in (fr.stats, fr.rebalance):
+        with pytest.raises(_ffi.BhgError) as ei:
+            call()
+        assert ei.value.code == _ffi.E_INVALID and "render" in str(ei.value)
+    b = fr.render(p)
+    st2 = fr.stats()
+    assert np.array_equal(a, b) and all(st2[k] == st[k] for k in ("rays", "attempted_steps", "accepted_steps", "horizon_rays") if k in st)
+    fr.rebalance()                            # fine again after a render
+    assert np.array_equal(fr.render(p), a)
+    # a camera that turns: rays regenerated on the devices from the kept draws == a frame created at that camera
+    rot = euler_xyz_matrix((0.03, -0.02, 0.2))
+    fr.set_camera(fov_x=0.6, fov_y=0.6, origin=(1e-4, 0.0, 30.0), rot=rot)
+    turned = fr.render(p)
+    fr.close()
+    f2 = _frame([0], W, H, S, euler=(0.03, -0.02, 0.2))
+    f2.set_scene(sky)
+    assert np.array_equal(f2.render(p), turned) and not np.array_equal(turned, a)
+    f2.close()
+
+
 def test_frame_profiling_reports_per_device_trace_times(ctx):
     from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
     fr = _frame([0, 0], 256, 256, 2)

@@ -808,8 +808,17 @@ def test_nonfinite_input_is_flagged_not_hung(ctx):
 
 
 def test_invalid_arguments_are_rejected(ctx):
+    import ctypes as C
     from blackhole_geodesic_calculator_amd import _ffi
     k = frame_rays(4, seed=1)
+    # bhg_trajectory is ONE launch: more rays than a launch takes (2^26: the kernels form result offsets in 32 bits) are
+    # refused before anything is read -- the arrays handed over here are four rays long
+    nv = np.zeros(4, np.uint32)
+    tr = np.zeros((4, 6, 2))
+    dp = C.POINTER(C.c_double)
+    rc = _ffi.load().bhg_trajectory(ctx._h, C.byref(_params()), CAM.ctypes.data_as(dp), 1, k.ctypes.data_as(dp), (1 << 26) + 1, 2,
+                                    tr.ctypes.data_as(dp), nv.ctypes.data_as(C.POINTER(C.c_uint32)), None, None)
+    assert rc == _ffi.E_INVALID and "2^26" in _ffi.load().bhg_last_error().decode()
     for bad in (dict(r_s=-1.0), dict(rtol=0.0), dict(lambda_end=float("nan")), dict(method=7), dict(rhs_form=5),
                 dict(max_step=0.0), dict(method=1, h_fixed=0.0)):
         with pytest.raises(_ffi.BhgError) as ei:
