@@ -344,7 +344,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
     calibrate = not overlap and not whole_frames and not a.lean
     calibration, sampler = {}, None
     if calibrate:
-        calibration["before"] = run_probes(rt.ctx)
+        calibration["before"] = run_probes(rt.ctx, rt.local_rank)
         barrier()
         sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
@@ -354,7 +354,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
     dt = time.perf_counter() - t0
     sclk = sampler.stop() if sampler is not None else None
     if calibrate:
-        calibration["after"] = run_probes(rt.ctx)
+        calibration["after"] = run_probes(rt.ctx, rt.local_rank)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -106,6 +106,8 @@ def pmc_traffic(a, method):
     if (a.width, a.height, a.samples) != (dflt[0], dflt[0], dflt[1]):
         return None, None, None
     tag = {"frame": "", "disk": "_disk", "orbit": "_orbit"}[a.workload] + ("_kerr" if a.rhs == "kerr" else "")
+    if a.workload == "frame" and a.rhs != "kerr" and getattr(a, "dir_only", False):
+        tag = "_dir"       # (the sky frame's direction-only trace writes 24 B/ray less than the full-record headline)
     import re
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary*.json"))
                    if re.fullmatch(r"r\d+_pmc_summary" + re.escape(tag) + r"\.json", os.path.basename(f)))
