@@ -336,16 +336,19 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
             if float(go.item()) == 0.0:
                 break
         barrier()
-    for i in range(a.warmup):
-        step(i, False)
-    barrier()
-    # roofline calibration (bhg_peak_probe: the fp64 rate THIS box sustains), right before and right after the timed
-    # region -- the headline's region only, outside its clock -- and the shader clock sampled from sysfs while it runs
+    # roofline calibration (bhg_peak_probe: the fp64 rate THIS box sustains) before and after the headline's timed region --
+    # outside its clock; the probes in front run before the warm-up steps (right before the timed region, before the
+    # warm-up, or only afterwards: the headline measures the same to 0.2 %, profiles/r05_probe_when_ab.log)
     calibrate = not overlap and not whole_frames and not a.lean
     calibration, sampler = {}, None
     if calibrate:
         calibration["before"] = run_probes(rt.ctx, rt.local_rank)
         barrier()
+    for i in range(a.warmup):
+        step(i, False)
+    barrier()
+    if calibrate:
+        # ... and the shader clock, sampled from sysfs while the region runs (measured: no effect on the region's time)
         sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
     for i in range(a.steps):

@@ -272,6 +272,8 @@ class ClockSampler:
             return None
 
     def start(self):
+        if os.environ.get("BHGEO_NO_CLOCK_SAMPLER") == "1":
+            self.path = None
         if self.path is None or self._read() is None:
             self.path = None
             return self
@@ -299,21 +301,15 @@ class ClockSampler:
 
 
 def run_probes(ctx, device_index=0):
-    """bhg_peak_probe, both kinds (2-ms launches, median of five each): what THIS box's fp64 pipe delivers -- with the
-    shader clock sampled from sysfs while each probe runs (the pure-FMA probe draws more power than the trace kernels and
-    clocks lower: rates are comparable only per clock)."""
+    """bhg_peak_probe, both kinds (2-ms launches, median of five each): what THIS box's fp64 pipe delivers.  (Sampling the
+    sysfs clock WHILE a probe runs was tried and dropped: reads every 0.5 ms slow the first probe by 11 %,
+    profiles/r05_sampler_ab.log; the 4-ms sampling of the timed region measures neutral.)"""
     from blackhole_geodesic_calculator_amd import _ffi
-    out = {}
-    for key, kind in (("fma", _ffi.PROBE_FMA), ("mix", _ffi.PROBE_STEP_MIX)):
-        smp = ClockSampler(device_index, period_s=0.0005).start()
-        r = ctx.peak_probe(kind, 2.0)
-        clk = smp.stop()
-        out[key] = dict(tflops=r["tflops"], wave_insts_per_s=r["valu_wave_insts"] / (r["ms"] * 1e-3), implied_clock_mhz=r["fp64_full_rate_clock_mhz"],
-                        sclk_mhz=None if clk is None else clk["mean_mhz"])
-    return {"fp64_fma_tflops": out["fma"]["tflops"], "fp64_fma_clock_mhz": out["fma"]["implied_clock_mhz"],
-            "fma_wave_insts_per_s": out["fma"]["wave_insts_per_s"], "fma_sclk_mhz": out["fma"]["sclk_mhz"],
-            "step_mix_tflops": out["mix"]["tflops"], "step_mix_wave_insts_per_s": out["mix"]["wave_insts_per_s"],
-            "mix_sclk_mhz": out["mix"]["sclk_mhz"]}
+    fma = ctx.peak_probe(_ffi.PROBE_FMA, 2.0)
+    mix = ctx.peak_probe(_ffi.PROBE_STEP_MIX, 2.0)
+    return {"fp64_fma_tflops": fma["tflops"], "fp64_fma_clock_mhz": fma["fp64_full_rate_clock_mhz"],
+            "fma_wave_insts_per_s": fma["valu_wave_insts"] / (fma["ms"] * 1e-3),
+            "step_mix_tflops": mix["tflops"], "step_mix_wave_insts_per_s": mix["valu_wave_insts"] / (mix["ms"] * 1e-3)}
 
 
 def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
@@ -336,7 +332,7 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
         "issue_bound_tflops": 0.5 * (b["step_mix_tflops"] + a_["step_mix_tflops"]),
         "frac_of_measured_peak": achieved_tf / fma,
         "sclk_mhz_timed_region": sclk if sclk is not None else "omitted: no hwmon freq1_input readable for this device on this box",
-        "method": "bhg_peak_probe (include/bhgeo.h) in this process, right before and right after the timed region, in the trace "
+        "method": "bhg_peak_probe (include/bhgeo.h) in this process, before the warm-up steps and right after the timed region, in the trace "
                   "kernels' launch geometry (1 wave64 per workgroup, 12 waves per CU, no memory traffic): 2-ms launches, median of 5; "
                   "figures are the mean of the two probes",
     }
@@ -346,30 +342,19 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
         peak_at_clock = sclk["mean_mhz"] * 1e6 * 128.0 * 256.0 / 1e12
         out["peak_tflops_at_timed_region_clock"] = peak_at_clock
         out["frac_at_timed_region_clock"] = achieved_tf / peak_at_clock
-    n_simd = 1024.0   # 256 CUs x 4 SIMDs; a full-rate wave64 fp64 instruction occupies its SIMD for 4 clocks: 0.25 per clock at best
-
-    def per_clock(rate_key, clk_key):
-        v = [c[rate_key] / (c[clk_key] * 1e6 * n_simd) for c in (b, a_) if c.get(clk_key)]
-        return sum(v) / len(v) if v else None
-    fma_ipc, mix_ipc = per_clock("fma_wave_insts_per_s", "fma_sclk_mhz"), per_clock("step_mix_wave_insts_per_s", "mix_sclk_mhz")
-    if fma_ipc:
-        out["probe_sclk_mhz"] = {"fma": [b.get("fma_sclk_mhz"), a_.get("fma_sclk_mhz")], "step_mix": [b.get("mix_sclk_mhz"), a_.get("mix_sclk_mhz")]}
-        out["fma_probe_wave_insts_per_clock_per_simd"] = fma_ipc            # 0.25 = the full fp64 rate
-        out["step_mix_wave_insts_per_clock_per_simd"] = mix_ipc
     if valu_per_64:
-        # the trace kernel's own instruction stream: wave-level VALU instructions per second, and -- the figure that does not
-        # depend on which clock the box chose for which kernel -- per clock and SIMD against the probes' (0.25 = full rate)
+        # the trace kernel's own instruction stream: wave-level VALU instructions per second, against what the probes issue on
+        # this box.  (Each kernel runs at the clock the box chooses for it -- the pure-FMA probe draws the most power and
+        # clocks lowest -- so a kernel with few stalls can read slightly above 1 against the FMA probe.)
         rate = valu_per_64 * (ray_steps / 64.0) / (k_ms * 1e-3)
+        fma_rate = 0.5 * (b["fma_wave_insts_per_s"] + a_["fma_wave_insts_per_s"])
+        out["fma_probe_wave_insts_per_s"] = fma_rate
         out["trace_kernel_wave_insts_per_s"] = rate
+        out["valu_issue_utilisation"] = rate / fma_rate                    # of a pure v_fma_f64 stream
+        out["valu_issue_utilisation_vs_step_mix"] = rate / mix_rate        # of the DP5(4) Christoffel step loop's own mix
         if isinstance(sclk, dict):
-            ipc = rate / (sclk["mean_mhz"] * 1e6 * n_simd)
-            out["trace_kernel_wave_insts_per_clock_per_simd"] = ipc
-            if fma_ipc:
-                out["valu_issue_utilisation"] = ipc / fma_ipc               # of what a pure-FMA stream issues per clock
-            if mix_ipc:
-                out["valu_issue_utilisation_vs_step_mix"] = ipc / mix_ipc   # of the DP5(4) Christoffel step loop's own mix
-        else:
-            out["valu_issue_utilisation_vs_step_mix_uncorrected_for_clock"] = rate / mix_rate
+            # per clock and SIMD (256 CUs x 4; a full-rate wave64 fp64 instruction occupies its SIMD for 4 clocks: 0.25 at best)
+            out["trace_kernel_wave_insts_per_clock_per_simd"] = rate / (sclk["mean_mhz"] * 1e6 * 1024.0)
     return out
 
 
