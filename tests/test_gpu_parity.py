@@ -26,6 +26,10 @@ from conftest import CAM, GOLDEN_TRACE_SETS, frame_rays, golden_kwargs, load_gol
 pytestmark = pytest.mark.gpu
 
 TOL_END = 1e-9   # absolute floor, values are O(1..50)
+# Largest fraction of a Kerr fuzz draw's rays whose step sequence may differ from the oracle's (all of them "touchy": horizon rays
+# or small L_z).  Measured over 150 draws (round 5, BHG_FUZZ=600, profiles/r05_kerr_fuzz.log): 139 draws with no such ray at all,
+# worst draw 1.07 %, 99th percentile of the draws 0.76 % -- asserted at 2.5 % (was 8 % up to round 4).
+KERR_FUZZ_DIFFER = 0.025
 LAST_COMPARE = {}   # filled by _compare: rays compared, rays further than TOL_END from the oracle, rays beyond the scaled bound
 COND = 500.0     # multiples of the oracle's own 1-ulp input sensitivity S_i (an estimate from three perturbations, not a
                  # bound).  Measured over 240 fuzz draws (round 4, LAST_COMPARE["worst_multiple_of_sensitivity"]): the worst ray
@@ -726,7 +730,7 @@ def test_randomised_objects(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(__import__("os").environ.get("BHG_FUZZ", "48")) // 4)))
-def test_randomised_kerr(ctx, oracle, seed):
+def test_randomised_kerr(ctx, oracle, seed, record_property):
     rng = np.random.default_rng(5000 + seed)
     r_s = float(rng.choice([0.6, 1.0, 2.0]))
     spin = float(rng.uniform(-0.98, 0.98)) * 0.5 * r_s
@@ -766,7 +770,13 @@ def test_randomised_kerr(ctx, oracle, seed):
     from oracle import scipy_reference as sr
     Lz = np.array([sr.kerr_constants(*sr.cart_to_bl(cam, kk, spin), 0.5 * r_s, spin, float(kw.get("time_like", 0)))[1] for kk in k[~same]])
     touchy = ((flags[~same] & (1 | 64)) != 0) | (np.abs(Lz) < 0.3 * r_s)
-    assert (~same).mean() <= 0.08 and touchy.mean() >= 0.9 if len(Lz) else True
+    rec = dict(rays=len(k), differ=int((~same).sum()), differ_fraction=float((~same).mean()), touchy_fraction=float(touchy.mean()) if len(Lz) else 1.0,
+               horizon_fraction=float(((flags & 1) != 0).mean()))
+    print("kerr fuzz", seed, rec)
+    for k_, v_ in rec.items():
+        record_property(k_, v_)
+    # measured over the 12 default draws + a 150-draw sweep (round 5, profiles/r05_kerr_fuzz.log): see KERR_FUZZ_DIFFER
+    assert (~same).mean() <= KERR_FUZZ_DIFFER and touchy.mean() >= 0.9 if len(Lz) else True
     d = np.abs(end - o["end"]).max(1)
     tol = 1e-9 + 1e4 * _sensitivity(oracle, k, cam, o["end"], **kw) + np.where((o["flags"] & 1) != 0, 1e-5, 0.0)
     ok = same & np.isfinite(o["end"]).all(1)
