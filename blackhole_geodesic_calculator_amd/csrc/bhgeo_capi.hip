@@ -226,6 +226,12 @@ struct bhg_context {
     bool ev_post = false;                                     // the last profiled call had a finalize pass
 };
 
+namespace bhg {
+// for bhgeo_frame.hip: a context's worker threads copy a page-locked staging block into the caller's pageable array (a
+// 16.8-MB frame through ONE thread's memcpy is 1.0-1.7 ms -- as long as the frame's trace)
+void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes) { c->pool.copy(dst, src, bytes); }
+}  // namespace bhg
+
 namespace {
 
 int ensure(void **p, size_t *have, size_t need)

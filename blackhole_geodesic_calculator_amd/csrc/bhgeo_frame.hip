@@ -33,6 +33,7 @@
 
 namespace bhg {
 int set_error(int code, const std::string &msg);   // bhgeo_capi.hip: the thread-local message of bhg_last_error()
+void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes);   // bhgeo_capi.hip: multi-threaded memcpy
 }
 
 namespace {
@@ -689,7 +690,7 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
             }
             HIP_TRY(hipMemcpyAsync(f->pin, f->image.p, bytes, hipMemcpyDeviceToHost, root.stream));
             HIP_TRY(hipStreamSynchronize(root.stream));
-            std::memcpy(rgba_host, f->pin, bytes);
+            bhg::host_copy(root.ctx, rgba_host, f->pin, bytes);    // (the root context's worker threads: not one core's memcpy)
         }
         // (the other devices' streams have been waited for through the gather; a frame of ONE device has one stream)
     }
