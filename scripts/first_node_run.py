@@ -12,6 +12,7 @@ line to gpurun_out/node_run.jsonl, and a failure does not stop the steps after i
   (ii)  python bench.py --single-process --gpus N     N = 2, 4, 8 with --frame-gather rccl | copy | peer (N = 1: auto)
   (iii) examples/render_frame.c on devices 0,1,..,N-1 (plain C through the C ABI; compiled here with gcc)
   (iv)  the N-device image against the 1-device image, bit for bit (library-owned frame, every gather mode)
+  (v)   the same through torch.distributed: N ranks' gathered frame (disk + objects + exit sphere) == the one-rank frame
 
 Usage:  python scripts/first_node_run.py [--gpus 8] [--steps 100] [--warmup 10] [--out gpurun_out/node_run.jsonl]
         --standin   the same plan on a ONE-GPU box: torch.distributed ranks over gloo sharing the GPU
@@ -92,6 +93,13 @@ def plan(a):
             devs = [0] * n if a.standin else list(range(n))
             steps.append(dict(name=f"bit_identity_n{n}_{mode}", kind="bit_identity", n=n, gather=mode,
                               cmd=[py, "-c", BIT_IDENTITY.format(root=ROOT, devs=devs, mode=mode)], env={}))
+    # (v) the torch.distributed form of the same question: N ranks (one GPU each, RCCL) gather a frame with disk, objects and
+    # exit sphere that must equal the one-rank frame bit for bit (scripts/dist_bit_identity_worker.py)
+    for n in Ns[1:]:
+        env = {} if a.standin else {"BHG_DISTINCT": "1"}
+        steps.append(dict(name=f"dist_bit_identity_n{n}", kind="dist_bit_identity", n=n, env=env,
+                          cmd=[py, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                               "--master-port", str(29600 + n), os.path.join(ROOT, "scripts", "dist_bit_identity_worker.py")]))
     return steps
 
 
@@ -148,6 +156,14 @@ def summarise(step, rc, out, err, seconds, predicted):
         head = (out or "").split("\n", 1)[0]
         rec["head"] = head[:300]
         rec["signature"] = head.split(":", 1)[1].strip() if ":" in head else None
+    elif step["kind"] == "dist_bit_identity":
+        ok = "MULTIRANK_OK" in (out or "")
+        rec["bit_identical"] = ok
+        line = next((l for l in (out or "").splitlines() if "MULTIRANK_OK" in l), "")
+        rec["detail"] = line[:300]
+        rec["rccl_ranks_seen"] = step["n"] if "'backend': 'nccl'" in line else 0
+        if not ok and rc == 0:
+            rec["rc"], rec["error"] = 1, "the worker did not report MULTIRANK_OK"
     elif step["kind"] == "bit_identity":
         if j is not None:
             rec.update(j)
