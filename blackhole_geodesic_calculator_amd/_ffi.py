@@ -713,7 +713,10 @@ class Context:
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         n = k0.shape[0]
         shared = x0.ndim == 1
-        traj = np.empty((n, 6, int(n_points)), np.float64)
+        # small calls (the engine's literal one ray x 10,000 samples): a page-locked sample array from the context's pool -- the
+        # kernel then writes the samples straight into it (no device-to-host copy, no host-side split; include/bhgeo.h)
+        small = n <= 2048 and n * 6 * int(n_points) * 8 <= (4 << 20)
+        traj = (self.pinned.empty if small else np.empty)((n, 6, int(n_points)), np.float64)
         nv = np.empty(n, np.uint32)
         end = np.empty((n, 6), np.float64)
         flags = np.empty(n, np.uint8)

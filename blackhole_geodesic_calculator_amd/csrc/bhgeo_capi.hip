@@ -1295,6 +1295,21 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     double *d_k0 = one ? nullptr : (double *)c->d_in, *d_x0 = x0_is_shared ? nullptr : (double *)c->d_in + n * 3;
     char *o = (char *)c->d_out;
     hipStream_t s = c->stream;
+    // Zero-copy samples: a small call (the engine's literal one: one ray, 10,000 samples = 480 kB) whose `traj` is
+    // page-locked memory (bhg_host_alloc) has the wave-per-ray kernel write its samples STRAIGHT into the caller's array
+    // over PCIe -- no device-to-host copy of the block, no host-side split: 40 of the call's 98 us.  (The kernel's stores
+    // are 512-byte runs per sample row; the array is complete when the stream has been waited for.)
+    double *d_traj = (double *)o;
+    bool direct = false;
+    if (wave && sz_traj <= (size_t(4) << 20) && is_pinned(traj)) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, traj, 0) == hipSuccess && dp) {
+            d_traj = (double *)dp;
+            direct = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (d_k0) HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (!wave) HIP_TRY(hipMemsetAsync(o, 0xFF, sz_traj, s));  // samples a ray never reaches read back as NaN
@@ -1343,8 +1358,21 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
     HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form,
-                                   (double *)o, (uint32_t *)(o + off_nv), n_points, s));
+                                   d_traj, (uint32_t *)(o + off_nv), n_points, s));
     const size_t total = off_flags + n;
+    if (direct) {
+        // only the small arrays behind the sample block come back by copy: end, n_valid, (steps, accepted,) flags
+        const size_t tail = total - off_end;
+        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, size_t(1) << 20);
+        if (rc != BHG_OK) return rc;
+        const char *h = (const char *)c->pin_out - off_end;
+        HIP_TRY(hipMemcpyAsync(c->pin_out, o + off_end, tail, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        std::memcpy(n_valid, h + off_nv, n * sizeof(uint32_t));
+        if (end) std::memcpy(end, h + off_end, n * 6 * sizeof(double));
+        if (flags) std::memcpy(flags, h + off_flags, n);
+        return BHG_OK;
+    }
     if (total <= (size_t(4) << 20)) {
         // the engine's per-ray call (one ray, 10,000 samples: 480 kB): ONE copy of the whole output block into page-locked
         // memory and a host-side split, instead of four copies into the caller's pageable arrays (each of which the

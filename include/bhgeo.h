@@ -208,7 +208,9 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * curve sampled up to the crossing, end = the crossing point: what checkHitDisk looks for on the sampled path,
  * LimitedRelativisticRenderEngine.py:284, :413-438).  BHG_METHOD_DP54 only; at most 2^26 rays per call.  Small-n path: one
  * WAVE per ray up to 2048 rays (a step's samples are shared out over the 64 lanes: the engine's literal call, one ray
- * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way. */
+ * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way.  A `traj` of at most 4 MB in
+ * PAGE-LOCKED memory (bhg_host_alloc) is written by the wave-per-ray kernel directly, over PCIe: no copy of the sample
+ * block, no host-side split (the Python adaptor allocates it so). */
 int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
                    size_t n, uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags);
 
