@@ -1310,6 +1310,21 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
             (void)hipGetLastError();
         }
     }
+    // ... and then the small arrays behind the sample block -- end state, n_valid, counts, flags: at most 2048 rays --
+    // are written into the context's page-locked block the same way: the call is a launch and a stream wait, no copy
+    char *os = o;     // where the kernel writes those (device address), laid out like the device block from off_end on
+    if (direct) {
+        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, size_t(1) << 20);
+        if (rc != BHG_OK) return rc;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->pin_out, 0) == hipSuccess && dp) {
+            os = (char *)dp - off_end;
+        } else {
+            (void)hipGetLastError();
+            direct = false;
+            d_traj = (double *)o;
+        }
+    }
     if (d_k0) HIP_TRY(hipMemcpyAsync(d_k0, k0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (d_x0) HIP_TRY(hipMemcpyAsync(d_x0, x0, n * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     if (!wave) HIP_TRY(hipMemsetAsync(o, 0xFF, sz_traj, s));  // samples a ray never reaches read back as NaN
@@ -1318,16 +1333,16 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     std::memset(&a, 0, sizeof(a));
     a.k0 = d_k0;
     a.x0 = d_x0;
-    a.end = (double *)(o + off_end);
+    a.end = (double *)(os + off_end);
     a.ws = wave ? nullptr : (double *)c->d_ws;
     if (one) {
         a.k0s[0] = k0[0];
         a.k0s[1] = k0[1];
         a.k0s[2] = k0[2];
     }
-    a.flags = (uint8_t *)(o + off_flags);
-    a.n_steps = (uint32_t *)(o + off_steps);
-    a.n_accepted = (uint32_t *)(o + off_acc);
+    a.flags = (uint8_t *)(os + off_flags);
+    a.n_steps = (uint32_t *)(os + off_steps);
+    a.n_accepted = (uint32_t *)(os + off_acc);
     a.counter = c->counter;        // (the trajectory kernel hands out no batches)
     a.counter_next = nullptr;
     a.n = n;
@@ -1358,15 +1373,11 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
     HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form,
-                                   d_traj, (uint32_t *)(o + off_nv), n_points, s));
+                                   d_traj, (uint32_t *)(os + off_nv), n_points, s));
     const size_t total = off_flags + n;
     if (direct) {
-        // only the small arrays behind the sample block come back by copy: end, n_valid, (steps, accepted,) flags
-        const size_t tail = total - off_end;
-        rc = ensure_pinned(&c->pin_out, &c->pin_out_bytes, size_t(1) << 20);
-        if (rc != BHG_OK) return rc;
         const char *h = (const char *)c->pin_out - off_end;
-        HIP_TRY(hipMemcpyAsync(c->pin_out, o + off_end, tail, hipMemcpyDeviceToHost, s));
+        // (polling hipStreamQuery before the blocking wait was measured: no gain, the runtime already spins)
         HIP_TRY(hipStreamSynchronize(s));
         std::memcpy(n_valid, h + off_nv, n * sizeof(uint32_t));
         if (end) std::memcpy(end, h + off_end, n * 6 * sizeof(double));
