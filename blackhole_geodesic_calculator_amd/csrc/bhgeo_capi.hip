@@ -1206,7 +1206,8 @@ int shade_scene_impl(bhg_context *c, const double *d_end, const uint8_t *d_flags
     if (samples <= 0 || sc->sky_w <= 0 || sc->sky_h <= 0) return fail(BHG_E_INVALID, "samples, sky_w, sky_h must be > 0");
     if (sc->n_spheres < 0 || sc->n_spheres > BHG_MAX_SPHERES || sc->n_lamps < 0 || sc->n_lamps > 4)
         return fail(BHG_E_INVALID, "n_spheres must be in [0, BHG_MAX_SPHERES], n_lamps in [0, 4]");
-    if (sc->n_spheres > 0 && !d_object_id) return fail(BHG_E_INVALID, "object_id is NULL but the scene has spheres");
+    // (an EMPTY shard -- a rank without pixels: fewer tiles than ranks -- has no rays and no arrays: nothing to check them against)
+    if (n_pixels > 0 && sc->n_spheres > 0 && !d_object_id) return fail(BHG_E_INVALID, "object_id is NULL but the scene has spheres");
     if (sc->disk_r_out > 0.0) {
         if (!(sc->disk_r_out > sc->disk_r_in) || !(sc->disk_stddev > 0.0))
             return fail(BHG_E_INVALID, "disk needs r_out > r_in and stddev > 0");

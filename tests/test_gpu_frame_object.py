@@ -208,6 +208,34 @@ def test_peer_store_frame_end_is_bit_identical(ctx):
     assert np.array_equal(imgs[_ffi.GATHER_PEER][1], imgs[_ffi.GATHER_PEER][2]) and not np.array_equal(imgs[_ffi.GATHER_PEER][0], imgs[_ffi.GATHER_PEER][1])
 
 
+def test_more_devices_than_tiles_leaves_empty_shards_and_the_same_image(ctx):
+    """160 x 96 in 32-pixel tiles = 15 tiles over EIGHT contexts: one shard is empty (no pixels, no rays).  Sky, then disk +
+    objects + exit sphere; before and after a re-deal by measured cost: the one-device image, bit for bit."""
+    from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
+    W, H, S = 160, 96, 2
+    sky = synthetic_sky(64, 32)
+    sph, rgb, lamps = [[3.0, 2.0, 9.0, 1.5]], [[1.0, 0.8, 0.6]], [[10.0, 10.0, 30.0, 25.0]]
+    p_sky = _params(r_s=1.0, lambda_end=50.0)
+    p_scn = _params(r_s=1.0, lambda_end=60.0, r_exit=40.0, disk_r_in=3.0, disk_r_out=8.0)
+    imgs = {}
+    for devs in ([0], [0] * 8):
+        fr = _frame(devs, W, H, S)
+        fr.set_scene(sky)
+        a = fr.render(p_sky)
+        fr.set_scene(None, disk=(3.0, 8.0), spheres=sph, sphere_rgb=rgb, lamps=lamps)
+        b = fr.render(p_scn)
+        info = fr.info()
+        if len(devs) > 1:
+            assert info["smallest_shard_pixels"] == 0 and info["n_devices"] == 8
+            fr.rebalance(root_share=0.7)
+            assert np.array_equal(fr.render(p_scn), b)
+        st = fr.stats()
+        assert st["rays"] == W * H * S
+        imgs[len(devs)] = (a, b)
+        fr.close()
+    assert np.array_equal(imgs[1][0], imgs[8][0]) and np.array_equal(imgs[1][1], imgs[8][1])
+
+
 def test_frame_argument_checks(ctx):
     from blackhole_geodesic_calculator_amd import _ffi
     from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
