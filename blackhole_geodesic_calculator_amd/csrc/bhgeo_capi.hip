@@ -975,7 +975,17 @@ int bhg_rays_create(bhg_context *c, const bhg_camera *cam, const double *jitter,
     if (cam->width <= 0 || cam->height <= 0 || cam->samples <= 0) return fail(BHG_E_INVALID, "width, height, samples must be > 0");
     const size_t frame_px = (size_t)cam->width * (size_t)cam->height;
     if (!pixels) n_pixels = frame_px;
-    if (n_pixels == 0) return fail(BHG_E_INVALID, "empty pixel list");
+    if (n_pixels == 0) {
+        // an empty pixel list -- a shard that was dealt no tile (more devices than tiles) -- is a ray set of 0 rays:
+        // bhg_rays_count() = 0, bhg_rays_trace(..., 0, 0, ...) a no-op
+        bhg_rays *r0 = new (std::nothrow) bhg_rays();
+        if (!r0) return fail(BHG_E_NOMEM, "host allocation failed");
+        r0->ctx = c;
+        r0->n = 0;
+        std::memcpy(r0->origin, cam->origin, sizeof(r0->origin));
+        *out = r0;
+        return BHG_OK;
+    }
     if (jitter_is_compact && !jitter) return fail(BHG_E_INVALID, "compact jitter stream is NULL");
     const size_t n = n_pixels * (size_t)cam->samples;
     if (n > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays");

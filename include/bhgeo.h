@@ -172,7 +172,8 @@ int bhg_trace(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is
  *           [samples][height][width][2]; 1: draws for the listed pixels only, [samples][n_pixels][2] in list order
  *           (a mark window: the engine only draws inside it, :219).
  *   pixels: HOST array of flat pixel ids y * width + x, or NULL = every pixel in row-major order.
- * Ray s * n_pixels + p is sample s of pixel p.  The rays belong to ctx and must be destroyed before it. */
+ * Ray s * n_pixels + p is sample s of pixel p.  The rays belong to ctx and must be destroyed before it.  An EMPTY pixel list
+ * (pixels != NULL, n_pixels = 0: a shard that was dealt no tile) gives a ray set of 0 rays. */
 typedef struct bhg_camera {
     int32_t width, height, samples, reserved;
     double fov_x, fov_y;  /* property values fov_x / fov_y of the engine (:504-505) */
