@@ -63,6 +63,36 @@ def test_device_shade_and_mean_match_numpy(ctx, oracle):
     assert np.array_equal((rgba[:, :3] == 0.0).all(1), all_hit)
 
 
+@pytest.mark.parametrize("W,H,S", [(37, 23, 1), (50, 31, 7), (9, 5, 300), (64, 3, 256), (3, 64, 257)])
+def test_shade_and_mean_on_odd_frame_shapes_and_sample_counts(ctx, W, H, S):
+    """Frame shapes that are multiples of nothing, one sample, a sample count that does not divide the shade kernel's 256-thread
+    block, exactly 256 samples per pixel, and MORE than 256 (the kernel's serial fallback): rays, trace, shade + sample mean
+    against the numpy restatement, in all three output forms (fp64, float32, float32 scattered by pixel id) and from
+    directions alone."""
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, synthetic_sky
+    from oracle import shade_reference as sh
+    sky = synthetic_sky(128, 64)
+    p = _params(r_s=1.0, lambda_end=50.0)
+    fr = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM)
+    fr.set_sky(sky)
+    rgba = fr.render(p).cpu().numpy()
+    end, flags = fr.d_end.cpu().numpy(), fr.d_flags.cpu().numpy()
+    want = sh.shade_reduce(end, flags, W * H, S, sky)
+    assert rgba.shape == (W * H, 4) and np.abs(rgba - want).max() < 1e-12
+    f32 = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+    fr.shade_f32(f32)
+    assert np.abs(f32.cpu().numpy() - want).max() < 1e-6
+    perm = torch.randperm(W * H, device="cuda")
+    sc = torch.zeros((W * H, 4), dtype=torch.float32, device="cuda")
+    fr.shade_f32(sc, perm)
+    torch.cuda.synchronize()
+    assert torch.equal(sc[perm], f32)
+    fd = DeviceFrame(ctx, W, H, S, fov_x=0.6, fov_y=0.6, sampling_seed=42.0, origin=CAM, directions_only=True)
+    fd.set_sky(sky)
+    assert np.array_equal(fd.render(p).cpu().numpy(), rgba)
+
+
 def test_device_scene_shade_disk_and_objects(ctx, oracle):
     """Disk colour (Limited engine's checkHitDisk profile) and object Lambert shading in the device shade
     kernel against the numpy restatement, on a frame that holds horizon, sky, disk and object pixels."""
