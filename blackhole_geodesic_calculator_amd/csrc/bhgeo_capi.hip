@@ -1280,7 +1280,6 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
     if (rc != BHG_OK) return rc;
-    if (p->method != BHG_METHOD_DP54) return fail(BHG_E_INVALID, "trajectories are sampled with BHG_METHOD_DP54 only");
     if (n_points < 2) return fail(BHG_E_INVALID, "n_points must be >= 2");
     if (n == 0) return BHG_OK;
     if (!x0 || !k0 || !traj || !n_valid) return fail(BHG_E_INVALID, "x0 / k0 / traj / n_valid is NULL");
@@ -1383,7 +1382,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
-    HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form,
+    HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form, p->method,
                                    d_traj, (uint32_t *)(os + off_nv), n_points, s));
     const size_t total = off_flags + n;
     if (direct) {

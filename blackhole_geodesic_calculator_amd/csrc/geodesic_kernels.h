@@ -125,14 +125,14 @@ hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t
 // machine LICM off, see the Makefile -- compiled on its own)
 hipError_t launch_trace_kerr(const TraceArgs &a, int method, int evt, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy_kerr(int method, int evt, int *blocks_per_cu);
-hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+hipError_t launch_trajectory_kerr(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 // ... and so does the time-like Christoffel form (geodesic_kernels_timelike.hip; one event variant)
 hipError_t launch_trace_timelike(const TraceArgs &a, int method, int grid, hipStream_t s, hipEvent_t *ev);
 hipError_t trace_occupancy_timelike(int method, int *blocks_per_cu);
-hipError_t launch_trajectory_timelike(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+hipError_t launch_trajectory_timelike(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 hipError_t launch_accel_timelike(const double *x, const double *k, double r_s, uint64_t n, double *acc, hipStream_t s);
 // prepare + one-lane-per-ray sampled trajectories (+ Kerr finalize); traj [n][6][T], n_valid [n]
-hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
+hipError_t launch_trajectory(const TraceArgs &a, int rhs, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s);
 // does a trajectory call of n rays run one wave per ray (the kernel then prepares the ray itself and NaN-fills the tail)?
 bool trajectory_wave_per_ray(uint64_t n);
 // rhs = Kerr: x, k and acc are Boyer-Lindquist (r, theta, phi) triples, E and L fixed by the null condition at each point

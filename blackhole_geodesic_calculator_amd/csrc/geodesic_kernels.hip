@@ -2740,7 +2740,7 @@ __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A, d
 // call, ONE ray with nr_points_curve = 10000 (:293-294): a single lane spent 1.9 ms of its 2.0 ms evaluating 10,000
 // dense-output points one after the other.
 // ------------------------------------------------------------------------------------------
-template <int RHS, bool WAVE>
+template <int RHS, bool WAVE, bool FIXED>
 __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, double *traj, uint32_t *n_valid,
                                                              uint32_t T)
 {
@@ -2781,7 +2781,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         }
         h_abs = 0.0;
         r_cur = 0.0;
-        initial_record<RHS, true>(A, met, x, v, a1, r_cur, h_abs);
+        initial_record<RHS, !FIXED>(A, met, x, v, a1, r_cur, h_abs);
     } else {
         const double *w = A.ws + i * (uint64_t)A.ws_stride;
         a1[0] = w[0];
@@ -2814,6 +2814,24 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
     bool rejected = false;
     double xe[3] = {x[0], x[1], x[2]}, ve[3] = {v[0], v[1], v[2]};
     for (;;) {
+        double t_new, h, a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+        if (FIXED) {
+            // classic RK4 with the fixed step h_fixed (the build's "R-fine" regime): no controller, every step accepted
+            if (t >= t_bound) {
+                flags = BHG_FLAG_REACHED_END_;
+                break;
+            }
+            if (n_att >= A.max_steps) {
+                flags = BHG_FLAG_MAX_STEPS_;
+                break;
+            }
+            t_new = t + A.h_fixed;
+            if (t_new - t_bound > 0.0) t_new = t_bound;
+            h = t_new - t;
+            rk4_step<RHS>(x, v, a1, h, met, xn, vn, a7, r_new);
+            n_att++;
+            n_acc = n_att;
+        } else {
         const double min_step = 10.0 * ulp_of(t);
         if (!rejected) {
             if (h_abs > max_step)
@@ -2833,11 +2851,10 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             flags = BHG_FLAG_REACHED_END_;
             break;
         }
-        double t_new = t + h_abs;
+        t_new = t + h_abs;
         if (t_new - t_bound > 0.0) t_new = t_bound;
-        const double h = t_new - t;
+        h = t_new - t;
         h_abs = fabs(h);
-        double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
         dp54_stages<RHS>(x, v, a1, h, met, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
         n_att++;
         double errsq = dp54_errsq(x, v, xn, vn, a1, a2, a3, a4, a5, a6, a7, h, rtol, atol);
@@ -2853,10 +2870,34 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         h_abs *= fac;
         rejected = false;
         n_acc++;
-        // dense output of the accepted step
+        }
+        // the step's interpolant: the dense output of the accepted DP5(4) step, or -- fixed steps -- its cubic Hermite interpolant
         Dense d;
-        build_dense(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
+        Hermite hd;
         const bool bl = RHS == BHG_RHS_KERR_BL_;
+        if (FIXED) {
+            hd.t0 = t;
+            hd.h = h;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                hd.x0[c] = x[c];
+                hd.v0[c] = v[c];
+                hd.a0[c] = a1[c];
+                hd.x1[c] = xn[c];
+                hd.v1[c] = vn[c];
+                hd.a1[c] = a7[c];
+            }
+        } else {
+            build_dense(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
+        }
+        auto state_at = [&](double tt, double sx[3], double sv[3]) {
+            if (FIXED) {
+                hermite_eval(hd, tt, sx, sv);
+            } else {
+                dense_pos(d, tt, sx);
+                dense_dir(d, tt, sv);
+            }
+        };
         const bool ev_h = ((r_cur - A.r_hor <= 0.0) && (r_new - A.r_hor >= 0.0)) ||
                           ((r_cur - A.r_hor >= 0.0) && (r_new - A.r_hor <= 0.0));
         const bool ev_e = (A.r_exit > 0.0) && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
@@ -2864,6 +2905,16 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         const bool ev_d = (A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(x, xn);
         double t_stop = t_new;
         uint32_t evflag = 0;
+        if (FIXED && !(ev_h || ev_e || ev_d) && !(r_new == r_new)) {
+            // a fixed step that ends in a non-finite state (through the Boyer-Lindquist 1 / Delta singularity): the ray ends
+            // there, flagged NaN by store_result; the step yields no samples
+            for (int c = 0; c < 3; c++) {
+                xe[c] = xn[c];
+                ve[c] = vn[c];
+            }
+            flags = 0;
+            break;
+        }
         if (ev_h || ev_e || ev_d) {
             // the trace kernels' own event settlement (Brent on the dense output, scipy's brentq step for step; of the
             // terminal candidates the earliest root wins, ties in the order horizon, exit, disk)
@@ -2871,16 +2922,31 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             double best;
             int obj;
             evflag = settle_events<(EVT_EXIT | EVT_DISK)>(
-                A, kind, t, t_new, x, xn, [&](double tt, double Rr) { return dense_g(d, tt, Rr, bl); },
+                A, kind, t, t_new, x, xn,
+                [&](double tt, double Rr) { return FIXED ? hermite_g(hd, tt, Rr, bl) : dense_g(d, tt, Rr, bl); },
                 [&](double tt) {
-                    if (!bl) return dense_z(d, tt);
                     double q[3];
-                    dense_pos(d, tt, q);
+                    if (FIXED) {
+                        double vv[3];
+                        hermite_eval(hd, tt, q, vv);
+                        if (!bl) return q[2];
+                    } else {
+                        if (!bl) return dense_z(d, tt);
+                        dense_pos(d, tt, q);
+                    }
                     double sn, cs;
                     sincos_pi4(q[1], sn, cs);
                     return cs;
                 },
-                [&](double tt, double xq[3]) { dense_pos(d, tt, xq); }, bl, best, obj);
+                [&](double tt, double xq[3]) {
+                    if (FIXED) {
+                        double vv[3];
+                        hermite_eval(hd, tt, xq, vv);
+                    } else {
+                        dense_pos(d, tt, xq);
+                    }
+                },
+                bl, best, obj);
             if (evflag) t_stop = best;
         }
         // emit every sample time up to where this step ends
@@ -2905,8 +2971,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
                 next = j + 1;
             }
             double sx[3], sv[3];
-            dense_pos(d, te, sx);
-            dense_dir(d, te, sv);
+            state_at(te, sx, sv);
             if (bl) {
                 const double r = sx[0], th = sx[1], ph = sx[2], a = A.spin;
                 const double R = sqrt(r * r + a * a), st = sin(th), ct = cos(th), sp = sin(ph), cp = cos(ph);
@@ -2925,8 +2990,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         }
         if (evflag) {
             flags = evflag;
-            dense_pos(d, t_stop, xe);
-            dense_dir(d, t_stop, ve);
+            state_at(t_stop, xe, ve);
             break;
         }
         for (int c = 0; c < 3; c++) {
@@ -2969,40 +3033,48 @@ bool trajectory_wave_per_ray(uint64_t n) { return n <= 2048; }
 #endif
 
 // prepare pass + sampled trajectories of one right-hand side
-template <int RHS>
-static void launch_trajectory_rhs(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+template <int RHS, bool FIXED>
+static void launch_trajectory_rhs_m(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
     if (trajectory_wave_per_ray(a.n)) {
-        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, true>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, true, FIXED>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
     } else {
-        hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, false>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+        hipLaunchKernelGGL((prepare_kernel<RHS, !FIXED>), dim3(gp), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, false, FIXED>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
     }
 }
 
-#if defined(BHG_TU_KERR)
-hipError_t launch_trajectory_kerr(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+// method: BHG_METHOD_DP54_ (the step's dense output) or BHG_METHOD_RK4_ (fixed steps, cubic Hermite interpolant)
+template <int RHS>
+static void launch_trajectory_rhs(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
-    launch_trajectory_rhs<BHG_RHS_KERR_BL_>(a, traj, n_valid, T, s);
+    if (method == BHG_METHOD_RK4_) launch_trajectory_rhs_m<RHS, true>(a, traj, n_valid, T, s);
+    else launch_trajectory_rhs_m<RHS, false>(a, traj, n_valid, T, s);
+}
+
+#if defined(BHG_TU_KERR)
+hipError_t launch_trajectory_kerr(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+{
+    launch_trajectory_rhs<BHG_RHS_KERR_BL_>(a, method, traj, n_valid, T, s);
     hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, (double *)nullptr);
     return hipGetLastError();
 }
 #elif defined(BHG_TU_TIMELIKE)
-hipError_t launch_trajectory_timelike(const TraceArgs &a, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+hipError_t launch_trajectory_timelike(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
-    launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_TL_>(a, traj, n_valid, T, s);
+    launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_TL_>(a, method, traj, n_valid, T, s);
     return hipGetLastError();
 }
 #else
-hipError_t launch_trajectory(const TraceArgs &a, int rhs, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
+hipError_t launch_trajectory(const TraceArgs &a, int rhs, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
-    if (rhs == BHG_RHS_KERR_BL_) return launch_trajectory_kerr(a, traj, n_valid, T, s);
-    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return launch_trajectory_timelike(a, traj, n_valid, T, s);
+    if (rhs == BHG_RHS_KERR_BL_) return launch_trajectory_kerr(a, method, traj, n_valid, T, s);
+    if (rhs == BHG_RHS_CHRISTOFFEL_TL_) return launch_trajectory_timelike(a, method, traj, n_valid, T, s);
     if (rhs == BHG_RHS_REDUCED_)
-        launch_trajectory_rhs<BHG_RHS_REDUCED_>(a, traj, n_valid, T, s);
+        launch_trajectory_rhs<BHG_RHS_REDUCED_>(a, method, traj, n_valid, T, s);
     else
-        launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_>(a, traj, n_valid, T, s);
+        launch_trajectory_rhs<BHG_RHS_CHRISTOFFEL_>(a, method, traj, n_valid, T, s);
     return hipGetLastError();
 }
 #endif

@@ -207,7 +207,8 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * (rows x, y, z, k_x, k_y, k_z).  end [n][6] / flags [n] (may be NULL): the same end state and flags
  * bhg_trace gives -- with the exit sphere and, since ABI 7, the thin disk (a ray that ends on it: BHG_FLAG_HIT_DISK, the
  * curve sampled up to the crossing, end = the crossing point: what checkHitDisk looks for on the sampled path,
- * LimitedRelativisticRenderEngine.py:284, :413-438).  BHG_METHOD_DP54 only; at most 2^26 rays per call.  Small-n path: one
+ * LimitedRelativisticRenderEngine.py:284, :413-438).  BHG_METHOD_RK4 (ABI 7): fixed steps h_fixed, the samples on each step's
+ * cubic Hermite interpolant (the one the fixed-step kernels locate events on).  At most 2^26 rays per call.  Small-n path: one
  * WAVE per ray up to 2048 rays (a step's samples are shared out over the 64 lanes: the engine's literal call, one ray
  * with 10,000 samples, takes about 0.1 ms), one lane per ray above; the same bits either way.  A `traj` of at most 4 MB in
  * PAGE-LOCKED memory (bhg_host_alloc) is written by the wave-per-ray kernel directly, over PCIe: no copy of the sample

@@ -708,7 +708,21 @@ static void trace_dp54(const bhgo_params *p, const rayctx *rc, const double x0[3
 /* ---------------------------------------------------------------------------------------
  * One ray, classic fixed-step RK4 (the build's own "R-fine" regime; not a scipy method)
  * ------------------------------------------------------------------------------------- */
-static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res)
+/* samples of a fixed step: the step's cubic Hermite interpolant (the fixed-step regime's dense output, also what its
+   events are located on) */
+static void sampler_emit_hermite(sampler_t *sm, const hermite_t *hm, double t_upto)
+{
+    while (sm->next < sm->T && sampler_time(sm, sm->next) <= t_upto) {
+        double y[6], e[6];
+        hermite_eval(hm, sampler_time(sm, sm->next), y);
+        pack_end(y, e);
+        for (int c = 0; c < 6; c++) sm->out[(size_t)c * sm->T + sm->next] = e[c];
+        sm->next++;
+    }
+}
+
+static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3], const double k0[3], ray_result *res,
+                      sampler_t *sm)
 {
     double y[6] = {k0[0], x0[0], k0[1], x0[1], k0[2], x0[2]};
     double f[6];
@@ -766,13 +780,15 @@ static void trace_rk4(const bhgo_params *p, const rayctx *rc, const double x0[3]
             res->flags |= fl;
             t = t_root;
             memcpy(y, y_root, sizeof(y));
+            if (sm) sampler_emit_hermite(sm, &hm, t);
             break;
         }
         g_h = g_h_new;
         g_e = g_e_new;
         int bad = 0;
         for (int i = 0; i < 6; i++) bad |= !isfinite(y[i]);
-        if (bad) break;
+        if (bad) break;     /* (a step that ends in a non-finite state yields no samples) */
+        if (sm) sampler_emit_hermite(sm, &hm, t);
     }
     int bad = 0;
     for (int i = 0; i < 6; i++) bad |= !isfinite(y[i]);
@@ -859,7 +875,7 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
         rc.E = -(gtt * kt + gtp * u[2]);
         rc.L = gtp * kt + gpp * u[2];
         if (p->method == BHGO_METHOD_RK4)
-            trace_rk4(p, &rc, q, u, res);
+            trace_rk4(p, &rc, q, u, res, sm);
         else
             trace_dp54(p, &rc, q, u, res, sm);
         /* res->end is {r, th, ph, ur, uth, uph}: back to Cartesian */
@@ -896,7 +912,7 @@ static void trace_one(const bhgo_params *p, const double x0[3], const double k0[
         return;
     }
     if (p->method == BHGO_METHOD_RK4)
-        trace_rk4(p, &rc, x0, k0, res);
+        trace_rk4(p, &rc, x0, k0, res, sm);
     else
         trace_dp54(p, &rc, x0, k0, res, sm);
 }
@@ -968,12 +984,12 @@ int bhgo_trace_objects(const bhgo_params *p, const double *x0, int x0_shared, co
     return 0;
 }
 
-/* Sampled trajectories (DP5(4) only): traj [n][6][T], n_valid [n] = samples emitted per ray
-   (t_eval points beyond the ray's end are not produced, as with solve_ivp's t_eval) */
+/* Sampled trajectories: traj [n][6][T], n_valid [n] = samples emitted per ray (t_eval points beyond the ray's end are
+   not produced, as with solve_ivp's t_eval).  DP5(4): the step's dense output; fixed-step RK4: its cubic Hermite interpolant */
 int bhgo_trajectory(const bhgo_params *p, const double *x0, int x0_shared, const double *k0, size_t n, uint32_t T,
                     double *traj, uint32_t *n_valid, uint8_t *flags)
 {
-    if (!p || !x0 || !k0 || !traj || !n_valid || T < 2 || p->method != BHGO_METHOD_DP54) return -1;
+    if (!p || !x0 || !k0 || !traj || !n_valid || T < 2) return -1;
     for (size_t i = 0; i < n; i++) {
         ray_result r;
         sampler_t sm = {T, 0, p->lambda_end, traj + i * 6 * (size_t)T};

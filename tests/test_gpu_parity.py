@@ -1026,6 +1026,54 @@ def test_trajectories_batch_match_trace_and_oracle(ctx, oracle):
             assert max(dmax) < 1e-8
 
 
+def test_trajectories_with_fixed_step_rk4(ctx, oracle):
+    """bhg_trajectory with BHG_METHOD_RK4 (ABI 7; VERDICT r04 missing #5): fixed steps h_fixed, samples on the step's cubic
+    Hermite interpolant -- the interpolant the fixed-step kernels locate their events on.  Flags and end states: what bhg_trace
+    gives for the same parameters (bit for bit for rays that run to curve_end); samples: the oracle's.  Wave-per-ray and
+    lane-per-ray forms, exit sphere, disk, Kerr."""
+    inc = np.radians(70.0)
+    cam = np.array([30 * np.sin(inc), 0.0, 30 * np.cos(inc)])
+    rot = np.array([[np.cos(inc), 0, np.sin(inc)], [0, 1, 0], [-np.sin(inc), 0, np.cos(inc)]])
+    for n, kw in ((300, dict(r_s=1.0, lambda_end=45.0, method=1, h_fixed=0.25)),
+                  (2300, dict(r_s=1.0, lambda_end=60.0, method=1, h_fixed=0.5, r_exit=38.0, disk_r_in=3.0, disk_r_out=9.0, rhs_form=1)),
+                  (200, dict(r_s=1.0, lambda_end=40.0, method=1, h_fixed=0.2, rhs_form=2, spin=0.45, r_exit=38.0))):
+        k = frame_rays(n, seed=59, fov=0.9) @ rot.T
+        T = 80
+        kerr = kw.get("rhs_form") == 2
+        traj, nv, end, flags = ctx.trajectory(k, cam, _params(**kw), T)
+        e2, f2, s2, a2 = ctx.trace(k, cam, _params(**kw))
+        if kerr:   # fixed steps through the Boyer-Lindquist horizon: whether the crossing is seen before the state turns NaN is rounding
+            ok = (flags == f2) | (((flags | f2) & ~np.uint8(1 | 64)) == 0)
+            assert ok.all() and (flags == f2).mean() > 0.95
+        else:
+            assert np.array_equal(flags, f2)
+        ran = (flags == 4) & (f2 == 4)
+        assert ran.sum() > 0.2 * n and np.array_equal(end[ran], e2[ran])
+        same_f = flags == f2
+        ev = same_f & ((flags & (8 | 128)) != 0)
+        assert np.abs(end[ev] - e2[ev]).max(initial=0.0) < (1e-10 if not kerr else 1e-8)
+        tr, onv, ofl = oracle.trajectory(k, cam, T, **kw)
+        agree = (flags == ofl)
+        assert agree.mean() > (0.999 if not kerr else 0.9)
+        same = agree & (nv == onv)
+        assert same.mean() > (0.99 if not kerr else 0.85)
+        worst = 0.0
+        compared = 0
+        for i in np.nonzero(same & ((flags & (1 | 64)) == 0))[0][:150]:
+            m = nv[i]
+            assert np.isnan(traj[i, :, m:]).all()
+            if kerr and not np.abs(tr[i, :, :m]).max() < 200.0:
+                continue      # (a fixed step that jumped the 1 / Delta singularity left garbage on both sides: nothing to compare)
+            compared += 1
+            worst = max(worst, np.abs(traj[i, :, :m] - tr[i, :, :m]).max())
+        assert compared > 50 and worst < (1e-9 if not kerr else 1e-5), (compared, worst)
+        # the curve's last sample of a ray that ran to curve_end IS its end state
+        full = np.nonzero(ran & (nv == T))[0][:50]
+        assert len(full) > 10
+        for i in full:
+            assert np.abs(traj[i, :, T - 1] - end[i]).max() < 1e-12
+
+
 def test_trajectories_with_the_thin_disk_event(ctx, oracle):
     """bhg_trajectory with the disk (ABI 7; VERDICT r04 missing #5): the Limited engine finds its disk hit on the SAMPLED
     path (checkHitDisk walks x_SW, y_SW, z_SW, LimitedRelativisticRenderEngine.py:284, :413-438).  A ray that ends on the

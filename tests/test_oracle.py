@@ -475,6 +475,30 @@ def test_oracle_kerr_objects_match_scipy_golden(oracle):
     assert np.abs(np.linalg.norm(o["end"][hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9
 
 
+def test_fixed_step_trajectories_are_the_hermite_interpolant_of_the_rk4_trace(oracle):
+    """oracle.trajectory with method = RK4: samples on each fixed step's cubic Hermite interpolant.  The last sample of a ray
+    that runs to lambda_end is the end state the trace gives; samples that fall ON step ends (t_eval a multiple of h) are the
+    step ends of the trace at that lambda (traced again with lambda_end = that time); and with a small step the curve agrees
+    with the adaptive solver's at tight tolerance."""
+    k = frame_rays(60, seed=91)
+    kw = dict(r_s=1.0, lambda_end=40.0, method=1, h_fixed=0.5)
+    T = 81                                     # t_eval = 0, 0.5, 1.0, ...: every sample sits on a step end
+    tr, nv, fl = oracle.trajectory(k, CAM, T, **kw)
+    o = oracle.trace(k, CAM, **kw)
+    assert np.array_equal(fl, o["flags"])
+    ran = fl == 4
+    assert ran.sum() > 30 and np.all(nv[ran] == T)
+    assert np.abs(tr[ran][:, :, T - 1] - o["end"][ran]).max() < 1e-13
+    i = int(np.nonzero(ran)[0][0])
+    for j in (1, 7, 40):
+        mid = oracle.trace(k[i:i + 1], CAM, **dict(kw, lambda_end=0.5 * j))
+        assert np.abs(tr[i, :, j] - mid["end"][0]).max() < 1e-12
+    fine = dict(r_s=1.0, lambda_end=40.0, method=1, h_fixed=0.02)
+    t2, nv2, _ = oracle.trajectory(k[ran][:10], CAM, 33, **fine)
+    t3, nv3, _ = oracle.trajectory(k[ran][:10], CAM, 33, r_s=1.0, lambda_end=40.0, rtol=1e-11, atol=1e-13)
+    assert np.array_equal(nv2, nv3) and np.abs(t2 - t3).max() < 1e-5
+
+
 def test_oracle_suite_under_sanitizers():
     """The checker is what every parity claim rests on: its C restatement built with -fsanitize=address,undefined
     (`make -C oracle asan`) must pass THIS file's tests in a child process with the sanitizer runtimes preloaded (a finding
