@@ -9,6 +9,7 @@ in a FRESH child process (this parent never touches the GPU, nothing is exec'ed 
 line to gpurun_out/node_run.jsonl, and a failure does not stop the steps after it; the exit code is non-zero if any failed.
 
   (i)   python bench.py --gpus N                      N = 1, 2, 4, 8: one process per GPU, torch.distributed over RCCL
+        (+ --workload disk and --workload orbit at the largest N: BASELINE configs 3 and 4)
   (ii)  python bench.py --single-process --gpus N     N = 2, 4, 8 with --frame-gather rccl | copy | peer (N = 1: auto)
   (iii) examples/render_frame.c on devices 0,1,..,N-1 (plain C through the C ABI; compiled here with gcc)
   (iv)  the N-device image against the 1-device image, bit for bit (library-owned frame, every gather mode)
@@ -75,6 +76,16 @@ def plan(a):
                           (["--cpu-seconds", "0", "--live-pmc", "0"] if n > 1 else
                            (["--live-pmc", "0", "--cpu-seconds", "0", "--emulate-shards", ",".join(str(v) for v in Ns[1:])] if a.quick else ["--live-pmc", "0"])),
                           env=env))
+    # ... and BASELINE's other sharded configurations at the largest N: config 3 (disk, five inclinations per step) and config 4
+    # (the 2048 x 2048 x 16 orbit frame: ONE frame's tiles over all ranks + whole frames round-robin)
+    nmax = Ns[-1]
+    if nmax > 1:
+        env = {"BHGEO_BENCH_BACKEND": "gloo"} if a.standin else {}
+        small = ["--width", "256", "--samples", "2"] if a.quick else []
+        for wl_, extra in (("disk", []), ("orbit", ["--steps", str(max(2, a.steps // 4)), "--warmup", "2"])):
+            steps.append(dict(name=f"dist_n{nmax}_{wl_}", kind="bench", n=nmax, env=env,
+                              cmd=[py, os.path.join(ROOT, "bench.py"), "--gpus", str(nmax), "--workload", wl_] + common + extra + small +
+                                  ["--cpu-seconds", "0", "--live-pmc", "0"]))
     for n in Ns:
         modes = ["auto"] if n == 1 else (["copy"] if a.standin else ["rccl", "copy", "peer"])
         for mode in modes:
