@@ -6,7 +6,13 @@ x 5 samples = 5,242,880 null geodesics (BASELINE.json config 2; camera (1e-4, 0,
 mass 0.5 -> r_s = 1, curve_end 50, directions from the reference's pinhole + MT19937 jitter,
 raytracer/RelativisticRenderEngine.py:185-230, seed 42).  Inputs are resident in HBM when the
 timed region starts; the timed region is trace + shade/sample-mean and, for N > 1, the single gather of
-per-pixel RGBA to rank 0 (asynchronous, overlapping the next frame's trace).
+per-pixel RGBA to rank 0 (asynchronous, overlapping the next frame's trace).  The trace writes WHOLE end records
+(exit position and direction, 48 B/ray: what spacetime_ray_cast returns, :307-308 -- the headline since round 5);
+--dir-only gives the sky frame's form (exit directions only), reported beside the headline as sky_frame_dir_only.
+
+roofline.calibration: bhg_peak_probe (a pure v_fma_f64 kernel and one with the step loop's instruction mix, in the trace
+kernels' launch geometry) before the warm-up steps and right after the timed region, and the shader clock sampled from
+sysfs while the region runs -> frac_of_measured_peak, frac_at_timed_region_clock beside frac (the vendor's 78.6 TFLOP/s).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the headline figures are WEAK scaling --
 the frame grows to (1024*nx) x (1024*ny), nx*ny = N, over the same window of directions, so every rank still
