@@ -475,6 +475,59 @@ def test_oracle_kerr_objects_match_scipy_golden(oracle):
     assert np.abs(np.linalg.norm(o["end"][hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9
 
 
+def test_sampled_curves_are_solve_ivps_t_eval_output(oracle):
+    """Row a2's literal semantics -- calc_trajectory(..., nr_points_curve=T) (RelativisticRenderEngine.py:293-294) -- pinned to
+    scipy ITSELF: solve_ivp(..., t_eval=linspace(0, curve_end, T), events=[horizon (, exit sphere)]) against the C
+    restatement's sampled curves.  Same number of samples per ray (a ray that ends on an event yields the grid points up to
+    the root and no more, ivp.py:706-723), same values to rounding; rays to curve_end, horizon rays (the Fig. 5 / capture
+    geometry) and exit-sphere rays; both right-hand-side forms."""
+    from oracle import scipy_reference as sr
+    g = load_golden("fig5")
+    cases = [(g["k0"], g["x0"], dict(r_s=1.0, lambda_end=60.0), 121),
+             (frame_rays(24, seed=93), CAM, dict(r_s=1.0, lambda_end=50.0), 50),
+             (frame_rays(24, seed=94, fov=0.25), CAM, dict(r_s=1.0, lambda_end=70.0, r_exit=31.0), 77),
+             (frame_rays(12, seed=95, fov=0.25), CAM, dict(r_s=1.0, lambda_end=50.0, max_step=0.5, rhs_form=1), 33)]
+    seen = {1: 0, 4: 0, 8: 0}
+    for k, x0, kw, T in cases:
+        k = np.atleast_2d(k)
+        tr, nv, fl = oracle.trajectory(k, x0, T, **kw)
+        for i in range(len(k)):
+            xi = x0 if np.ndim(x0) == 1 else x0[i]
+            r = sr.trace_ray(k[i], xi, r_s=kw["r_s"], lambda_end=kw["lambda_end"], max_step=kw.get("max_step", np.inf),
+                             form="reduced" if kw.get("rhs_form") == 1 else "christoffel", r_exit=kw.get("r_exit", 0.0),
+                             nr_points_curve=T)
+            sol = r["sol"]
+            assert int(fl[i]) == r["flags"], (i, int(fl[i]), r["flags"])
+            seen[int(fl[i])] = seen.get(int(fl[i]), 0) + 1
+            m = sol.y.shape[1]
+            assert nv[i] == m, (i, int(nv[i]), m)
+            want = np.stack([sol.y[1], sol.y[3], sol.y[5], sol.y[0], sol.y[2], sol.y[4]])     # state order k_x, x, k_y, y, k_z, z (:301)
+            d = np.abs(tr[i, :, :m] - want).max()
+            assert d < (1e-9 if not (int(fl[i]) & 1) else 1e-6), (i, d)
+            assert np.isnan(tr[i, :, m:]).all()
+    assert seen[1] >= 5 and seen[4] >= 20 and seen[8] >= 10, seen
+    # the thin disk: scipy's crossing event is non-terminal (the annulus test comes afterwards), so its samples run on past the
+    # disk; the restatement's curve is scipy's up to the crossing and ends there
+    inc = np.radians(70.0)
+    cam = np.array([30 * np.sin(inc), 0.0, 30 * np.cos(inc)])
+    rot = np.array([[np.cos(inc), 0, np.sin(inc)], [0, 1, 0], [-np.sin(inc), 0, np.cos(inc)]])
+    k = frame_rays(40, seed=96, fov=0.8) @ rot.T
+    T, kw = 90, dict(r_s=1.0, lambda_end=70.0, disk_r_in=3.0, disk_r_out=9.0)
+    tr, nv, fl = oracle.trajectory(k, cam, T, **kw)
+    t_eval = np.linspace(0.0, 70.0, T)
+    hits = 0
+    for i in range(len(k)):
+        r = sr.trace_ray(k[i], cam, r_s=1.0, lambda_end=70.0, disk=(3.0, 9.0), nr_points_curve=T)
+        assert int(fl[i]) == r["flags"]
+        sol = r["sol"]
+        m = int(np.searchsorted(t_eval, r["t_end"], side="right")) if r["flags"] == 128 else sol.y.shape[1]
+        hits += r["flags"] == 128
+        assert nv[i] == m, (i, int(nv[i]), m)
+        want = np.stack([sol.y[1], sol.y[3], sol.y[5], sol.y[0], sol.y[2], sol.y[4]])[:, :m]
+        assert np.abs(tr[i, :, :m] - want).max() < (1e-9 if not (int(fl[i]) & 1) else 1e-6)
+    assert hits >= 8
+
+
 def test_fixed_step_trajectories_are_the_hermite_interpolant_of_the_rk4_trace(oracle):
     """oracle.trajectory with method = RK4: samples on each fixed step's cubic Hermite interpolant.  The last sample of a ray
     that runs to lambda_end is the end state the trace gives; samples that fall ON step ends (t_eval a multiple of h) are the
