@@ -141,7 +141,8 @@ def summarise(step, rc, out, err, seconds, predicted):
         cfg, n = j.get("config", {}), step["n"]
         rec.update(n_gpus=j.get("n_gpus"), value_mrays_s=j.get("value"), ms_per_step=j.get("ms_per_step"), scaling=j.get("scaling"),
                    collective=cfg.get("collective"), root_share=cfg.get("root_share"), frac=(j.get("roofline") or {}).get("frac"),
-                   frac_of_measured_peak=(j.get("roofline") or {}).get("frac_of_measured_peak"))
+                   frac_of_measured_peak=(j.get("roofline") or {}).get("frac_of_measured_peak"),
+                   frac_at_timed_region_clock=((j.get("roofline") or {}).get("calibration") or {}).get("frac_at_timed_region_clock"))
         # RCCL ranks seen: "rccl gather, N rank(s)" (torch.distributed form) / "rccl (single-process mode), N device(s)"
         col = str(cfg.get("collective") or "")
         rec["rccl_ranks_seen"] = n if ("rccl" in col.lower() and str(n) in col) else 0
