@@ -413,3 +413,29 @@ def test_tile_dealing_under_address_and_ub_sanitizers(tmp_path):
         assert ok, line
         checked += 1
     assert checked >= 50
+
+
+def test_bench_calibration_block_is_plain_arithmetic():
+    """roofline.calibration (bench_common.calibration_block): the measured-peak fractions follow from the probes' figures by
+    the stated formulas, with and without a sysfs clock sample, and a line without probes carries no block."""
+    import bench_common as bc
+    probe = {"fp64_fma_tflops": 72.0, "fp64_fma_clock_mhz": 2197.0, "fma_wave_insts_per_s": 5.5e11, "step_mix_tflops": 66.0,
+             "step_mix_wave_insts_per_s": 5.3e11}
+    after = dict(probe, fp64_fma_tflops=70.0)
+    sclk = {"mean_mhz": 2300.0, "min_mhz": 2280.0, "max_mhz": 2320.0, "samples": 60, "source": "x", "pci": "y"}
+    achieved, valu64, ray_steps, k_ms = 36.0, 581.0, 65.05e6, 1.14
+    c = bc.calibration_block({"before": probe, "after": after}, sclk, achieved, valu64, ray_steps, k_ms)
+    assert abs(c["fp64_fma_tflops_measured"] - 71.0) < 1e-12 and c["fp64_fma_tflops_before_after"] == [72.0, 70.0]
+    assert abs(c["frac_of_measured_peak"] - 36.0 / 71.0) < 1e-12 and abs(c["fp64_fma_frac_of_vendor_peak"] - 71.0 / 78.6) < 1e-12
+    assert abs(c["peak_tflops_at_timed_region_clock"] - 2300e6 * 128 * 256 / 1e12) < 1e-9
+    assert abs(c["frac_at_timed_region_clock"] - 36.0 / (2300e6 * 128 * 256 / 1e12)) < 1e-12
+    rate = valu64 * (ray_steps / 64.0) / (k_ms * 1e-3)
+    assert abs(c["trace_kernel_wave_insts_per_s"] - rate) < 1.0 and abs(c["valu_issue_utilisation"] - rate / 5.5e11) < 1e-12
+    assert abs(c["valu_issue_utilisation_vs_step_mix"] - rate / 5.3e11) < 1e-12
+    assert abs(c["trace_kernel_wave_insts_per_clock_per_simd"] - rate / (2300e6 * 1024)) < 1e-12
+    c2 = bc.calibration_block({"before": probe}, None, achieved, None, ray_steps, k_ms)
+    assert isinstance(c2["sclk_mhz_timed_region"], str) and "frac_at_timed_region_clock" not in c2 and "valu_issue_utilisation" not in c2
+    assert bc.calibration_block({}, sclk, achieved, valu64, ray_steps, k_ms) is None
+    # the sampler on a box without the sysfs file (this one): no thread, no figure
+    smp = bc.ClockSampler(0).start()
+    assert smp.stop() is None or isinstance(smp.stop(), dict)
