@@ -86,9 +86,8 @@ public:
         for (auto &t : th_) t.join();
     }
     // dst <- src, blocking; the calling thread takes pieces too
-    void copy(void *dst, const void *src, size_t bytes)
+    void copy(void *dst, const void *src, size_t bytes, size_t piece = size_t(2) << 20)
     {
-        const size_t piece = size_t(2) << 20;
         if (bytes <= 2 * piece) {
             std::memcpy(dst, src, bytes);
             return;
@@ -229,7 +228,7 @@ struct bhg_context {
 namespace bhg {
 // for bhgeo_frame.hip: a context's worker threads copy a page-locked staging block into the caller's pageable array (a
 // 16.8-MB frame through ONE thread's memcpy is 1.0-1.7 ms -- as long as the frame's trace)
-void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes) { c->pool.copy(dst, src, bytes); }
+void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes, size_t piece) { c->pool.copy(dst, src, bytes, piece); }
 }  // namespace bhg
 
 namespace {

@@ -33,7 +33,7 @@
 
 namespace bhg {
 int set_error(int code, const std::string &msg);   // bhgeo_capi.hip: the thread-local message of bhg_last_error()
-void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes);   // bhgeo_capi.hip: multi-threaded memcpy
+void host_copy(bhg_context *c, void *dst, const void *src, size_t bytes, size_t piece);   // bhgeo_capi.hip: multi-threaded memcpy in jobs of `piece` bytes
 }
 
 namespace {
@@ -193,6 +193,7 @@ struct bhg_frame {
     bool rendered = false;
     bool profiling = false;
     std::vector<hipEvent_t> ev_root;   // around the root's gather + assembly (profiling)
+    std::vector<hipEvent_t> ev_piece;  // the pieces of the image's way back to a pageable caller array
     hipEvent_t assembled = nullptr;    // the root has read the receive block of the last render (copies of the next wait for it)
     uint64_t renders = 0;
 };
@@ -374,6 +375,8 @@ void destroy_frame(bhg_frame *f)
     for (auto e : f->ev_root)
         if (e) (void)hipEventDestroy(e);
     if (f->assembled) (void)hipEventDestroy(f->assembled);
+    for (auto e : f->ev_piece)
+        if (e) (void)hipEventDestroy(e);
     if (f->pin) (void)hipHostFree(f->pin);
     delete f;
 }
@@ -688,9 +691,27 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
                 HIP_TRY(hipHostMalloc(&f->pin, bytes, hipHostMallocDefault));
                 f->pin_bytes = bytes;
             }
-            HIP_TRY(hipMemcpyAsync(f->pin, f->image.p, bytes, hipMemcpyDeviceToHost, root.stream));
-            HIP_TRY(hipStreamSynchronize(root.stream));
-            bhg::host_copy(root.ctx, rgba_host, f->pin, bytes);    // (the root context's worker threads: not one core's memcpy)
+            // in two halves: while the second half crosses PCIe the first goes from the staging block into the caller's array
+            // (the context's copy threads, 512-kB jobs so that all of them have work on half a frame).  Measured on one box
+            // (scripts/dev/dev_library_frame.py, 1024 x 1024 frame): 1.80 ms in one piece, 1.72 in two, 1.70-1.75 in four;
+            // four pieces with the pool's usual 2-MB jobs: 2.15 (two jobs per piece leave six threads idle)
+            constexpr int PIECES = 2;
+            if (f->ev_piece.empty()) {
+                f->ev_piece.resize(PIECES, nullptr);
+                for (auto &e : f->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+            const size_t piece = ((bytes / PIECES) + 4095) & ~size_t(4095);
+            int n_pieces = 0;
+            for (size_t off = 0; off < bytes; off += piece, n_pieces++) {
+                const size_t len = std::min(piece, bytes - off);
+                HIP_TRY(hipMemcpyAsync((char *)f->pin + off, (const char *)f->image.p + off, len, hipMemcpyDeviceToHost, root.stream));
+                HIP_TRY(hipEventRecord(f->ev_piece[n_pieces], root.stream));
+            }
+            int k = 0;
+            for (size_t off = 0; off < bytes; off += piece, k++) {
+                HIP_TRY(hipEventSynchronize(f->ev_piece[k]));
+                bhg::host_copy(root.ctx, (char *)rgba_host + off, (const char *)f->pin + off, std::min(piece, bytes - off), size_t(512) << 10);
+            }
         }
         // (the other devices' streams have been waited for through the gather; a frame of ONE device has one stream)
     }
