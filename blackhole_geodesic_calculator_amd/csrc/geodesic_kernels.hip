@@ -2317,6 +2317,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
     unsigned long long diag_iters = 0, diag_lanes = 0;
+    unsigned long long diag_cross = 0, diag_pass = 0;    // iterations in which some lane crossed the disk plane / passed the filter
 #endif
     W.slice = blockIdx.x % NSLICE;
     W.dry = 0;
@@ -2428,6 +2429,9 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) &&
                                 crossed_disk_plane<RHS>(L.x, xn);
                     const bool ev_o = (EVT & EVT_OBJ) && any_sphere_candidate_of<RHS>(A, L.x, xn);
+#ifdef BHG_DIAG
+                    const bool diag_crossed = ev_d;
+#endif
                     // (whatever else the step holds: a plane crossing that cannot lie in the annulus is no event -- and
                     // a parked step with ONE candidate event takes the drain's short path)
                     if ((EVT & EVT_DISK) && ev_d &&
@@ -2442,6 +2446,12 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                     // Schwarzschild disk frame -1.1 % with it -- so Kerr only.
                     if (RHS == BHG_RHS_KERR_BL_ && (EVT & EVT_DISK) && __ballot(ev_d) != 0ull) {
                         if (ev_d && !disk_crossing_may_hit_sharp<RHS>(A, L.x, L.v, xn, vn, h, L.a1, a2, a3, a4, a5, a6)) ev_d = false;
+                    }
+#endif
+#ifdef BHG_DIAG
+                    if (EVT & EVT_DISK) {      // (inside the accepted branch: the ballots below count lanes of THIS branch only)
+                        diag_cross += __builtin_popcountll(__ballot(diag_crossed)) ? 1 : 0;
+                        diag_pass += __builtin_popcountll(__ballot(ev_d)) ? 1 : 0;
                     }
 #endif
                     if (ev_h || ev_e || ev_d || ev_o) {
@@ -2479,7 +2489,7 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         unsigned long long *d = A.diag + (size_t)blockIdx.x * 8;
         d[0] = diag_t0;
         d[1] = __builtin_amdgcn_s_memrealtime();
-        d[2] = diag_iters;
+        d[2] = diag_iters | (diag_cross << 24) | (diag_pass << 44);   // (a wave runs < 2^20 iterations)
         d[4] = __builtin_amdgcn_s_memtime() - diag_c0;
         d[5] = W.diag_drain_cyc;
         d[6] = W.diag_drained | (W.diag_drained_long << 40);   // steps drained from the short list | from the long list

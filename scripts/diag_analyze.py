@@ -1,6 +1,9 @@
 import numpy as np, sys
 d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
 d = d[d[:, 1] > 0]
+cross = ((d[:, 2] >> np.uint64(24)) & np.uint64((1 << 20) - 1)).astype(np.float64)
+passed = (d[:, 2] >> np.uint64(44)).astype(np.float64)
+d = d.copy(); d[:, 2] &= np.uint64((1 << 24) - 1)
 long_cyc = (d[:, 3] >> np.uint64(40)).astype(np.float64)
 d = d.copy(); d[:, 3] &= np.uint64((1 << 40) - 1)
 t0, t1, it, ln = d[:, 0].astype(np.int64), d[:, 1].astype(np.int64), d[:, 2], d[:, 3]
@@ -28,3 +31,6 @@ if general.sum():
 if refill.sum():
     other = refill.sum() - d[:, 5].sum() - d[:, 7].sum()
     print("refill() calls without drain / batch fill (LDS pops, work fetch): %.4f of wave cycles = %.0f cycles per iteration" % (other / cyc.sum(), other / it.sum()))
+if cross.sum():
+    print("disk plane: some lane crossed it in %.4f of the iterations; some lane passed the filter (is parked) in %.4f; "
+          "the filter ran for nothing in %.4f" % (cross.sum() / it.sum(), passed.sum() / it.sum(), (cross.sum() - passed.sum()) / it.sum()))
