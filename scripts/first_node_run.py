@@ -67,6 +67,8 @@ def plan(a):
     Ns = [n for n in (1, 2, 4, 8) if n <= a.gpus]
     common = ["--steps", str(a.steps), "--warmup", str(a.warmup)]
     steps = []
+    # what the node looks like: devices, xGMI links between them, NUMA placement (informational: never fails the run)
+    steps.append(dict(name="topology", kind="info", env={}, cmd=["bash", "-c", "rocm-smi --showtopo 2>&1 | tail -60; rocm-smi --showuniqueid 2>&1 | tail -12"]))
     for n in Ns:
         env = {}
         if a.standin and n > 1:
@@ -164,6 +166,9 @@ def summarise(step, rc, out, err, seconds, predicted):
             predicted.clear()
             predicted.update(j["strong_predicted"])
             rec["strong_predicted_rank0"] = {k: v.get("efficiency_rank0") for k, v in j["strong_predicted"].get("shards", {}).items()}
+    elif step["kind"] == "info":
+        rec["rc"] = 0                      # (informational)
+        rec["output_tail"] = (out or "")[-3000:]
     elif step["kind"] == "c_example":
         head = (out or "").split("\n", 1)[0]
         rec["head"] = head[:300]

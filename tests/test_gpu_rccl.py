@@ -216,7 +216,7 @@ def test_first_node_run_script_works_with_one_gpu_stand_ins(tmp_path):
                         "--warmup", "2", "--out", str(out), "--timeout", "300"], capture_output=True, text=True, timeout=1200)
     recs = {x["step"]: x for x in (json.loads(l) for l in open(out))}
     assert r.returncode == 0 and recs["summary"]["failed"] == [], (r.stdout[-2000:], r.stderr[-2000:])
-    want = ["dist_n1", "dist_n2", "dist_n2_disk", "dist_n2_orbit", "single_n1_auto", "single_n2_copy", "build_render_frame", "c_example_n1", "c_example_n2", "bit_identity_n2_copy",
+    want = ["topology", "dist_n1", "dist_n2", "dist_n2_disk", "dist_n2_orbit", "single_n1_auto", "single_n2_copy", "build_render_frame", "c_example_n1", "c_example_n2", "bit_identity_n2_copy",
             "dist_bit_identity_n2"]
     assert [k for k in recs if k != "summary"] == want and all(recs[k]["rc"] == 0 for k in want)
     assert recs["dist_n1"]["strong_predicted_rank0"].get("2") is not None and recs["dist_n1"]["frac_of_measured_peak"] > 0.3

@@ -324,7 +324,7 @@ def test_first_node_run_plan_covers_every_form_and_device_count():
         for mode in ("rccl", "copy", "peer"):
             assert f"single_n{n}_{mode}" in names and f"bit_identity_n{n}_{mode}" in names
         assert f"dist_bit_identity_n{n}" in names
-    assert "dist_n8_disk" in names and "dist_n8_orbit" in names
+    assert "dist_n8_disk" in names and "dist_n8_orbit" in names and names[0] == "topology"
     assert names.index("build_render_frame") < names.index("c_example_n1")
     # the stand-in plan for a one-GPU box: gloo ranks sharing the GPU, repeated device indices, copies only
     st = nr.plan(argparse.Namespace(gpus=2, steps=5, warmup=1, standin=True, quick=True))
