@@ -581,6 +581,23 @@ def main():
                          "shaded from them" if other_dir else
                          "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them")}
             del fro
+        if world == 1 and a.workload == "frame" and a.regime == "adaptive" and not a.lean:
+            # SURVEY section 8d asks for both step regimes: the fine one (max_step 0.1, ~490 steps per ray) and the fixed-step RK4
+            # (h = 0.1, 500 steps per ray) on the same frame, a few steps each (40 and 16 ms per step), same output form
+            import copy
+            regs = {}
+            for reg in ("fine", "rk4"):
+                a2 = copy.copy(a)
+                a2.regime = reg
+                w2 = Workload(a2)
+                ms_r, call_r, steps_r = time_frame(fr, w2.params, 10, 2, device=rt.local_rank, ramp=0.0)
+                regs[reg] = {"value": n / (ms_r * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_r, "ray_steps_per_s": steps_r / (ms_r * 1e-3),
+                             "attempted_steps_per_ray": steps_r / n, "flop_per_ray_step": w2.flop,
+                             "frac": steps_r * w2.flop / (call_r * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                             "what": ("DP5(4), max_step = 0.1 (the Cam edition's pickle-name value)" if reg == "fine" else "classic RK4, h = 0.1") +
+                                     ", 10 timed steps after 2 warm-up steps; frac from the trace call's HIP-event time"}
+            out["regimes"] = regs
+            fr.trace(wl.params)      # (leave the frame's buffers holding the adaptive result)
         if world == 1 and a.workload == "frame" and a.emulate_shards.strip():
             t1_ms, t1_call, _ = time_frame(fr, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
             out["strong_predicted"] = strong_predicted(rt, wl, sky, m, (t1_ms, t1_call))

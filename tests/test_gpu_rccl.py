@@ -138,6 +138,8 @@ def test_bench_measured_tile_order_two_ranks_and_single_gpu_blocks():
     # the headline writes whole end states (x and k, what spacetime_ray_cast returns); the sky frame's direction-only form beside it
     assert "full_records" in line["config"]["north_star_output"] and line["roofline"]["algorithmic_bytes_per_ray"] == 81
     assert line["sky_frame_dir_only"]["value"] > 0 and line["sky_frame_dir_only"]["algorithmic_bytes_per_ray"] == 57
+    # both step regimes of SURVEY section 8d beside the adaptive headline
+    assert line["regimes"]["fine"]["attempted_steps_per_ray"] > 100 and line["regimes"]["rk4"]["frac"] > 0.1
     cal = line["roofline"]["calibration"]
     assert 30.0 < cal["fp64_fma_tflops_measured"] < 90.0 and 0.0 < line["roofline"]["frac_of_measured_peak"] < 1.0
     assert cal["issue_bound_wave_insts_per_s"] > 1e11
