@@ -84,9 +84,9 @@ def plan(a):
     if nmax > 1:
         env = {"BHGEO_BENCH_BACKEND": "gloo"} if a.standin else {}
         small = ["--width", "256", "--samples", "2"] if a.quick else []
-        for wl_, extra in (("disk", []), ("orbit", ["--steps", str(max(2, a.steps // 4)), "--warmup", "2"])):
+        for wl_, sw in (("disk", common), ("orbit", ["--steps", str(max(2, a.steps // 4)), "--warmup", "2"])):   # (an orbit step is 16 x a frame step)
             steps.append(dict(name=f"dist_n{nmax}_{wl_}", kind="bench", n=nmax, env=env,
-                              cmd=[py, os.path.join(ROOT, "bench.py"), "--gpus", str(nmax), "--workload", wl_] + common + extra + small +
+                              cmd=[py, os.path.join(ROOT, "bench.py"), "--gpus", str(nmax), "--workload", wl_] + sw + small +
                                   ["--cpu-seconds", "0", "--live-pmc", "0"]))
     for n in Ns:
         modes = ["auto"] if n == 1 else (["copy"] if a.standin else ["rccl", "copy", "peer"])
