@@ -2340,6 +2340,8 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
         diag_iters++;
         diag_lanes += __builtin_popcountll(__ballot(L.active));
 #endif
+        // (s_setprio for a wave that carries a long ray -- so that a small launch does not last as long as its longest ray takes
+        // next to two other waves -- measured in round 5: 1/8 shard -0.7 %, whole frame +0.4 %, profiles/r05_prio_ab.log; not kept)
 
         if (L.active) {
             // ---- one attempted step (rk.py:111-165 flattened: one attempt per iteration) ----
