@@ -389,6 +389,40 @@ def host_buffer_figures(ctx, fr, cam, params, n):
     out["library_frame"] = {"value": W * H * S / best / 1e6, "unit": "Mrays/s", "ms": best * 1e3,
                             "what": "bhg_frame_render into a pageable numpy array, best of 3: rays resident, trace + shade + sample "
                                     "mean on the device, one [H, W, 4] float image back (the add-on's device path; no torch)"}
+    # ... into a page-locked array (bhg_host_alloc): the copy engine writes the caller's array, no staging copy
+    img_p = ctx.pinned.empty((H, W, 4), np.float32)
+    fo.render(params, out=img_p)
+    best_p = float("inf")
+    for _ in range(3):
+        t = time.perf_counter()
+        fo.render(params, out=img_p)
+        best_p = min(best_p, time.perf_counter() - t)
+    out["library_frame"].update(pinned_image_ms=best_p * 1e3, pinned_image_value=W * H * S / best_p / 1e6,
+                                pinned_image_identical=bool(np.array_equal(img_p, img)))
+    # ... and an animation's form (config 4 is 100 frames): two frame objects on two host threads, each call blocking on its
+    # own frame -- one frame's image crosses PCIe while the other frame is traced
+    import threading
+    ctx2 = _ffi.Context(ctx.device)
+    fo2 = _ffi.Frame([ctx.device], W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, origin=cam, jitter=jit)
+    fo2.set_scene(sky)
+    img2 = ctx2.pinned.empty((H, W, 4), np.float32)
+    fo2.render(params, out=img2)
+    K2 = 10
+    def _animate(f_, o_):
+        for _ in range(K2):
+            f_.render(params, out=o_)
+    th = [threading.Thread(target=_animate, args=(fo, img_p)), threading.Thread(target=_animate, args=(fo2, img2))]
+    t = time.perf_counter()
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    dt2 = (time.perf_counter() - t) / (2 * K2)
+    out["library_frame"].update(two_frames_ms=dt2 * 1e3, two_frames_value=W * H * S / dt2 / 1e6,
+                                two_frames_identical=bool(np.array_equal(img2, img)),
+                                two_frames_what=f"{2 * K2} frames, two frame objects on two host threads (page-locked images): wall time per frame")
+    fo2.close()
+    ctx2.close()
     fo.close()
     # the engine's literal per-ray call (RelativisticRenderEngine.py:293-294: one ray, nr_points_curve = 10000) through the
     # adaptor -- what a caller gets who swaps the integrator object and nothing else
