@@ -48,6 +48,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the pool's host driver supports dmabuf IPC only: without this RCCL between processes fails with hipIpcGetMemHandle:
+# invalid argument.  Set before anything initialises the GPU -- also when a launcher, not self_launch(), started this rank.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from bench_common import (BYTES_PER_RAY, BYTES_PER_RAY_DIR, CAM, DISK, EV_EVERY, PEAK_FP64_VALU_TFLOPS, ClockSampler, Lanes, Runtime,  # noqa: F401
                           Workload, emit, grid_for, roofline_block, run_probes, traced_with_events)
