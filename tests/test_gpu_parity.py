@@ -31,6 +31,13 @@ TOL_END = 1e-9   # absolute floor, values are O(1..50)
 # draws have no such ray at all; the worst are 2.53 % (31 of 1226 rays, half of them horizon rays) and 2 of 76 rays -- asserted
 # at 4 % or three rays, whichever is more (8 % up to round 4).
 KERR_FUZZ_DIFFER = 0.04
+# ... and per class since the 1 187-draw run (round 5, BHG_FUZZ=6000, profiles/r05_fuzz6000.log, scripts/dev/dev_r05_fuzz_fail.py):
+# two draws whose rays nearly all END ON THE HORIZON (87 % and 64 % of them, camera near the equatorial plane, rtol 5e-3) had
+# 5.1 % and 6.4 % of their rays differ -- every one a horizon ray, 5.9 % and 10 % of the draw's horizon rays, by one or two
+# steps in the median (the right-hand side is singular there, 1/Delta).  So: horizon rays (either side says so) against
+# the draw's horizon rays, the others against the draw.
+KERR_FUZZ_DIFFER_HORIZON = 0.15
+KERR_FUZZ_DIFFER_OTHER = 0.02
 LAST_COMPARE = {}   # filled by _compare: rays compared, rays further than TOL_END from the oracle, rays beyond the scaled bound
 COND = 500.0     # multiples of the oracle's own 1-ulp input sensitivity S_i (an estimate from three perturbations, not a
                  # bound).  Measured over 240 fuzz draws (round 4, LAST_COMPARE["worst_multiple_of_sensitivity"]): the worst ray
@@ -79,8 +86,20 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0,
         assert np.abs(steps.astype(int) - o["n_attempted"].astype(int)).max(initial=0) <= 2
     else:
         assert np.array_equal(flags, o["flags"])
-        assert np.array_equal(steps, o["n_attempted"])
-        assert np.array_equal(acc, o["n_accepted"])
+        sdiff = np.nonzero((steps != o["n_attempted"]) | (acc != o["n_accepted"]))[0]
+        # Identical accept / reject sequences on every ray -- or, for at most two rays of a draw, a sequence the CHECKER
+        # ITSELF produces when the ray's direction moves by an ulp or two: an error norm within rounding of 1.  (9 500 draws,
+        # 13 M rays, round 5, profiles/r05_fuzz6000.log: one such ray -- a horizon ray at rtol 1.5e-6, 29 / 16 steps on the GPU,
+        # 31 / 17 in the checker, 29 / 16 in the checker with k0 scaled by 1 - 1e-16.)
+        assert len(sdiff) <= 2, f"{len(sdiff)} rays differ in step count"
+        for i in sdiff:
+            xi = x0 if np.ndim(x0) == 1 else np.asarray(x0)[i]
+            seen = set()
+            for eps in (1e-16, -1e-16, 2e-16, -2e-16, 3e-16, -3e-16, 4e-16, -4e-16):
+                oo = oracle.trace(np.asarray(k0)[i:i + 1] * (1.0 + eps), xi, **kw)
+                seen.add((int(oo["n_attempted"][0]), int(oo["n_accepted"][0])))
+            assert (int(steps[i]), int(acc[i])) in seen, f"ray {i}: GPU {steps[i]}/{acc[i]}, checker {o['n_attempted'][i]}/{o['n_accepted'][i]}, checker near by {seen}"
+        LAST_COMPARE["rounding_flips"] = int(len(sdiff))
     d = np.abs(end - o["end"]).max(1) if len(end) else np.zeros(0)
     if len(end):
         fin = np.isfinite(o["end"]).all(1)
@@ -770,14 +789,23 @@ def test_randomised_kerr(ctx, oracle, seed, record_property):
     same = (steps == o["n_attempted"]) & (acc == o["n_accepted"]) & (flags == o["flags"])
     from oracle import scipy_reference as sr
     Lz = np.array([sr.kerr_constants(*sr.cart_to_bl(cam, kk, spin), 0.5 * r_s, spin, float(kw.get("time_like", 0)))[1] for kk in k[~same]])
-    touchy = ((flags[~same] & (1 | 64)) != 0) | (np.abs(Lz) < 0.3 * r_s)
+    # (a horizon ray is one EITHER side ends on the horizon or in NaN: with a step budget, max_steps, the two can stop one
+    # accept / reject decision apart -- MAX_STEPS here, HIT_HORIZON there)
+    hor_all = ((flags | o["flags"]) & (1 | 64)) != 0
+    hor = hor_all[~same]
+    touchy = hor | (np.abs(Lz) < 0.3 * r_s)
     rec = dict(rays=len(k), differ=int((~same).sum()), differ_fraction=float((~same).mean()), touchy_fraction=float(touchy.mean()) if len(Lz) else 1.0,
-               horizon_fraction=float(((flags & 1) != 0).mean()))
+               horizon_fraction=float(hor_all.mean()), differ_horizon=int(hor.sum()), horizon_rays=int(hor_all.sum()),
+               differ_other=int((~hor).sum()), differ_neither=int((~touchy).sum()))
     print("kerr fuzz", seed, rec)
     for k_, v_ in rec.items():
         record_property(k_, v_)
-    # (bound and what was measured: KERR_FUZZ_DIFFER at the top of this file)
-    assert (~same).sum() <= max(3, KERR_FUZZ_DIFFER * len(k)) and touchy.mean() >= 0.9 if len(Lz) else True
+    # (bounds and what was measured: KERR_FUZZ_DIFFER* at the top of this file; a ray that is neither a horizon ray nor near
+    # the axis may flip too -- one in 1.5 M of them did, 19 of 5.24 M on the off-axis frame of test_gpu_fullsize -- but not two)
+    assert hor.sum() <= max(3, KERR_FUZZ_DIFFER_HORIZON * hor_all.sum()), rec
+    assert (~hor).sum() <= max(3, KERR_FUZZ_DIFFER_OTHER * len(k)), rec
+    assert (~same).sum() <= max(3, KERR_FUZZ_DIFFER * len(k), KERR_FUZZ_DIFFER_HORIZON * hor_all.sum()), rec
+    assert (~touchy).sum() <= 1, rec
     d = np.abs(end - o["end"]).max(1)
     tol = 1e-9 + 1e4 * _sensitivity(oracle, k, cam, o["end"], **kw) + np.where((o["flags"] & 1) != 0, 1e-5, 0.0)
     ok = same & np.isfinite(o["end"]).all(1)
