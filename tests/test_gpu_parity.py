@@ -36,8 +36,11 @@ KERR_FUZZ_DIFFER = 0.04
 # 5.1 % and 6.4 % of their rays differ -- every one a horizon ray, 5.9 % and 10 % of the draw's horizon rays, by one or two
 # steps in the median (the right-hand side is singular there, 1/Delta).  So: horizon rays (either side says so) against
 # the draw's horizon rays, the others against the draw.
+# The run repeated with these bounds: 1 499 Kerr draws, 1.85 M rays, 483 k of them horizon rays -- 102 draws have a ray that
+# differs, 618 rays in all: 614 horizon rays (worst draws 10.4 %, 9.9 %, 5.9 % of their horizon rays), 4 near-axis rays (worst
+# draw 0.075 % of its rays), none that is neither.
 KERR_FUZZ_DIFFER_HORIZON = 0.15
-KERR_FUZZ_DIFFER_OTHER = 0.02
+KERR_FUZZ_DIFFER_OTHER = 0.005
 LAST_COMPARE = {}   # filled by _compare: rays compared, rays further than TOL_END from the oracle, rays beyond the scaled bound
 COND = 500.0     # multiples of the oracle's own 1-ulp input sensitivity S_i (an estimate from three perturbations, not a
                  # bound).  Measured over 240 fuzz draws (round 4, LAST_COMPARE["worst_multiple_of_sensitivity"]): the worst ray
