@@ -53,6 +53,7 @@ int fail(int code, const std::string &msg)
 int fail_hip(hipError_t e, const char *what)
 {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();     // (reported here: not again by the next launch's status)
     return (e == hipErrorOutOfMemory) ? BHG_E_NOMEM : BHG_E_HIP;
 }
 

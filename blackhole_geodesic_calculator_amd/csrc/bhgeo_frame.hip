@@ -42,6 +42,7 @@ int fail(int code, const std::string &msg) { return bhg::set_error(code, msg); }
 
 int fail_hip(hipError_t e, const char *what)
 {
+    (void)hipGetLastError();     // (reported here: not again by the next launch's status)
     return bhg::set_error(e == hipErrorOutOfMemory ? BHG_E_NOMEM : BHG_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 

@@ -262,14 +262,14 @@ __global__ void __launch_bounds__(256) split_end_kernel(const double *end, uint6
 hipError_t launch_split_end(const double *end, uint64_t n, double *loc, double *dir, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(split_end_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, s, end, n, loc, dir);
+    BHG_LAUNCH(split_end_kernel, dim3((unsigned)((n * 3 + 255) / 256)), dim3(256), 0, s, end, n, loc, dir);
     return hipGetLastError();
 }
 
 hipError_t launch_gather_rows4(const float *src, const int64_t *index, uint64_t n, float *dst, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_rows4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+    BHG_LAUNCH(gather_rows4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const float4 *>(src), index, n, reinterpret_cast<float4 *>(dst));
     return hipGetLastError();
 }
@@ -278,7 +278,7 @@ hipError_t launch_raygen(const RaygenArgs &a, hipStream_t s)
 {
     const uint64_t n = a.n_pixels * (uint64_t)a.samples;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    BHG_LAUNCH(raygen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -286,11 +286,11 @@ hipError_t launch_shade(const ShadeArgs &a, hipStream_t s)
 {
     if (a.n_pixels == 0) return hipSuccess;
     if (a.samples > 256) {
-        hipLaunchKernelGGL(shade_reduce_serial_kernel, dim3((unsigned)((a.n_pixels + 255) / 256)), dim3(256), 0, s, a);
+        BHG_LAUNCH(shade_reduce_serial_kernel, dim3((unsigned)((a.n_pixels + 255) / 256)), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const uint32_t ppb = 256u / (uint32_t)a.samples;      // pixels per workgroup
-    hipLaunchKernelGGL(shade_reduce_kernel, dim3((unsigned)((a.n_pixels + ppb - 1) / ppb)), dim3(256), 0, s, a, ppb);
+    BHG_LAUNCH(shade_reduce_kernel, dim3((unsigned)((a.n_pixels + ppb - 1) / ppb)), dim3(256), 0, s, a, ppb);
     return hipGetLastError();
 }
 

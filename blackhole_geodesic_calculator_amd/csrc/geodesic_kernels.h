@@ -4,6 +4,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Every launcher returns hipGetLastError() as THIS launch's status.  That call reports -- and clears -- the last error any
+// earlier HIP call of the thread left behind, ours (a refused allocation) or another library's (a probing
+// hipPointerGetAttributes): it is read away before the launch, so that a launch that went through is not reported
+// with somebody else's error.
+#define BHG_LAUNCH(...)                    \
+    do {                                   \
+        (void)hipGetLastError();           \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
+
 namespace bhg {
 
 // mirrors of the public constants (include/bhgeo.h); static_asserts in bhgeo_capi.hip tie them

@@ -2693,7 +2693,7 @@ hipError_t launch_accel_kerr(const double *x, const double *k, double r_s, doubl
 {
     const int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(accel_kerr_kernel, dim3(grid), dim3(256), 0, s, x, k, r_s, spin, mu2, n, acc);
+    BHG_LAUNCH(accel_kerr_kernel, dim3(grid), dim3(256), 0, s, x, k, r_s, spin, mu2, n, acc);
     return hipGetLastError();
 }
 
@@ -3050,10 +3050,10 @@ static void launch_trajectory_rhs_m(const TraceArgs &a, double *traj, uint32_t *
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
     if (trajectory_wave_per_ray(a.n)) {
-        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, true, FIXED>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
+        BHG_LAUNCH((trajectory_dp54_kernel<RHS, true, FIXED>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
     } else {
-        hipLaunchKernelGGL((prepare_kernel<RHS, !FIXED>), dim3(gp), dim3(256), 0, s, a);
-        hipLaunchKernelGGL((trajectory_dp54_kernel<RHS, false, FIXED>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
+        BHG_LAUNCH((prepare_kernel<RHS, !FIXED>), dim3(gp), dim3(256), 0, s, a);
+        BHG_LAUNCH((trajectory_dp54_kernel<RHS, false, FIXED>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);
     }
 }
 
@@ -3069,7 +3069,7 @@ static void launch_trajectory_rhs(const TraceArgs &a, int method, double *traj, 
 hipError_t launch_trajectory_kerr(const TraceArgs &a, int method, double *traj, uint32_t *n_valid, uint32_t T, hipStream_t s)
 {
     launch_trajectory_rhs<BHG_RHS_KERR_BL_>(a, method, traj, n_valid, T, s);
-    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, (double *)nullptr);
+    BHG_LAUNCH(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, (double *)nullptr);
     return hipGetLastError();
 }
 #elif defined(BHG_TU_TIMELIKE)
@@ -3128,15 +3128,15 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
     if (ev) (void)hipEventRecord(ev[0], s);
     if (!a.inline_prepare) {
         if (method == BHG_METHOD_RK4_)
-            hipLaunchKernelGGL((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
+            BHG_LAUNCH((prepare_kernel<RHS, false>), dim3(gp), dim3(256), 0, s, a);
         else
-            hipLaunchKernelGGL((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
+            BHG_LAUNCH((prepare_kernel<RHS, true>), dim3(gp), dim3(256), 0, s, a);
     }
     if (ev) (void)hipEventRecord(ev[1], s);
     if (method == BHG_METHOD_RK4_)
-        hipLaunchKernelGGL((trace_rk4_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
+        BHG_LAUNCH((trace_rk4_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
     else
-        hipLaunchKernelGGL((trace_dp54_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
+        BHG_LAUNCH((trace_dp54_kernel<RHS, EVT>), dim3(grid), dim3(64), 0, s, a);
     if (ev) (void)hipEventRecord(ev[2], s);
     return hipGetLastError();
 }
@@ -3146,7 +3146,7 @@ static hipError_t launch_variant(const TraceArgs &a_in, int method, int grid, hi
 hipError_t launch_kerr_finalize(const TraceArgs &a, double *dir_out, hipStream_t s)
 {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, dir_out);
+    BHG_LAUNCH(kerr_finalize_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, a, dir_out);
     return hipGetLastError();
 }
 #endif
@@ -3198,7 +3198,7 @@ hipError_t launch_accel_timelike(const double *x, const double *k, double r_s, u
 {
     const int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL((accel_kernel<BHG_RHS_CHRISTOFFEL_TL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+    BHG_LAUNCH((accel_kernel<BHG_RHS_CHRISTOFFEL_TL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
     return hipGetLastError();
 }
 #else
@@ -3254,9 +3254,9 @@ hipError_t launch_accel(const double *x, const double *k, double r_s, double spi
     int grid = (int)((n + 255) / 256);
     if (grid == 0) return hipSuccess;
     if (rhs == BHG_RHS_REDUCED_)
-        hipLaunchKernelGGL((accel_kernel<BHG_RHS_REDUCED_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+        BHG_LAUNCH((accel_kernel<BHG_RHS_REDUCED_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
     else
-        hipLaunchKernelGGL((accel_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
+        BHG_LAUNCH((accel_kernel<BHG_RHS_CHRISTOFFEL_>), dim3(grid), dim3(256), 0, s, x, k, r_s, n, acc);
     return hipGetLastError();
 }
 #endif  // BHG_TU_KERR

@@ -90,8 +90,8 @@ hipError_t launch_probe(int kind, int grid, uint32_t iters, double *out, hipStre
 {
     // a, b: a contraction towards 1 (x <- 0.999 x + 0.001), so that every chain stays finite for any iteration count
     const double a = 0.999, b = 0.001;
-    if (kind == 0) hipLaunchKernelGGL(probe_fma_kernel, dim3(grid), dim3(64), 0, s, iters, a, b, out);
-    else hipLaunchKernelGGL(probe_mix_kernel, dim3(grid), dim3(64), 0, s, iters, a, b, out);
+    if (kind == 0) BHG_LAUNCH(probe_fma_kernel, dim3(grid), dim3(64), 0, s, iters, a, b, out);
+    else BHG_LAUNCH(probe_mix_kernel, dim3(grid), dim3(64), 0, s, iters, a, b, out);
     return hipGetLastError();
 }
 
