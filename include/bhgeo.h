@@ -28,12 +28,16 @@
  *     n_steps [n]    attempted RK steps (accepted + rejected)
  *     n_accepted [n] accepted RK steps
  *
- * Threading: one bhg_context per device; calls on one context must not overlap.  Host-buffer
+ * Threading: one bhg_context per device; calls on one context must not overlap (contexts of different
+ * threads may run at the same time, on one device or several).  Host-buffer
  * calls block until the results are in the caller's buffers.  Device-buffer calls enqueue on the
  * given HIP stream and return; the library keeps no pointer after the call's work completes.
  *
  * Errors: every int-returning function returns BHG_OK (0) or a negative BHG_E_* code;
- * bhg_last_error() gives a thread-local message for the last failure.  There is no CPU
+ * bhg_last_error() gives a thread-local message for the last failure.  A refused device allocation is
+ * BHG_E_NOMEM and leaves the context usable.  The status of a call is its own: an error another caller of the
+ * HIP runtime left behind on the thread (hipGetLastError() is sticky) is not reported, and the library leaves none
+ * of its own behind.  There is no CPU
  * fallback: without a usable gfx950 device the calls fail with BHG_E_NO_DEVICE.
  */
 #ifndef BHGEO_H
