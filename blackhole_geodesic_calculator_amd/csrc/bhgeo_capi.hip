@@ -126,10 +126,18 @@ private:
     };
     void start()
     {
-        if (!th_.empty()) return;
+        if (started_) return;
+        started_ = true;
         unsigned hw = std::thread::hardware_concurrency();
         unsigned n = hw > 1 ? std::min(hw - 1, 7u) : 0u;  // + the calling thread
-        for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { run(); });
+        // (a process at its thread limit: fewer workers, or none -- the calling thread copies what nobody else takes)
+        for (unsigned i = 0; i < n; i++) {
+            try {
+                th_.emplace_back([this] { run(); });
+            } catch (const std::exception &) {
+                break;
+            }
+        }
     }
     void finish_one()
     {
@@ -156,7 +164,7 @@ private:
     std::condition_variable cv_, done_;
     std::deque<Job> q_;
     size_t pending_ = 0;
-    bool stop_ = false;
+    bool stop_ = false, started_ = false;
 };
 
 // Entry points make the context's device current for their own HIP calls and put the caller's current device back on

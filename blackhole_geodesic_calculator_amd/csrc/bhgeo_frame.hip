@@ -46,6 +46,21 @@ int fail_hip(hipError_t e, const char *what)
     return bhg::set_error(e == hipErrorOutOfMemory ? BHG_E_NOMEM : BHG_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// No C++ exception leaves the library through the C ABI: the entry points that use standard containers (the jitter stream and
+// the images are copied into vectors, the tile dealing sorts) are function-try-blocks that end here.
+int host_exception()
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(BHG_E_NOMEM, "host allocation failed");
+    } catch (const std::exception &e) {
+        return fail(BHG_E_HIP, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(BHG_E_HIP, "internal error: unknown exception");
+    }
+}
+
 #define HIP_TRY(expr)                                     \
     do {                                                  \
         hipError_t _e = (expr);                           \
@@ -388,9 +403,10 @@ extern "C" {
 
 int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, const double *tile_cost, int32_t visit_by_cost,
                    double root_share, int32_t rank, int64_t *pixels, size_t capacity, size_t *n_out)
-{
+try {
     if (width <= 0 || height <= 0 || tile <= 0 || world <= 0 || rank < 0 || rank >= world || !n_out || !(root_share > 0.0 && root_share <= 1.0))
         return fail(BHG_E_INVALID, "bad argument");
+    if (!bhg::tile_grid_fits(width, height, tile)) return fail(BHG_E_INVALID, "more than 2^31 - 1 tiles");
     std::vector<std::vector<int64_t>> px;
     deal_tiles_into(width, height, tile, world, tile_cost, visit_by_cost != 0, root_share, px);
     const auto &mine = px[(size_t)rank];
@@ -400,11 +416,13 @@ int bhg_deal_tiles(int32_t width, int32_t height, int32_t tile, int32_t world, c
         std::memcpy(pixels, mine.data(), mine.size() * sizeof(int64_t));
     }
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera *cam, const double *jitter, int32_t tile,
                      int32_t gather, bhg_frame **out)
-{
+try {
     if (!out) return fail(BHG_E_INVALID, "out is NULL");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return fail(BHG_E_INVALID, "devices: a list of 1 .. 64 device indices");
@@ -416,6 +434,7 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
         return fail(BHG_E_INVALID, "unknown gather mode");
     const size_t HW = (size_t)cam->width * (size_t)cam->height;
     if (HW * (size_t)cam->samples > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays in the frame");
+    if (!bhg::tile_grid_fits(cam->width, cam->height, tile)) return fail(BHG_E_INVALID, "more than 2^31 - 1 tiles");
     const int n_vis = bhg_device_count();
     if (n_vis <= 0) return fail(BHG_E_NO_DEVICE, "no HIP device visible (libbhgeo has no CPU fallback)");
     bool distinct = true;
@@ -427,7 +446,11 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
         return fail(BHG_E_INVALID, "RCCL needs distinct devices (a repeated device gathers by device-to-device copies)");
     if (gather == BHG_FRAME_GATHER_RCCL && !rccl().ok()) return fail(BHG_E_HIP, "librccl.so could not be loaded");
     DeviceScope scope;
-    bhg_frame *f = new (std::nothrow) bhg_frame();
+    struct Guard {        // (an exception on the way -- the jitter copy, the dealing -- must not leave the half-built frame behind)
+        bhg_frame *f = nullptr;
+        ~Guard() { if (f) destroy_frame(f); }
+    } guard;
+    bhg_frame *f = guard.f = new (std::nothrow) bhg_frame();
     if (!f) return fail(BHG_E_NOMEM, "host allocation failed");
     f->cam = *cam;
     f->tile = tile;
@@ -486,11 +509,15 @@ int bhg_frame_create(const int32_t *devices, int32_t n_devices, const bhg_camera
     }
     if (rc != BHG_OK) {
         const std::string msg = bhg_last_error();
+        guard.f = nullptr;
         destroy_frame(f);
         return fail(rc, msg);
     }
+    guard.f = nullptr;
     *out = f;
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 void bhg_frame_destroy(bhg_frame *f)
@@ -513,7 +540,7 @@ int bhg_frame_set_camera(bhg_frame *f, const bhg_camera *cam)
 }
 
 int bhg_frame_set_scene(bhg_frame *f, const bhg_frame_scene *sc)
-{
+try {
     if (!f || !sc) return fail(BHG_E_INVALID, "frame / scene is NULL");
     if (sc->n_spheres < 0 || sc->n_spheres > BHG_MAX_SPHERES || sc->n_lamps < 0 || sc->n_lamps > 4)
         return fail(BHG_E_INVALID, "n_spheres must be in [0, BHG_MAX_SPHERES], n_lamps in [0, 4]");
@@ -546,10 +573,12 @@ int bhg_frame_set_scene(bhg_frame *f, const bhg_frame_scene *sc)
     if (images_changed)
         for (auto &s : f->sh) s.scene_ready = false;
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
-{
+try {
     if (!f || !p) return fail(BHG_E_INVALID, "frame / params is NULL");
     if (f->sky.empty()) return fail(BHG_E_INVALID, "bhg_frame_set_scene() first (the frame has no sky)");
     if ((p->disk_r_out > 0.0) != (f->scene.disk_r_out > 0.0) ||
@@ -719,6 +748,8 @@ int bhg_frame_render(bhg_frame *f, const bhg_params *p, float *rgba_host)
     f->rendered = true;
     f->renders++;
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 int bhg_frame_synchronize(bhg_frame *f)
@@ -735,7 +766,7 @@ int bhg_frame_synchronize(bhg_frame *f)
 const float *bhg_frame_device_image(bhg_frame *f) { return f ? f->image.as<float>() : nullptr; }
 
 int bhg_frame_stats(bhg_frame *f, uint64_t out[4])
-{
+try {
     if (!f || !out) return fail(BHG_E_INVALID, "bad argument");
     if (!f->rendered) return fail(BHG_E_INVALID, "no render yet");
     DeviceScope scope;
@@ -768,10 +799,12 @@ int bhg_frame_stats(bhg_frame *f, uint64_t out[4])
     out[2] = acc;
     out[3] = hor;
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 int bhg_frame_rebalance(bhg_frame *f, double root_share)
-{
+try {
     if (!f) return fail(BHG_E_INVALID, "frame is NULL");
     if (root_share == 0.0) root_share = 1.0;
     if (!(root_share > 0.0 && root_share <= 1.0)) return fail(BHG_E_INVALID, "root_share must be in (0, 1] (0 = 1)");
@@ -782,6 +815,8 @@ int bhg_frame_rebalance(bhg_frame *f, double root_share)
     f->root_share = root_share;
     deal_tiles(f);
     return build_root(f);
+} catch (...) {
+    return host_exception();
 }
 
 int bhg_frame_info(const bhg_frame *f, int64_t out[8])
@@ -808,7 +843,7 @@ int bhg_frame_set_profiling(bhg_frame *f, int enable)
 }
 
 int bhg_frame_last_ms(bhg_frame *f, float *trace_ms, float *root_ms)
-{
+try {
     if (!f || !trace_ms) return fail(BHG_E_INVALID, "bad argument");
     DeviceScope scope;
     bool any = false;
@@ -838,6 +873,8 @@ int bhg_frame_last_ms(bhg_frame *f, float *trace_ms, float *root_ms)
         }
     }
     return BHG_OK;
+} catch (...) {
+    return host_exception();
 }
 
 }  // extern "C"

@@ -19,6 +19,12 @@ namespace bhg {
 // root_share in (0, 1): device 0 -- the frame's owner, which also receives the gather and assembles the frame -- sits out
 // a fraction 1 - root_share of the dealing rounds (evenly spread), i.e. is dealt that share of an equal part (dist.py's
 // deal_sequence, restated); only with a cost ranking.
+// (the dealing counts tiles in int: a frame whose tile grid does not fit is refused by the callers)
+inline bool tile_grid_fits(int64_t W, int64_t H, int64_t T)
+{
+    return W > 0 && H > 0 && T > 0 && ((W + T - 1) / T) * ((H + T - 1) / T) <= (int64_t)INT32_MAX;
+}
+
 inline void deal_tiles_into(int W, int H, int T, int world, const double *cost, bool visit_by_cost, double root_share,
                      std::vector<std::vector<int64_t>> &out)
 {

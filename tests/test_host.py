@@ -178,6 +178,11 @@ def test_frame_object_host_side():
     seq = bdist.deal_sequence(8000, 8, 0.9)
     counts = np.bincount(seq, minlength=8)
     assert abs(counts[0] / counts[1:].mean() - 0.9) < 0.01 and counts[1:].max() - counts[1:].min() <= 1
+    # a tile grid the dealing's int counters cannot hold is refused at the boundary (no overflow, nothing allocated)
+    for W, H, T in ((2 ** 31 - 1, 2 ** 31 - 1, 1), (65536, 65536, 1), (2 ** 31 - 1, 3, 1)):
+        with pytest.raises(_ffi.BhgError) as e:
+            _ffi.deal_tiles(W, H, T, 2, 0)
+        assert e.value.code == _ffi.E_INVALID and "tiles" in str(e.value)
     assert np.array_equal(bdist.deal_sequence(20, 4, 1.0), np.arange(20) % 4)
     for bad in (dict(devices=[]), dict(devices=[0], gather=9), dict(devices=[0], width=0)):
         with pytest.raises(_ffi.BhgError) as ei:
