@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cfloat>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -281,6 +282,10 @@ bool is_pinned(const void *p)
     }
     return at.type == hipMemoryTypeHost;
 }
+
+// validate_tol (scipy _ivp/common.py:44-51): an rtol below 100 eps is raised to 100 eps -- scipy warns and carries on, and so
+// does every solve the reference runs through solve_ivp (README.md:196)
+inline double scipy_rtol(double rtol) { return rtol < 100.0 * DBL_EPSILON ? 100.0 * DBL_EPSILON : rtol; }
 
 int validate(const bhg_params *p)
 {
@@ -606,7 +611,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     a.r_s = p->r_s;
     a.lambda_end = p->lambda_end;
     a.max_step = p->max_step;
-    a.rtol = p->rtol;
+    a.rtol = scipy_rtol(p->rtol);
     a.atol = p->atol;
     a.h_fixed = p->h_fixed;
     a.r_exit = p->r_exit;
@@ -1372,7 +1377,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     a.r_s = p->r_s;
     a.lambda_end = p->lambda_end;
     a.max_step = p->max_step;
-    a.rtol = p->rtol;
+    a.rtol = scipy_rtol(p->rtol);
     a.atol = p->atol;
     a.h_fixed = p->h_fixed;
     a.r_exit = p->r_exit;

@@ -93,7 +93,7 @@ typedef struct bhg_params {
     double r_s;         /* horizon radius = 2*mass                 (RelativisticRenderEngine.py:95) */
     double lambda_end;  /* curve_end                               (:62, :294) */
     double max_step;    /* max_step; +inf for "unset" (-1)         (:57-60) */
-    double rtol;        /* DP54 relative tolerance, scipy default 1e-3 */
+    double rtol;        /* DP54 relative tolerance, scipy default 1e-3; below 100 eps it is raised to 100 eps, as solve_ivp does (_ivp/common.py:44-51) */
     double atol;        /* DP54 absolute tolerance, scipy default 1e-6 */
     double h_fixed;     /* RK4 step */
     double r_exit;      /* 0 = off; else terminate when r crosses r_exit outward */

@@ -844,8 +844,12 @@ static void bl_to_cart(const double q[3], const double u[3], double a, double x[
     for (int i = 0; i < 3; i++) k[i] = J[i][0] * u[0] + J[i][1] * u[1] + J[i][2] * u[2];
 }
 
-static void trace_one(const bhgo_params *p, const double x0[3], const double k0[3], ray_result *res, sampler_t *sm)
+static void trace_one(const bhgo_params *p_in, const double x0[3], const double k0[3], ray_result *res, sampler_t *sm)
 {
+    /* validate_tol (scipy _ivp/common.py:44-51): an rtol below 100 eps is raised to 100 eps (scipy warns and carries on) */
+    bhgo_params pc = *p_in;
+    if (pc.rtol < 100.0 * DBL_EPSILON) pc.rtol = 100.0 * DBL_EPSILON;
+    const bhgo_params *p = &pc;
     rayctx rc;
     memset(&rc, 0, sizeof(rc));
     rc.r_hor = p->r_s;

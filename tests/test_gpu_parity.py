@@ -838,6 +838,29 @@ def test_gpu_error_against_converged_solution(ctx, oracle):
     assert worst[1e-3] < 2e4 and worst[1e-5] < 400 and worst[1e-7] < 200, worst
 
 
+def test_rtol_below_100_eps_is_raised_like_scipy_does(ctx, oracle):
+    """scipy's validate_tol (_ivp/common.py:44-51) through the C ABI: rtol = 1e-15 is the solve at rtol = 100 eps, bit for bit
+    -- for the trace and for the sampled curves -- and lands where the checker lands (tests/test_oracle.py has scipy itself)."""
+    cam = np.array([0.5, 0.0, 8.0])
+    k = frame_rays(64, seed=78, fov=0.9)
+    kw = dict(r_s=1.0, lambda_end=12.0, atol=1e-30)
+    lo = 100 * np.finfo(float).eps
+    a = ctx.trace(k, cam, _params(rtol=1e-15, **kw))
+    b = ctx.trace(k, cam, _params(rtol=lo, **kw))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert not np.array_equal(ctx.trace(k, cam, _params(rtol=1e-13, **kw))[2], b[2])
+    ta = ctx.trajectory(k[:3], cam, _params(rtol=1e-15, **kw), 50)
+    tb = ctx.trajectory(k[:3], cam, _params(rtol=lo, **kw), 50)
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y, equal_nan=True)
+    o = oracle.trace(k, cam, rtol=1e-15, **kw)
+    esc = (a[1] == 4) & (o["flags"] == 4)
+    assert esc.sum() >= 30
+    assert np.abs(a[0][esc] - o["end"][esc]).max() < 1e-7
+    assert np.median(np.abs(a[2][esc].astype(float) / o["n_attempted"][esc] - 1.0)) < 0.02
+
+
 def test_nonfinite_input_is_flagged_not_hung(ctx):
     k = frame_rays(130, seed=29)
     k[3] = np.nan

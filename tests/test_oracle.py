@@ -33,6 +33,32 @@ def test_oracle_matches_live_scipy(oracle):
     assert np.abs(o["end"] - ref["end"]).max() < 5e-10
 
 
+def test_rtol_below_100_eps_is_raised_like_scipy_does(oracle):
+    """validate_tol (scipy _ivp/common.py:44-51): `rtol < 100 eps` is set to 100 eps with a warning -- every solve_ivp call
+    does that, so the restatement does: rtol = 1e-15 and 1e-18 are the solve at rtol = 100 eps, bit for bit, and what scipy
+    itself returns for rtol = 1e-15.  (At that tolerance the error estimate is rounding noise: step counts agree with scipy's
+    to a fraction of a percent, not step for step.)"""
+    import warnings
+    from oracle import scipy_reference as sr
+    cam = np.array([0.5, 0.0, 8.0])
+    k = frame_rays(4, seed=78, fov=0.9)
+    kw = dict(r_s=1.0, lambda_end=12.0, atol=1e-30)
+    floor = oracle.trace(k, cam, rtol=100 * np.finfo(float).eps, **kw)
+    for rtol in (1e-15, 1e-18):
+        o = oracle.trace(k, cam, rtol=rtol, **kw)
+        for key in ("end", "flags", "n_attempted", "n_accepted"):
+            assert np.array_equal(o[key], floor[key], equal_nan=(key == "end"))
+    assert not np.array_equal(oracle.trace(k, cam, rtol=1e-13, **kw)["n_attempted"], floor["n_attempted"])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ref = sr.trace_rays(k, cam, rtol=1e-15, form="christoffel", **kw)
+    assert any("rtol" in str(x.message) for x in w)
+    esc = (ref["flags"] == 4) & (floor["flags"] == 4)
+    assert esc.sum() >= 2
+    assert np.abs(floor["end"][esc] - ref["end"][esc]).max() < 1e-7
+    assert np.all(np.abs(floor["n_attempted"][esc].astype(float) / ref["n_attempted"][esc] - 1.0) < 0.02)
+
+
 def test_rhs_forms_agree(oracle):
     rng = np.random.default_rng(3)
     x = rng.normal(size=(500, 3)) * 6
