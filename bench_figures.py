@@ -402,10 +402,9 @@ def host_buffer_figures(ctx, fr, cam, params, n):
     # ... and an animation's form (config 4 is 100 frames): two frame objects on two host threads, each call blocking on its
     # own frame -- one frame's image crosses PCIe while the other frame is traced
     import threading
-    ctx2 = _ffi.Context(ctx.device)
     fo2 = _ffi.Frame([ctx.device], W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, origin=cam, jitter=jit)
     fo2.set_scene(sky)
-    img2 = ctx2.pinned.empty((H, W, 4), np.float32)
+    img2 = ctx.pinned.empty((H, W, 4), np.float32)
     fo2.render(params, out=img2)
     K2 = 10
     def _animate(f_, o_):
@@ -422,7 +421,6 @@ def host_buffer_figures(ctx, fr, cam, params, n):
                                 two_frames_identical=bool(np.array_equal(img2, img)),
                                 two_frames_what=f"{2 * K2} frames, two frame objects on two host threads (page-locked images): wall time per frame")
     fo2.close()
-    ctx2.close()
     fo.close()
     # the engine's literal per-ray call (RelativisticRenderEngine.py:293-294: one ray, nr_points_curve = 10000) through the
     # adaptor -- what a caller gets who swaps the integrator object and nothing else
