@@ -32,6 +32,7 @@
  * threads may run at the same time, on one device or several).  Host-buffer
  * calls block until the results are in the caller's buffers.  Device-buffer calls enqueue on the
  * given HIP stream and return; the library keeps no pointer after the call's work completes.
+ * Device buffers need only the alignment of their element type (8 bytes for the doubles, 4 for the counts).
  *
  * Errors: every int-returning function returns BHG_OK (0) or a negative BHG_E_* code;
  * bhg_last_error() gives a thread-local message for the last failure.  A refused device allocation is

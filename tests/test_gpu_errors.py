@@ -81,3 +81,38 @@ def test_a_refused_allocation_is_nomem_and_the_context_carries_on():
         if hog.value:
             h.hipFree(hog)
         c.close()
+
+
+def test_device_buffers_need_only_their_element_alignment(ctx):
+    """The device-buffer calls take whatever address a caller's array view has: buffers that start one ELEMENT into an
+    allocation (8 bytes for the doubles, 4 for the counts, 1 for the flags -- not the 16 bytes of the kernels' widest
+    stores) give the same bits as aligned ones, for the full records, the directions-only form and the Kerr kernel."""
+    import torch
+    from blackhole_geodesic_calculator_amd import _ffi as ffi
+    n = 70_001
+    k = frame_rays(n, seed=8)
+    st = torch.cuda.current_stream().cuda_stream
+    for kw in (dict(r_s=1.0, lambda_end=50.0), dict(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45),
+               dict(r_s=1.0, lambda_end=80.0, r_exit=40.0, disk_r_in=4.5, disk_r_out=10.5)):
+        p = ffi.make_params(**kw)
+        ref = ctx.trace(k, CAM, p)
+        dk = torch.zeros(n * 3 + 1, dtype=torch.float64, device="cuda")
+        dk[1:] = torch.from_numpy(k.reshape(-1)).cuda()
+        dend = torch.full((n * 6 + 1,), -7.0, dtype=torch.float64, device="cuda")
+        ddir = torch.full((n * 3 + 1,), -7.0, dtype=torch.float64, device="cuda")
+        dfl = torch.full((n + 1,), 255, dtype=torch.uint8, device="cuda")
+        dst = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        dac = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        ctx.trace_device(p, n, dk.data_ptr() + 8, dend.data_ptr() + 8, x0_shared=CAM, d_flags=dfl.data_ptr() + 1,
+                         d_n_steps=dst.data_ptr() + 4, d_n_accepted=dac.data_ptr() + 4, stream=st)
+        torch.cuda.synchronize()
+        assert np.array_equal(dend[1:].cpu().numpy().reshape(n, 6), ref[0], equal_nan=True)
+        assert np.array_equal(dfl[1:].cpu().numpy(), ref[1])
+        assert np.array_equal(dst[1:].cpu().numpy().astype(np.uint32), ref[2])
+        assert np.array_equal(dac[1:].cpu().numpy().astype(np.uint32), ref[3])
+        # (the element in front of each buffer is untouched)
+        assert dend[0].item() == -7.0 and dfl[0].item() == 255 and dst[0].item() == -1 and dac[0].item() == -1
+        if "disk_r_out" not in kw:
+            ctx.trace_dir_device(p, n, dk.data_ptr() + 8, ddir.data_ptr() + 8, x0_shared=CAM, d_flags=dfl.data_ptr() + 1, stream=st)
+            torch.cuda.synchronize()
+            assert np.array_equal(ddir[1:].cpu().numpy().reshape(n, 3), ref[0][:, 3:6], equal_nan=True) and ddir[0].item() == -7.0
