@@ -59,7 +59,8 @@ def _sensitivity(oracle, k0, x0, ref_end, **kw):
     k0 = np.asarray(k0, float)
     eps = np.finfo(float).eps
     pats = (np.nextafter(k0, np.inf), np.nextafter(k0, -np.inf), k0 * (1.0 + np.array([2.0, -2.0, 2.0]) * eps))
-    return np.max([np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1) for kp in pats], axis=0)
+    with np.errstate(invalid="ignore"):      # (inf - inf on rays whose fixed-step state overflowed: NaN, treated as "no bound" by the callers)
+        return np.max([np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1) for kp in pats], axis=0)
 
 
 def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0, **kw):
