@@ -25,6 +25,14 @@ elif what == "framesorted":
         return -abs(np.hypot(0.6 * (cx - 512) / 1024, 0.6 * (cy - 512) / 1024) - 2.598 / 30.0)
     fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6, pixels=bd.rank_pixels(1024, 1024, 32, 0, 1, tile_cost=tile_cost))
     p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
+elif what.startswith("shard"):
+    # rank 0's shard of a world-N dealing of the fixed frame (shard8, shard4 ...), tiles visited longest-first
+    from blackhole_geodesic_calculator_amd import dist as bd
+    def tile_cost(cx, cy):
+        return -abs(np.hypot(0.6 * (cx - 512) / 1024, 0.6 * (cy - 512) / 1024) - 2.598 / 30.0)
+    tile_cost.visit = "cost"
+    fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6, pixels=bd.rank_pixels(1024, 1024, 32, 0, int(what[5:]), tile_cost=tile_cost))
+    p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
 else:
     fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
     p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
