@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -208,6 +209,8 @@ struct bhg_frame {
     double root_share = 1.0;        // part of an equal share the first device is dealt (bhg_frame_rebalance)
     bool rendered = false;
     bool profiling = false;
+    bool peer_copy_always = false;  // BHG_FRAME_TEST_PEER_COPY=1 at bhg_frame_create: the gather's copies go through hipMemcpyPeerAsync also
+                                    // between contexts of ONE device (tests: the N-device call on a one-GPU box)
     std::vector<hipEvent_t> ev_root;   // around the root's gather + assembly (profiling)
     std::vector<hipEvent_t> ev_piece;  // the pieces of the image's way back to a pageable caller array
     hipEvent_t assembled = nullptr;    // the root has read the receive block of the last render (copies of the next wait for it)
@@ -454,6 +457,8 @@ try {
     if (!f) return fail(BHG_E_NOMEM, "host allocation failed");
     f->cam = *cam;
     f->tile = tile;
+    const char *tpc = std::getenv("BHG_FRAME_TEST_PEER_COPY");
+    f->peer_copy_always = tpc && tpc[0] == '1';
     std::memset(&f->scene, 0, sizeof(f->scene));
     f->scene.disk_mean = 0.2;   // the Limited engine's defaults (LimitedRelativisticRenderEngine.py:495-498)
     f->scene.disk_stddev = 0.3;
@@ -691,7 +696,7 @@ try {
                 // (the root must have read the previous render's slabs out of the receive block)
                 if (f->renders > 0) HIP_TRY(hipStreamWaitEvent(s.stream, f->assembled, 0));
                 float *dst = f->recv.as<float>() + r * slab_floats;
-                if (s.device == root.device)
+                if (s.device == root.device && !f->peer_copy_always)
                     HIP_TRY(hipMemcpyAsync(dst, s.slab.p, slab_floats * sizeof(float), hipMemcpyDeviceToDevice, s.stream));
                 else
                     HIP_TRY(hipMemcpyPeerAsync(dst, root.device, s.slab.p, s.device, slab_floats * sizeof(float), s.stream));
