@@ -880,6 +880,28 @@ def test_gpu_against_live_scipy(ctx, case):
     assert d[~hor].max(initial=0.0) < 1e-8 and d[hor].max(initial=0.0) < 1e-4, (d[~hor].max(initial=0.0), d[hor].max(initial=0.0))
 
 
+def test_gpu_kerr_against_live_scipy(ctx):
+    """Config 5's metric against solve_ivp on the sympy-generated Boyer-Lindquist right-hand side
+    (oracle/scipy_reference.py trace_ray_kerr), off the polar axis: flags and accepted steps identical, attempted steps
+    identical, end states of escaping rays within the stated 5e-8 (horizon rays end at the coordinate singularity)."""
+    from oracle import scipy_reference as sr
+    inc = np.radians(60.0)
+    cam = np.array([30 * np.sin(inc), 0.3, 30 * np.cos(inc)])
+    rng = np.random.default_rng(11)
+    aim = rng.normal(size=(120, 3)) * 3.0
+    k = aim - cam
+    k /= np.linalg.norm(k, axis=1)[:, None]
+    ref = [sr.trace_ray_kerr(kk, cam, M=0.5, a=0.45, lambda_end=60.0) for kk in k]
+    end, flags, steps, acc = ctx.trace(k, cam, _params(r_s=1.0, lambda_end=60.0, rhs_form=2, spin=0.45))
+    rf = np.array([r["flags"] for r in ref], dtype=np.uint8)
+    assert np.array_equal(flags, rf) and ((flags & 1) != 0).sum() >= 5 and (flags == 4).sum() >= 50
+    differ = (steps != np.array([r["n_attempted"] for r in ref])) | (acc != np.array([r["n_accepted"] for r in ref]))
+    assert differ.sum() <= 1, int(differ.sum())     # (3.6e-6 of the off-axis full-size frame's rays differ from the checker)
+    d = np.abs(end - np.array([r["end"] for r in ref])).max(1)
+    esc = (flags == 4) & ~differ
+    assert d[esc].max() < 5e-8, d[esc].max()
+
+
 def test_rtol_below_100_eps_is_raised_like_scipy_does(ctx, oracle):
     """scipy's validate_tol (_ivp/common.py:44-51) through the C ABI: rtol = 1e-15 is the solve at rtol = 100 eps, bit for bit
     -- for the trace and for the sampled curves -- and lands where the checker lands (tests/test_oracle.py has scipy itself)."""
