@@ -880,6 +880,38 @@ def test_gpu_against_live_scipy(ctx, case):
     assert d[~hor].max(initial=0.0) < 1e-8 and d[hor].max(initial=0.0) < 1e-4, (d[~hor].max(initial=0.0), d[hor].max(initial=0.0))
 
 
+def test_gpu_sampled_curves_against_live_scipy(ctx):
+    """Row a2's literal call -- calc_trajectory(..., nr_points_curve=T), RelativisticRenderEngine.py:293-294 -- on the GPU against
+    solve_ivp(..., t_eval=linspace(0, curve_end, T)) itself: the same number of samples per ray (a ray that ends on an event
+    yields the grid points up to the root, ivp.py:706-723), the same values to rounding, NaN behind them."""
+    from oracle import scipy_reference as sr
+    g = load_golden("fig5")
+    cases = [(g["k0"], g["x0"], dict(r_s=1.0, lambda_end=60.0), 121),
+             (frame_rays(24, seed=193), CAM, dict(r_s=1.0, lambda_end=50.0), 50),
+             (frame_rays(24, seed=194, fov=0.25), CAM, dict(r_s=1.0, lambda_end=70.0, r_exit=31.0), 77),
+             (frame_rays(12, seed=195, fov=0.25), CAM, dict(r_s=1.0, lambda_end=50.0, max_step=0.5, rhs_form=1), 33),
+             (frame_rays(1, seed=196), CAM, dict(r_s=1.0, lambda_end=50.0), 10000)]      # the engine's literal call: one ray, 10 000 samples
+    seen = {}
+    for k, x0, kw, T in cases:
+        k = np.atleast_2d(k)
+        tr, nv, end, fl = ctx.trajectory(k, x0, _params(**kw), T)
+        for i in range(len(k)):
+            xi = x0 if np.ndim(x0) == 1 else x0[i]
+            r = sr.trace_ray(k[i], xi, r_s=kw["r_s"], lambda_end=kw["lambda_end"], max_step=kw.get("max_step", np.inf),
+                             form="reduced" if kw.get("rhs_form") == 1 else "christoffel", r_exit=kw.get("r_exit", 0.0),
+                             nr_points_curve=T)
+            sol = r["sol"]
+            assert int(fl[i]) == r["flags"], (i, int(fl[i]), r["flags"])
+            seen[int(fl[i])] = seen.get(int(fl[i]), 0) + 1
+            m = sol.y.shape[1]
+            assert nv[i] == m, (i, int(nv[i]), m)
+            want = np.stack([sol.y[1], sol.y[3], sol.y[5], sol.y[0], sol.y[2], sol.y[4]])
+            d = np.abs(tr[i, :, :m] - want).max()
+            assert d < (1e-8 if not (int(fl[i]) & 1) else 1e-5), (i, d)
+            assert np.isnan(tr[i, :, m:]).all()
+    assert seen.get(1, 0) >= 5 and seen.get(4, 0) >= 20 and seen.get(8, 0) >= 10, seen
+
+
 def test_gpu_kerr_against_live_scipy(ctx):
     """Config 5's metric against solve_ivp on the sympy-generated Boyer-Lindquist right-hand side
     (oracle/scipy_reference.py trace_ray_kerr), off the polar axis: flags and accepted steps identical, attempted steps
