@@ -95,7 +95,8 @@ typedef struct bhg_params {
     double lambda_end;  /* curve_end                               (:62, :294) */
     double max_step;    /* max_step; +inf for "unset" (-1)         (:57-60) */
     double rtol;        /* DP54 relative tolerance, scipy default 1e-3; below 100 eps it is raised to 100 eps, as solve_ivp does (_ivp/common.py:44-51) */
-    double atol;        /* DP54 absolute tolerance, scipy default 1e-6 */
+    double atol;        /* DP54 absolute tolerance, scipy default 1e-6; must be > 0 (solve_ivp takes 0 too and then fails on the first state
+                           component that is exactly zero -- scale = 0 -- with "step size too small": refused here up front) */
     double h_fixed;     /* RK4 step */
     double r_exit;      /* 0 = off; else terminate when r crosses r_exit outward */
     int32_t method;     /* BHG_METHOD_* */
