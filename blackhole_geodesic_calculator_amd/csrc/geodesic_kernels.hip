@@ -2752,8 +2752,10 @@ __global__ void __launch_bounds__(256) kerr_finalize_kernel(const TraceArgs A, d
 // call, ONE ray with nr_points_curve = 10000 (:293-294): a single lane spent 1.9 ms of its 2.0 ms evaluating 10,000
 // dense-output points one after the other.
 // ------------------------------------------------------------------------------------------
+// (WAVE: the workgroup is one wave -- or, for a handful of rays with many samples each, several waves that ALL integrate the ray,
+// every lane alike, and share the samples of each step between them: no hand-off, no barrier; blockDim.x samples per pass)
 template <int RHS, bool WAVE, bool FIXED>
-__global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, double *traj, uint32_t *n_valid,
+__global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const TraceArgs A, double *traj, uint32_t *n_valid,
                                                              uint32_t T)
 {
     const uint32_t lane = threadIdx.x;
@@ -2784,7 +2786,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             r0 = sqrt(__builtin_fma(x[2], x[2], __builtin_fma(x[1], x[1], x[0] * x[0])));
         }
         if (r0 <= A.r_hor) {    // 'start_inside_hole' (RelativisticRenderEngine.py:296, :311-313)
-            for (uint32_t j = lane; j < 6 * T; j += 64) out[j] = __builtin_nan("");
+            for (uint32_t j = lane; j < 6 * T; j += blockDim.x) out[j] = __builtin_nan("");
             if (lane == 0) {
                 n_valid[i] = 0;
                 store_result(A, (uint32_t)i, cx, ck, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
@@ -2972,7 +2974,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
             while (g > next && !(te_of(g - 1) <= t_stop)) g--;
             while (g < T && te_of(g) <= t_stop) g++;
             first = next + lane;
-            stride = 64;
+            stride = blockDim.x;
             last = g;
             next = g;
         }
@@ -3028,7 +3030,7 @@ __global__ void __launch_bounds__(64) trajectory_dp54_kernel(const TraceArgs A, 
         }
     }
     if (WAVE) {     // samples the ray never reached read back as NaN
-        for (uint32_t j = next + lane; j < T; j += 64)
+        for (uint32_t j = next + lane; j < T; j += blockDim.x)
             for (int c = 0; c < 6; c++) out[(uint64_t)c * T + j] = __builtin_nan("");
         if (lane != 0) return;
     }
@@ -3050,7 +3052,10 @@ static void launch_trajectory_rhs_m(const TraceArgs &a, double *traj, uint32_t *
 {
     const unsigned gp = (unsigned)((a.n + 255) / 256), gt = (unsigned)((a.n + 63) / 64);
     if (trajectory_wave_per_ray(a.n)) {
-        BHG_LAUNCH((trajectory_dp54_kernel<RHS, true, FIXED>), dim3((unsigned)a.n), dim3(64), 0, s, a, traj, n_valid, T);
+        // the engine's literal call is ONE ray with 10,000 samples: four waves share the samples (the step loop itself is one
+        // wave's work however many run it: 43 us of the call; the samples 27 us with one wave)
+        const unsigned threads = (a.n <= 64 && T >= 1024) ? 256u : 64u;   // (four waves = one per SIMD of a CU; eight measured slower than one)
+        BHG_LAUNCH((trajectory_dp54_kernel<RHS, true, FIXED>), dim3((unsigned)a.n), dim3(threads), 0, s, a, traj, n_valid, T);
     } else {
         BHG_LAUNCH((prepare_kernel<RHS, !FIXED>), dim3(gp), dim3(256), 0, s, a);
         BHG_LAUNCH((trajectory_dp54_kernel<RHS, false, FIXED>), dim3(gt), dim3(64), 0, s, a, traj, n_valid, T);

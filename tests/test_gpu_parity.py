@@ -1135,6 +1135,15 @@ def test_trajectory_kernel_shapes_give_the_same_bits(ctx):
             assert np.array_equal(a[:500], b, equal_nan=True)
         nv, flags = sub[1], sub[3]
         assert (nv == T).any() and ((nv < T) & ((flags & 1) != 0)).any()
+    # ... and up to 64 rays with 1024 samples or more, FOUR waves per ray share the samples (all four integrate the ray, every
+    # lane alike): the same bits again, horizon rays and a sample count that is no multiple of 256 included
+    k5 = frame_rays(70, seed=53, fov=0.16)
+    for kw in (dict(r_s=1.0, lambda_end=50.0), dict(r_s=1.0, lambda_end=40.0, rhs_form=2, spin=0.45), dict(r_s=1.0, lambda_end=50.0, method=1, h_fixed=0.25)):
+        one = ctx.trajectory(k5, CAM if kw.get("rhs_form") != 2 else np.array([2.0, -24.0, 14.0]), _params(**kw), 1500)          # 70 rays: one wave each
+        four = ctx.trajectory(k5[:40], CAM if kw.get("rhs_form") != 2 else np.array([2.0, -24.0, 14.0]), _params(**kw), 1500)    # 40 rays: four waves each
+        for a, b in zip(one, four):
+            assert np.array_equal(a[:40], b, equal_nan=True)
+        assert (four[1] == 1500).any() and ("rhs_form" in kw or (four[1] < 1500).any())    # (the Kerr camera looks past the hole)
     # the literal call's size, against a per-sample restatement of t_eval's rule: sample j is there iff its time
     # j * dt (the last one: curve_end) does not lie beyond where the ray ends
     k3 = np.array([[b / 30.0, 0.0, -1.0] for b in (5.0, 8.0, 12.0)])
