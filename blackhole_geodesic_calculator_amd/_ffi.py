@@ -230,8 +230,9 @@ def load():
     L.bhg_shade_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.bhg_trajectory.restype = C.c_int
-    L.bhg_trajectory.argtypes = [C.c_void_p, C.POINTER(Params), _dp, C.c_int, _dp, C.c_size_t, C.c_uint32, _dp,
-                                 _u32p, _dp, _u8p]
+    # (raw addresses: building a typed ctypes pointer costs ~2 us per array, and the engine's literal call is one ray long)
+    L.bhg_trajectory.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
     L.bhg_set_profiling.restype = C.c_int
     L.bhg_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.bhg_last_pass_ms.restype = C.c_int
@@ -329,6 +330,11 @@ def device_count() -> int:
 
 def _np_dp(a):
     return a.ctypes.data_as(_dp)
+
+
+def _addr(a):
+    """The address of a numpy array's first element (for void* parameters)."""
+    return a.__array_interface__["data"][0]
 
 
 class _PinnedBlock:
@@ -720,9 +726,8 @@ class Context:
         nv = np.empty(n, np.uint32)
         end = np.empty((n, 6), np.float64)
         flags = np.empty(n, np.uint8)
-        _check(load().bhg_trajectory(self._h, C.byref(params), _np_dp(x0), 1 if shared else 0, _np_dp(k0), n,
-                                     int(n_points), _np_dp(traj), nv.ctypes.data_as(_u32p), _np_dp(end),
-                                     flags.ctypes.data_as(_u8p)))
+        _check(load().bhg_trajectory(self._h, C.byref(params), _addr(x0), 1 if shared else 0, _addr(k0), n,
+                                     int(n_points), _addr(traj), _addr(nv), _addr(end), _addr(flags)))
         return traj, nv, end, flags
 
     # -- device buffers (raw addresses, e.g. torch.Tensor.data_ptr()) -------------------
