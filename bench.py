@@ -166,6 +166,17 @@ def self_launch(n_gpus):
     raise SystemExit(rc)
 
 
+def secondary(out, key, fn):
+    """A secondary figure of the line: whatever goes wrong in it is recorded under its key and does not cost the line its
+    headline, its roofline block or the CPU baseline."""
+    try:
+        val = fn()
+        if val is not None:
+            out[key] = val
+    except Exception as e:   # noqa: BLE001
+        out[key] = {"error": f"{type(e).__name__}: {e}"}
+
+
 def build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky):
     """The DeviceFrames one step passes over (and, disk workload, the batch that traces them with one call)."""
     from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame, FrameBatch, synthetic_sky
@@ -571,42 +582,48 @@ def main():
             # names -- "exit position/direction written back" -- and the headline) against the exit directions alone that a
             # sky frame reads (57 B/ray; background_hit, :366-378)
             other_dir = not getattr(fr, "_dir_traced", False)
-            fro = DeviceFrame(rt.ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=CAM,
-                              pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=other_dir)
-            fro.d_k0 = fr.d_k0
-            fro.set_sky(sky)
-            ms_f, call_f, steps_f = time_frame(fro, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
-            out["sky_frame_dir_only" if other_dir else "full_records"] = {
-                "value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
-                "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "algorithmic_bytes_per_ray": BYTES_PER_RAY_DIR if other_dir else BYTES_PER_RAY,
-                "what": ("the same frame and K / W with only the exit directions written (24 B/ray: all a sky frame reads of its rays) and "
-                         "shaded from them" if other_dir else
-                         "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them")}
-            del fro
+
+            def other_output_form():
+                fro = DeviceFrame(rt.ctx, W, H, S, fov_x=fr.fov_x, fov_y=fr.fov_y, sampling_seed=42.0, origin=CAM,
+                                  pixels=fr.d_pixels.cpu().numpy(), jitter=np.zeros(2), directions_only=other_dir)
+                fro.d_k0 = fr.d_k0
+                fro.set_sky(sky)
+                ms_f, call_f, steps_f = time_frame(fro, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
+                return {
+                    "value": n / (ms_f * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_f, "trace_call_ms": call_f,
+                    "frac": steps_f * F / (call_f * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                    "algorithmic_bytes_per_ray": BYTES_PER_RAY_DIR if other_dir else BYTES_PER_RAY,
+                    "what": ("the same frame and K / W with only the exit directions written (24 B/ray: all a sky frame reads of its rays) and "
+                             "shaded from them" if other_dir else
+                             "the same frame and K / W with whole end states written (x, k: 48 B/ray) and shaded from them")}
+            secondary(out, "sky_frame_dir_only" if other_dir else "full_records", other_output_form)
         if world == 1 and a.workload == "frame" and a.regime == "adaptive" and not a.lean:
             # SURVEY section 8d asks for both step regimes: the fine one (max_step 0.1, ~490 steps per ray) and the fixed-step RK4
             # (h = 0.1, 500 steps per ray) on the same frame, a few steps each (40 and 16 ms per step), same output form
-            import copy
-            regs = {}
-            for reg in ("fine", "rk4"):
-                a2 = copy.copy(a)
-                a2.regime = reg
-                w2 = Workload(a2)
-                ms_r, call_r, steps_r = time_frame(fr, w2.params, 10, 2, device=rt.local_rank, ramp=0.0)
-                regs[reg] = {"value": n / (ms_r * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_r, "ray_steps_per_s": steps_r / (ms_r * 1e-3),
-                             "attempted_steps_per_ray": steps_r / n, "flop_per_ray_step": w2.flop,
-                             "frac": steps_r * w2.flop / (call_r * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                             "what": ("DP5(4), max_step = 0.1 (the Cam edition's pickle-name value)" if reg == "fine" else "classic RK4, h = 0.1") +
-                                     ", 10 timed steps after 2 warm-up steps; frac from the trace call's HIP-event time"}
-            out["regimes"] = regs
-            fr.trace(wl.params)      # (leave the frame's buffers holding the adaptive result)
+            def regimes():
+                import copy
+                regs = {}
+                for reg in ("fine", "rk4"):
+                    a2 = copy.copy(a)
+                    a2.regime = reg
+                    w2 = Workload(a2)
+                    ms_r, call_r, steps_r = time_frame(fr, w2.params, 10, 2, device=rt.local_rank, ramp=0.0)
+                    regs[reg] = {"value": n / (ms_r * 1e-3) / 1e6, "unit": "Mrays/s", "ms_per_step": ms_r, "ray_steps_per_s": steps_r / (ms_r * 1e-3),
+                                 "attempted_steps_per_ray": steps_r / n, "flop_per_ray_step": w2.flop,
+                                 "frac": steps_r * w2.flop / (call_r * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                                 "what": ("DP5(4), max_step = 0.1 (the Cam edition's pickle-name value)" if reg == "fine" else "classic RK4, h = 0.1") +
+                                         ", 10 timed steps after 2 warm-up steps; frac from the trace call's HIP-event time"}
+                fr.trace(wl.params)      # (leave the frame's buffers holding the adaptive result)
+                return regs
+            secondary(out, "regimes", regimes)
         if world == 1 and a.workload == "frame" and a.emulate_shards.strip():
-            t1_ms, t1_call, _ = time_frame(fr, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
-            out["strong_predicted"] = strong_predicted(rt, wl, sky, m, (t1_ms, t1_call))
+            def predicted():
+                t1_ms, t1_call, _ = time_frame(fr, wl.params, a.steps, a.warmup, device=rt.local_rank, ramp=a.ramp_seconds)
+                return strong_predicted(rt, wl, sky, m, (t1_ms, t1_call))
+            secondary(out, "strong_predicted", predicted)
         if world == 1 and a.workload == "frame" and a.cpu_seconds > 0:   # (--cpu-seconds 0 = kernels only: profiling runs)
-            out["pipelined"] = pipelined_figure(rt, fr, wl.params, a)
-            out["host_buffer_call"] = host_buffer_figures(rt.ctx, fr, CAM, wl.params, n)
+            secondary(out, "pipelined", lambda: pipelined_figure(rt, fr, wl.params, a))
+            secondary(out, "host_buffer_call", lambda: host_buffer_figures(rt.ctx, fr, CAM, wl.params, n))
         if a.cpu_seconds > 0 and world == 1:   # the CPU baseline is an N = 1 figure (rank 0's host cores, nothing else running)
             okw = dict(wl.okw)
             if a.workload == "orbit":
