@@ -361,23 +361,34 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
     # warm-up, or only afterwards: the headline measures the same to 0.2 %, profiles/r05_probe_when_ab.log)
     calibrate = not overlap and not whole_frames and not a.lean
     calibration, sampler = {}, None
+    def probes(when):        # (a probe that fails leaves the line without that part of `calibration`, not without its headline)
+        try:
+            calibration[when] = run_probes(rt.ctx, rt.local_rank)
+        except Exception as e:   # noqa: BLE001
+            calibration[when + "_error"] = f"{type(e).__name__}: {e}"
     if calibrate:
-        calibration["before"] = run_probes(rt.ctx, rt.local_rank)
+        probes("before")
         barrier()
     for i in range(a.warmup):
         step(i, False)
     barrier()
     if calibrate:
         # ... and the shader clock, sampled from sysfs while the region runs (measured: no effect on the region's time)
-        sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
+        try:
+            sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
+        except Exception:   # noqa: BLE001
+            sampler = None
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
     barrier(final=True)
     dt = time.perf_counter() - t0
-    sclk = sampler.stop() if sampler is not None else None
+    try:
+        sclk = sampler.stop() if sampler is not None else None
+    except Exception:   # noqa: BLE001
+        sclk = None
     if calibrate:
-        calibration["after"] = run_probes(rt.ctx, rt.local_rank)
+        probes("after")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -628,7 +639,7 @@ def main():
             okw = dict(wl.okw)
             if a.workload == "orbit":
                 okw["spheres"] = wl.orbit_scene(a.steps - 1)[0]
-            out["cpu_baseline"] = cpu_baseline(fr.d_k0.cpu().numpy(), fr.origin, a, okw)
+            secondary(out, "cpu_baseline", lambda: cpu_baseline(fr.d_k0.cpu().numpy(), fr.origin, a, okw))
     rt.close()
     if rank == 0:
         emit(out)
