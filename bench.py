@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from bench_common import (BYTES_PER_RAY, BYTES_PER_RAY_DIR, CAM, DISK, EV_EVERY, PEAK_FP64_VALU_TFLOPS, ClockSampler, Lanes, Runtime,  # noqa: F401
-                          Workload, emit, grid_for, roofline_block, run_probes, traced_with_events)
+                          Workload, emit, grid_for, hbm_copy_probe, merge_clock_samples, roofline_block, run_probes, spread, traced_with_events)
 from bench_figures import (counters_for, host_buffer_figures, live_pmc, main_single_process, pipelined_figure,  # noqa: F401
                            pmc_traffic, strong_predicted, time_frame)
 
@@ -63,6 +63,16 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="the headline's timed region -- EXACTLY --steps steps between barrier + synchronise -- is run this many times "
+                         "back to back; every repetition's ms per step goes into the line (ms_per_step_samples), the headline is "
+                         "their MEDIAN (a 20-step region is 28 ms: one number of it cannot tell a slow box from a transient); "
+                         "1 = the single region of rounds 1-5")
+    ap.add_argument("--probe-when", choices=["after_only", "before_warmup", "before_timed", "off"],
+                    default=os.environ.get("BHGEO_PROBE_WHEN", "after_only"),
+                    help="where the roofline calibration probes (bhg_peak_probe, power-bound pure-FMA launches, 25 ms) run relative to "
+                         "the headline's timed region: after_only (default since round 6: nothing power-hungry in front of a short "
+                         "region), before_warmup (round 5: in front of the W warm-up steps, and again afterwards), before_timed, off")
     ap.add_argument("--ramp-seconds", type=float, default=0.3,
                     help="untimed steps run before the W warm-up steps until this much wall time has passed: the "
                          "GPU's clocks take tens of milliseconds of load to settle (a 20-step timed region right "
@@ -200,7 +210,7 @@ def build_frames(rt, wl, W, H, S, fov_x, fov_y, pixels, jitter, sky):
     return frames, batch
 
 
-def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
+def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1):
     """One timed region over a frame of (width * nx) x (height * ny) pixels sharded over the ranks.
     Returns the figures of this rank (dt already the maximum over ranks).
       overlap (frame workload): two frames in flight -- consecutive frames alternate between two streams / contexts.
@@ -356,43 +366,60 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
             if float(go.item()) == 0.0:
                 break
         barrier()
-    # roofline calibration (bhg_peak_probe: the fp64 rate THIS box sustains) before and after the headline's timed region --
-    # outside its clock; the probes in front run before the warm-up steps (right before the timed region, before the
-    # warm-up, or only afterwards: the headline measures the same to 0.2 %, profiles/r05_probe_when_ab.log)
-    calibrate = not overlap and not whole_frames and not a.lean
+    # roofline calibration (bhg_peak_probe: the fp64 rate THIS box sustains) -- outside the headline's clock.  Since round 6
+    # the probes run AFTER the timed region only (--probe-when after_only): they are power-bound pure-FMA launches, and the
+    # driver's command times a 28-ms region five warm-up steps behind them (profiles/r06_driver_cmd_ab.log)
+    calibrate = not overlap and not whole_frames and not a.lean and a.probe_when != "off"
     calibration, sampler = {}, None
     def probes(when):        # (a probe that fails leaves the line without that part of `calibration`, not without its headline)
         try:
             calibration[when] = run_probes(rt.ctx, rt.local_rank)
         except Exception as e:   # noqa: BLE001
             calibration[when + "_error"] = f"{type(e).__name__}: {e}"
-    if calibrate:
+    if calibrate and a.probe_when == "before_warmup":
         probes("before")
         barrier()
     for i in range(a.warmup):
         step(i, False)
     barrier()
-    if calibrate:
-        # ... and the shader clock, sampled from sysfs while the region runs (measured: no effect on the region's time)
+    if calibrate and a.probe_when == "before_timed":
+        probes("before")
+        barrier()
+    # The timed region: EXACTLY K steps between barrier + synchronise on both sides -- `reps` times back to back, every
+    # repetition with its own wall clock, its own HIP-event samples and its own shader-clock samples (sysfs, a thread:
+    # measured neutral).  The headline is the MEDIAN repetition; all of them go into the line.
+    dts, sclks, rep_events = [], [], []
+    for rep in range(max(1, reps)):
+        sampler = None
+        if not overlap and not whole_frames and not a.lean and rank == 0:
+            try:
+                sampler = ClockSampler(rt.local_rank).start()
+            except Exception:   # noqa: BLE001
+                sampler = None
+        n_ev = len(kernel_ms)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i, True)
+        barrier(final=True)
+        dt_rep = time.perf_counter() - t0
         try:
-            sampler = ClockSampler(rt.local_rank).start() if rank == 0 else None
+            sclks.append(sampler.stop() if sampler is not None else None)
         except Exception:   # noqa: BLE001
-            sampler = None
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, True)
-    barrier(final=True)
-    dt = time.perf_counter() - t0
-    try:
-        sclk = sampler.stop() if sampler is not None else None
-    except Exception:   # noqa: BLE001
-        sclk = None
+            sclks.append(None)
+        if world > 1:
+            tmax = torch.tensor([dt_rep], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_rep = float(tmax.item())
+        dts.append(dt_rep)
+        rep_events.append(kernel_ms[n_ev:])
+    dt = float(np.median(dts))
+    sclk = merge_clock_samples(sclks)
     if calibrate:
         probes("after")
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        try:
+            calibration["hbm_copy_GBps"] = hbm_copy_probe()
+        except Exception as e:   # noqa: BLE001
+            calibration["hbm_copy_error"] = f"{type(e).__name__}: {e}"
 
     # the frame really is the frame: rank 0's assembled image against a shade of ITS OWN pixels at their places
     # (outside the timed region; catches a slab / pixel-order mismatch)
@@ -404,11 +431,12 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
         assert torch.equal(img[fr.d_pixels], own), "assembled frame does not hold rank 0's pixels at their places"
 
     ray_steps = sum(int(f.d_steps.to(torch.int64).sum().item()) for f in frames)
-    # per step: the trace calls of all its frames (HIP events on the stream the library launches on)
-    n_sampled = len(range(0, a.steps, EV_EVERY))
-    if whole_frames:
-        n_sampled = max(1, len(kernel_ms))
-    call_ms = float(np.sum([e0.elapsed_time(e1) for e0, e1 in kernel_ms])) / max(n_sampled, 1) if kernel_ms else float("nan")
+    # per step: the trace calls of all its frames (HIP events on the stream the library launches on); one sample = one
+    # step's call(s).  Every sample goes into the line; kernel_ms is their MEDIAN times the trace kernel's share (below)
+    call_samples = [[float(e0.elapsed_time(e1)) for e0, e1 in evs] for evs in rep_events]
+    flat = [x for r_ in call_samples for x in r_]
+    call_ms = float(np.median(flat)) if flat else float("nan")
+    call_ms_mean = float(np.mean(flat)) if flat else float("nan")
     # the dominant kernel alone: one launch per call finishes every ray (events are located and resumed rays
     # carry on inside trace_*_kernel); Kerr adds a prepare and a finalize launch.  A few extra profiled calls
     # after the timed region (HIP events recorded by the library around prepare | trace on this same stream)
@@ -432,7 +460,8 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False):
         lanes.close()
     return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                 steps_all=float(tot[1].item()), launch=rt.ctx.last_launch(), fr=fr, tcost=tcost,
-                visit=tile_cost.visit, root_share=root_share, calibration=calibration, sclk=sclk)
+                visit=tile_cost.visit, root_share=root_share, calibration=calibration, sclk=sclk,
+                dts=dts, sclks=sclks, call_samples=call_samples, call_ms_mean=call_ms_mean, share=share)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -513,9 +542,9 @@ def main():
     world, rank = rt.world, rt.rank
 
     nx, ny = grid_for(world) if a.workload != "orbit" else (1, 1)   # orbit: ONE fixed frame over all ranks
-    m = measure(rt, wl, sky, nx, ny, a.ramp_seconds)
+    m = measure(rt, wl, sky, nx, ny, a.ramp_seconds, reps=a.reps)
     strong = frames_sharded = None
-    per_step = lambda r: r["dt"] / a.steps    # noqa: E731
+    per_step = lambda r: r["dt"] / a.steps    # noqa: E731  (dt = the median repetition of the region)
     if world > 1 and a.workload != "orbit":
         # BASELINE.json's metric read as strong scaling: ONE fixed frame of the single-GPU size over all ranks.  The
         # headline of the sharded path has two frames in flight per rank (consecutive frames on alternating streams): a
@@ -557,6 +586,10 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
+            # every repetition of the K-step region, in the order they ran (ms per step): the headline is their median
+            "ms_per_step_samples": [d_ / a.steps * 1e3 for d_ in m["dts"]],
+            "ms_per_step_spread": spread([d_ / a.steps * 1e3 for d_ in m["dts"]]),
+            "sclk_mhz_per_repetition": [None if c is None else round(c["mean_mhz"], 1) for c in m["sclks"]],
             "higher_is_better": True,
             "scaling": "strong" if a.workload == "orbit" else "weak",
             "vs_baseline": None,
@@ -575,9 +608,13 @@ def main():
                 "parallelism": f"one process per GPU (torch.distributed), {world} rank(s)",
                 "root_share": m["root_share"],
                 "launch": m["launch"],
+                "timed_region": f"{len(m['dts'])} repetition(s) of EXACTLY {a.steps} steps between barrier + synchronise (max over ranks each), "
+                                f"after {a.warmup} warm-up steps; value / ms_per_step = the MEDIAN repetition, every repetition in "
+                                f"ms_per_step_samples; calibration probes: {a.probe_when}",
             },
             "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64,
-                                       calibration=m["calibration"], sclk=m["sclk"]),
+                                       calibration=m["calibration"], sclk=m["sclk"], call_samples=m["call_samples"], share=m["share"],
+                                       num_cus=rt.ctx.num_cus()),
         }
         if a.workload == "frame":
             out["config"]["north_star_output"] = ("exit directions only (--dir-only)" if getattr(fr, "_dir_traced", False) else

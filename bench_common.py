@@ -264,10 +264,15 @@ class ClockSampler:
                 self.path = c
         self.pci = want
 
-    def _read(self):
+    # what else hwmon shows of the same card, sampled at the same instants when readable (round 6: a box can be slow in
+    # something other than the shader clock): memory clock, socket power, junction temperature
+    EXTRA = {"mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_average", 1e-6), "power_input_w": ("power1_input", 1e-6),
+             "temp_junction_c": ("temp2_input", 1e-3)}
+
+    def _read(self, path=None, scale=1e-6):
         try:
-            with open(self.path) as f:
-                return float(f.read().strip()) * 1e-6     # Hz -> MHz
+            with open(path or self.path) as f:
+                return float(f.read().strip()) * scale     # Hz -> MHz
         except Exception:
             return None
 
@@ -278,12 +283,20 @@ class ClockSampler:
             self.path = None
             return self
         import threading
+        d = os.path.dirname(self.path)
+        self.extra_paths = {k: (os.path.join(d, f), sc) for k, (f, sc) in self.EXTRA.items()
+                            if self._read(os.path.join(d, f), sc) is not None}
+        self.extra = {k: [] for k in self.extra_paths}
 
         def loop():
             while not self._stop:
                 v = self._read()
                 if v is not None:
                     self.samples.append(v)
+                for k, (pth, sc) in self.extra_paths.items():
+                    x = self._read(pth, sc)
+                    if x is not None:
+                        self.extra[k].append(x)
                 time.sleep(self.period)
         self._t = threading.Thread(target=loop, daemon=True)
         self._t.start()
@@ -296,8 +309,40 @@ class ClockSampler:
         if not self.samples:
             return None
         v = np.array(self.samples)
-        return {"mean_mhz": float(v.mean()), "min_mhz": float(v.min()), "max_mhz": float(v.max()), "samples": int(len(v)),
-                "source": self.path, "pci": self.pci}
+        out = {"mean_mhz": float(v.mean()), "min_mhz": float(v.min()), "max_mhz": float(v.max()), "samples": int(len(v)),
+               "source": self.path, "pci": self.pci}
+        for k, xs in getattr(self, "extra", {}).items():
+            if xs:
+                out[k] = float(np.mean(xs))
+        return out
+
+
+def spread(xs):
+    """min / median / max (and their relative spread) of a list of samples."""
+    v = np.asarray([x for x in xs if x is not None and np.isfinite(x)], dtype=float)
+    if v.size == 0:
+        return None
+    return {"n": int(v.size), "min": float(v.min()), "median": float(np.median(v)), "max": float(v.max()),
+            "rel_spread": float((v.max() - v.min()) / np.median(v))}
+
+
+MIN_CLOCK_SAMPLES = 16   # below this the clock-scaled peak is not reported (a 28-ms region gives 7 samples at 4 ms)
+
+
+def merge_clock_samples(sclks):
+    """The ClockSampler summaries of the repetitions as one (all samples pooled)."""
+    got = [c for c in sclks if isinstance(c, dict)]
+    if not got:
+        return None
+    n = sum(c["samples"] for c in got)
+    out = {"mean_mhz": sum(c["mean_mhz"] * c["samples"] for c in got) / n, "min_mhz": min(c["min_mhz"] for c in got),
+           "max_mhz": max(c["max_mhz"] for c in got), "samples": int(n), "repetitions": len(got),
+           "source": got[0]["source"], "pci": got[0]["pci"]}
+    for k in ClockSampler.EXTRA:
+        xs = [c[k] for c in got if k in c]
+        if xs:
+            out[k] = float(np.mean(xs))
+    return out
 
 
 def run_probes(ctx, device_index=0):
@@ -312,12 +357,33 @@ def run_probes(ctx, device_index=0):
             "step_mix_tflops": mix["tflops"], "step_mix_wave_insts_per_s": mix["valu_wave_insts"] / (mix["ms"] * 1e-3)}
 
 
-def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
+def hbm_copy_probe(nbytes=512 << 20, reps=5):
+    """Device-to-device copy rate of this box (torch copy_, HIP events; read + write bytes per second): the one thing the
+    compute probes do not see -- a box whose memory side is slow."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return 2.0 * nbytes / (float(np.median(ms)) * 1e-3) / 1e9
+
+
+def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms, num_cus=256):
     """roofline.calibration: the box's own peak beside the vendor's.  cal = {"before": run_probes(), "after": run_probes()}
-    around the timed region."""
-    if not cal or "before" not in cal:
+    around the timed region, or "after" alone (the default since round 6)."""
+    if not cal or not ("before" in cal or "after" in cal):
         return None
-    b, a_ = cal["before"], cal.get("after") or cal["before"]
+    b = cal.get("before") or cal["after"]
+    a_ = cal.get("after") or cal["before"]
+    where = " and ".join(w for w in ("before", "after") if w in cal)
+    n_probes = len([w for w in ("before", "after") if w in cal])
     fma = 0.5 * (b["fp64_fma_tflops"] + a_["fp64_fma_tflops"])
     mix_rate = 0.5 * (b["step_mix_wave_insts_per_s"] + a_["step_mix_wave_insts_per_s"])
     out = {
@@ -332,14 +398,20 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
         "issue_bound_tflops": 0.5 * (b["step_mix_tflops"] + a_["step_mix_tflops"]),
         "frac_of_measured_peak": achieved_tf / fma,
         "sclk_mhz_timed_region": sclk if sclk is not None else "omitted: no hwmon freq1_input readable for this device on this box",
-        "method": "bhg_peak_probe (include/bhgeo.h) in this process, before the warm-up steps and right after the timed region, in the trace "
-                  "kernels' launch geometry (1 wave64 per workgroup, 12 waves per CU, no memory traffic): 2-ms launches, median of 5; "
-                  "figures are the mean of the two probes",
+        "method": f"bhg_peak_probe (include/bhgeo.h) in this process, {where} the timed region (outside its clock), in the trace "
+                  "kernels' launch geometry (1 wave64 per workgroup, 12 waves per CU, no memory traffic): 2-ms launches, median of 5" +
+                  ("; figures are the mean of the two probes" if n_probes > 1 else ""),
+        "probes": where,
     }
+    if "hbm_copy_GBps" in cal:
+        out["hbm_copy_GBps"] = cal["hbm_copy_GBps"]      # (512-MiB device-to-device copy after the timed region, read + write)
+    if isinstance(sclk, dict) and sclk["samples"] < MIN_CLOCK_SAMPLES:
+        out["sclk_mhz_timed_region"] = {**sclk, "note": f"fewer than {MIN_CLOCK_SAMPLES} samples: no clock-scaled peak derived"}
+        sclk = None
     if isinstance(sclk, dict):
-        # ... and against the vendor's formula at the clock the timed region actually ran at (256 CU x 128 flop per clock):
+        # ... and against the vendor's formula at the clock the timed region actually ran at (num_cus CUs x 128 flop per clock):
         # the pure-FMA probe draws more power than the trace kernel and sustains a lower clock than the timed region's
-        peak_at_clock = sclk["mean_mhz"] * 1e6 * 128.0 * 256.0 / 1e12
+        peak_at_clock = sclk["mean_mhz"] * 1e6 * 128.0 * num_cus / 1e12
         out["peak_tflops_at_timed_region_clock"] = peak_at_clock
         out["frac_at_timed_region_clock"] = achieved_tf / peak_at_clock
     if valu_per_64:
@@ -354,15 +426,26 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms):
         out["valu_issue_utilisation_vs_step_mix"] = rate / mix_rate        # of the DP5(4) Christoffel step loop's own mix
         if isinstance(sclk, dict):
             # per clock and SIMD (256 CUs x 4; a full-rate wave64 fp64 instruction occupies its SIMD for 4 clocks: 0.25 at best)
-            out["trace_kernel_wave_insts_per_clock_per_simd"] = rate / (sclk["mean_mhz"] * 1e6 * 1024.0)
+            out["trace_kernel_wave_insts_per_clock_per_simd"] = rate / (sclk["mean_mhz"] * 1e6 * 4.0 * num_cus)
     return out
 
 
 def roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, calibration=None,
-                   sclk=None):
+                   sclk=None, call_samples=None, share=None, num_cus=256):
     achieved_tf = ray_steps * wl.flop / (k_ms * 1e-3) / 1e12
-    cal = calibration_block(calibration, sclk, achieved_tf, valu_per_64, ray_steps, k_ms)
+    cal = calibration_block(calibration, sclk, achieved_tf, valu_per_64, ray_steps, k_ms, num_cus=num_cus)
     extra = {} if cal is None else {"frac_of_measured_peak": cal["frac_of_measured_peak"], "calibration": cal}
+    if call_samples:
+        # every HIP-event sample of the timed region(s), not their mean: the trace call of every EV_EVERY-th step of each
+        # repetition (ms) times the trace kernel's share of a call (1 for the Schwarzschild forms: one launch per call)
+        sh = 1.0 if share is None else share
+        k_samples = [[x * sh for x in r_] for r_ in call_samples]
+        flat = [x for r_ in k_samples for x in r_]
+        extra["kernel_ms_samples"] = k_samples
+        extra["kernel_ms_spread"] = spread(flat)
+        extra["kernel_ms_mean"] = float(np.mean(flat)) if flat else None
+        extra["kernel_ms_is"] = (f"median of the {len(flat)} HIP-event samples (every {EV_EVERY}th step of each repetition, on the stream the "
+                                 f"library launches on) x the trace kernel's share of a call ({sh:.4f})")
     return {**_roofline_core(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, achieved_tf), **extra}
 
 

@@ -209,9 +209,19 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         return color
 
     # ---- the whole frame on the device (opt-in, scene.device_shading) ------------------------------------------------
+    SKY_CHECKSUM_SAMPLES = 1024      # pixel values read for the identity's checksum (of w * h * 4)
+
     def _sky_identity(self):
-        """What tells one sky image from another WITHOUT reading its pixels: name, size, file -- and None while the image
-        has unsaved edits (`is_dirty`: its pixels may differ from render to render, so it is read and uploaded each time)."""
+        """What tells one sky image's CONTENT from another's without reading all of its pixels (33 MB for a 2k x 1k image):
+        name, size, file path -- and what moves when the content does: the file's mtime and length (an image edited
+        outside Blender and reloaded keeps name, size and path, and `is_dirty` stays False), the image source with the
+        scene's current frame for sequences and movies, the colour space and alpha mode, and a checksum over
+        SKY_CHECKSUM_SAMPLES pixel values at a fixed stride.  None -- "cannot be proven unchanged: read and upload" -- while
+        the image has unsaved edits (`is_dirty`), when the pixels cannot be sampled, or after invalidate_device_sky()."""
+        global _SKY_FORCE_REFRESH
+        if _SKY_FORCE_REFRESH:
+            _SKY_FORCE_REFRESH = False
+            return None
         name = os.path.basename(getattr(self, "sky_image_path", "") or "")
         if not name or name not in bpy.data.images:
             return ("<none>",)
@@ -219,7 +229,38 @@ class RelativisticRenderEngine(bpy.types.RenderEngine):
         if getattr(img, "is_dirty", False):
             return None
         size = getattr(img, "size", None) or (0, 0)
-        return (name, int(size[0]), int(size[1]), str(getattr(img, "filepath", "")))
+        filepath = str(getattr(img, "filepath", "") or "")
+        source = str(getattr(img, "source", "FILE"))
+        ident = [name, int(size[0]), int(size[1]), filepath, source,
+                 str(getattr(getattr(img, "colorspace_settings", None), "name", "")), str(getattr(img, "alpha_mode", ""))]
+        if source in ("SEQUENCE", "MOVIE"):
+            scene = getattr(getattr(bpy, "context", None), "scene", None)
+            ident.append(int(getattr(scene, "frame_current", 0) or 0))
+        if source in ("FILE", "SEQUENCE", "MOVIE") and filepath and getattr(img, "packed_file", None) is None:
+            path = filepath
+            absp = getattr(getattr(bpy, "path", None), "abspath", None)
+            if callable(absp):
+                try:
+                    path = absp(filepath)
+                except Exception:   # noqa: BLE001
+                    path = filepath
+            try:
+                st = os.stat(path)
+                ident += [int(st.st_mtime_ns), int(st.st_size)]
+            except OSError:
+                ident += [None, None]      # (no such file -- a generated image, a relative path: the checksum below carries it)
+        try:
+            px = img.pixels
+            n = int(size[0]) * int(size[1]) * 4
+            if n <= 0 or len(px) < n:
+                return None
+            step = max(1, n // self.SKY_CHECKSUM_SAMPLES)
+            # (+ 1: a stride that is a multiple of 4 would only ever look at one channel)
+            vals = np.asarray([px[i] for i in range(0, n, step + (1 if step % 4 == 0 else 0))], dtype=np.float32)
+            ident.append(hash(vals.tobytes()))
+        except Exception:   # noqa: BLE001
+            return None
+        return tuple(ident)
 
     def _sky_pixels(self):
         """The sky image as float32 [h, w, 4], rows bottom-up as Blender stores them -- which is the library's
@@ -371,6 +412,14 @@ EXTRA_PROPS = [
 
 # the library-owned frame of the device path, kept across renders (see ray_trace_device): at most one
 _DEVICE_FRAMES = {}
+_SKY_FORCE_REFRESH = False
+
+
+def invalidate_device_sky():
+    """Force the next device render to read the sky image and upload it again, whatever its identity says (a hook for
+    scripts that change the image in ways the identity cannot see)."""
+    global _SKY_FORCE_REFRESH
+    _SKY_FORCE_REFRESH = True
 
 
 def release_device_frames():

@@ -685,6 +685,7 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
                 std::fwrite(host, 1, sizeof(host), f);
                 std::fclose(f);
             }
+            HIP_TRY(hipMemset(dbuf + BHG_DIAG_HIST, 0, 131 * sizeof(unsigned long long)));   // (the histogram accumulates: one launch per dump)
         }
     }
 #endif

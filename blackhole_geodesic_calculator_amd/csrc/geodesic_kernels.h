@@ -76,10 +76,13 @@ struct TraceArgs {
     int32_t order_blocks;        // work-order hint: n = order_blocks * order_block_len, batches are
     uint64_t order_block_len;    // handed out chunk-major over the blocks; 0/1 = plain order
     int8_t *object_id;           // [n] or nullptr: sphere index of rays that end with BHG_FLAG_HIT_OBJECT, else -1
-    unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][4] per-wave stamps
+    unsigned long long *diag;    // diagnostic builds only (BHG_DIAG): [grid][8] per-wave stamps; + BHG_DIAG_HIST: event-coherence histogram
     uint32_t dbg_idx;            // diagnostic builds: ray whose controller trace is logged
     double spheres[BHG_MAX_SPHERES_][4];  // {cx, cy, cz, radius}, BH-centred
 };
+
+#define BHG_DIAG_HIST 400000   // u64 index into `diag`: H[0..64] iterations by lanes parking ONE short event, [65..129] the lanes
+                               // stepping in those iterations, [130] all parked steps (zeroed after every dump)
 
 // camera-ray generation (frame_kernels.hip)
 struct RaygenArgs {

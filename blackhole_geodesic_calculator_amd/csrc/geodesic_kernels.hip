@@ -2456,6 +2456,25 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                         diag_pass += __builtin_popcountll(__ballot(ev_d)) ? 1 : 0;
                     }
 #endif
+#ifdef BHG_DIAG
+                    if ((EVT & (EVT_EXIT | EVT_DISK)) && A.diag) {
+                        // round 6: how coherent are the short events?  Per iteration: k = lanes that park a step with ONE
+                        // candidate of a short kind (exit or disk alone) -> H[k]++, and the lanes stepping beside them
+                        const bool one_short = (ev_e != ev_d) && !ev_h && !ev_o;
+                        const uint64_t om = __ballot(one_short);
+                        if (om) {
+                            const int k = __builtin_popcountll(om);
+                            const unsigned long long act = (unsigned long long)__builtin_popcountll(__ballot(true));
+                            if (lane == (uint32_t)__builtin_ctzll(om)) {
+                                atomicAdd(A.diag + BHG_DIAG_HIST + k, 1ull);
+                                atomicAdd(A.diag + BHG_DIAG_HIST + 65 + k, act);
+                            }
+                        }
+                        const uint64_t am_ = __ballot(ev_h || ev_e || ev_d || ev_o);
+                        if (am_ && lane == (uint32_t)__builtin_ctzll(am_))
+                            atomicAdd(A.diag + BHG_DIAG_HIST + 130, (unsigned long long)__builtin_popcountll(am_));   // all parked steps
+                    }
+#endif
                     if (ev_h || ev_e || ev_d || ev_o) {
                         // Park the step: x, v, a1, t still hold its START (the event drain recomputes it from there),
                         // h_abs is already the controller's choice for the next step, the radius register takes the

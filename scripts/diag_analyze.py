@@ -34,3 +34,20 @@ if refill.sum():
 if cross.sum():
     print("disk plane: some lane crossed it in %.4f of the iterations; some lane passed the filter (is parked) in %.4f; "
           "the filter ran for nothing in %.4f" % (cross.sum() / it.sum(), passed.sum() / it.sum(), (cross.sum() - passed.sum()) / it.sum()))
+# round 6: event coherence (BHG_DIAG_HIST = u64 index 400000 of the dump): iterations by k = lanes parking ONE short event
+raw = np.fromfile(sys.argv[1], dtype=np.uint64)
+if raw.size >= 400131:
+    H = raw[400000:400065].astype(np.float64)
+    A = raw[400065:400130].astype(np.float64)
+    allp = float(raw[400130])
+    k = np.arange(65)
+    steps = H * k
+    if steps.sum() > 0 and it.sum() > 0:
+        print("event coherence: %d steps parked with ONE short event (%.4f of all %d parked) in %d iterations (%.4f of all iterations); mean k %.2f"
+              % (steps.sum(), steps.sum() / max(allp, 1), allp, H.sum(), H.sum() / it.sum(), steps.sum() / H.sum()))
+        for lo, hi in ((1, 1), (2, 3), (4, 7), (8, 15), (16, 31), (32, 63), (64, 64)):
+            sel = slice(lo, hi + 1)
+            if H[sel].sum():
+                print("   k %2d..%2d: %.4f of such iterations, %.4f of such steps, lanes stepping beside them (mean) %.1f"
+                      % (lo, hi, H[sel].sum() / H.sum(), steps[sel].sum() / steps.sum(), A[sel].sum() / H[sel].sum()))
+        print("   share of one-short-event steps from iterations with k >= 16: %.4f; k >= 8: %.4f" % (steps[16:].sum() / steps.sum(), steps[8:].sum() / steps.sum()))

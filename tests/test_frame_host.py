@@ -281,3 +281,50 @@ def test_addon_object_lighting_is_the_contracts_lambert_model_with_shadow_rays()
     assert (alone.sum(1) > got[idx == 0].sum(1) + 1e-12).any()
     names = [p[0] for p in addon.PROPS + addon.EXTRA_PROPS]
     assert "device_shading" in names and "curved_space_objects" in names and len(addon.PROPS) == 12
+
+
+def test_addon_sky_identity_follows_the_content(tmp_path):
+    """The device path keeps the sky image on the GPU while its identity stands still (blender_addon._sky_identity).  The
+    identity must move whenever the CONTENT may have: a file rewritten outside Blender (same name, size, path; is_dirty
+    False), other pixels under the same name, another colour space, another frame of an image sequence, unsaved edits,
+    an explicit invalidate_device_sky()."""
+    import types
+    bpy, depsgraph = fake_bpy.install(width=8, height=8, samples=1)
+    addon = importlib.import_module("blackhole_geodesic_calculator_amd.blender_addon")
+    f = tmp_path / "sky.png"
+    f.write_bytes(b"a" * 100)
+    img = fake_bpy.FakeImage(str(f))
+    bpy.data.images["sky.png"] = img
+    eng = addon.RelativisticRenderEngine()
+    eng.sky_image_path = str(f)
+    id0 = eng._sky_identity()
+    assert id0 is not None and id0 == eng._sky_identity()             # stands still while nothing changes
+    # the file rewritten in place (another length; mtime too)
+    f.write_bytes(b"b" * 120)
+    id1 = eng._sky_identity()
+    assert id1 is not None and id1 != id0
+    # other pixels, everything else equal (an image reloaded from an identical-looking file): the strided checksum
+    img.array = np.ascontiguousarray(img.array[:, ::-1])
+    img.pixels = img.array.reshape(-1).tolist()
+    id2 = eng._sky_identity()
+    assert id2 is not None and id2 != id1
+    # colour space
+    img.colorspace_settings = types.SimpleNamespace(name="Linear")
+    id3 = eng._sky_identity()
+    assert id3 != id2
+    img.colorspace_settings.name = "sRGB"
+    assert eng._sky_identity() != id3
+    # an image sequence: the scene's frame is part of the identity
+    img.source = "SEQUENCE"
+    bpy.context.scene.frame_current = 3
+    id4 = eng._sky_identity()
+    bpy.context.scene.frame_current = 4
+    assert eng._sky_identity() != id4
+    # unsaved edits and the explicit hook: cannot be proven unchanged -> None (read and upload), the hook once
+    addon.invalidate_device_sky()
+    assert eng._sky_identity() is None and eng._sky_identity() is not None
+    img.is_dirty = True
+    assert eng._sky_identity() is None
+    # no image at all is an identity of its own
+    eng.sky_image_path = ""
+    assert eng._sky_identity() == ("<none>",)

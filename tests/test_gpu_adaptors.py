@@ -241,6 +241,23 @@ def test_addon_keeps_its_device_frame_across_renders(ctx, oracle):
     rect2 = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(size, size, 4)
     want2 = sh.shade_reduce(o["end"], o["flags"], size * size, 2, img.array).reshape(size, size, 4)
     assert np.abs(rect2 - want2).max() < 1e-6 and np.abs(rect2 - rect).max() > 1e-3
+    # ... or was changed behind Blender's back (reloaded from an edited file: same name, size, path, is_dirty False -- ADVICE
+    # r05): the identity's checksum sees other pixels; the render after that one finds the same image and uploads nothing;
+    # invalidate_device_sky() forces one upload
+    img.is_dirty = False
+    img.array = np.ascontiguousarray(img.array[::-1])
+    img.pixels = img.array.reshape(-1).tolist()
+    ups = []
+    for hook in (False, False, True):
+        if hook:
+            addon.invalidate_device_sky()
+        eng = addon.RelativisticRenderEngine()
+        eng.render(depsgraph)
+        ups.append(eng.device_sky_uploaded)
+        rect3 = np.array(eng.result.layers[0].passes["Combined"].rect).reshape(size, size, 4)
+        want3 = sh.shade_reduce(o["end"], o["flags"], size * size, 2, img.array).reshape(size, size, 4)
+        assert np.abs(rect3 - want3).max() < 1e-6
+    assert ups == [True, False, True] and np.abs(rect3 - rect2).max() > 1e-3
     addon.unregister()
     assert len(addon._DEVICE_FRAMES) == 0
 

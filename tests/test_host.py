@@ -441,6 +441,21 @@ def test_bench_calibration_block_is_plain_arithmetic():
     c2 = bc.calibration_block({"before": probe}, None, achieved, None, ray_steps, k_ms)
     assert isinstance(c2["sclk_mhz_timed_region"], str) and "frac_at_timed_region_clock" not in c2 and "valu_issue_utilisation" not in c2
     assert bc.calibration_block({}, sclk, achieved, valu64, ray_steps, k_ms) is None
+    # round 6: the probes run after the timed region only; a clock mean of too few samples derives nothing; num_cus from the context
+    c3 = bc.calibration_block({"after": after}, sclk, achieved, valu64, ray_steps, k_ms, num_cus=128)
+    assert c3["probes"] == "after" and abs(c3["frac_of_measured_peak"] - 36.0 / 70.0) < 1e-12
+    assert abs(c3["peak_tflops_at_timed_region_clock"] - 2300e6 * 128 * 128 / 1e12) < 1e-9
+    few = dict(sclk, samples=7)
+    c4 = bc.calibration_block({"after": after}, few, achieved, valu64, ray_steps, k_ms)
+    assert "frac_at_timed_region_clock" not in c4 and c4["sclk_mhz_timed_region"]["samples"] == 7
+    merged = bc.merge_clock_samples([dict(sclk, samples=10, mean_mhz=2000.0), None, dict(sclk, samples=30, mean_mhz=2400.0)])
+    assert merged["samples"] == 40 and abs(merged["mean_mhz"] - 2300.0) < 1e-9 and merged["repetitions"] == 2
+    assert bc.merge_clock_samples([None, None]) is None
+    sp = bc.spread([1.0, 1.2, None, 1.1])
+    assert sp == {"n": 3, "min": 1.0, "median": 1.1, "max": 1.2, "rel_spread": (1.2 - 1.0) / 1.1}
+    rb = bc.roofline_block(type("W", (), {"flop": 654, "flop_executed": 601, "method": "dp54", "a": type("A", (), {"rhs": "christoffel"})})(),
+                           ray_steps, k_ms, k_ms, 5242880, 81, None, "none", None, call_samples=[[1.1, 1.2], [1.3]], share=0.5)
+    assert rb["kernel_ms_samples"] == [[0.55, 0.6], [0.65]] and rb["kernel_ms_spread"]["n"] == 3 and abs(rb["kernel_ms_mean"] - 0.6) < 1e-12
     # the sampler on a box without the sysfs file (this one): no thread, no figure
     smp = bc.ClockSampler(0).start()
     assert smp.stop() is None or isinstance(smp.stop(), dict)
