@@ -614,7 +614,7 @@ def main():
             },
             "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64,
                                        calibration=m["calibration"], sclk=m["sclk"], call_samples=m["call_samples"], share=m["share"],
-                                       num_cus=rt.ctx.num_cus()),
+                                       num_cus=rt.ctx.num_cus),
         }
         if a.workload == "frame":
             out["config"]["north_star_output"] = ("exit directions only (--dir-only)" if getattr(fr, "_dir_traced", False) else

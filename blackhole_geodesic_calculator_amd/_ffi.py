@@ -15,7 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BHGEO_LIB") or os.path.join(_HERE, "libbhgeo.so")  # BHGEO_LIB: A/B builds
 
-ABI_VERSION = 7
+ABI_VERSION = 8
+ABI_COMPAT_MIN = 7    # bhg_abi_check serves bindings from this ABI on (8 only added bhg_trajectory_objects)
 
 OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_NOMEM = -1, -2, -3, -4
@@ -50,7 +51,7 @@ EXPORTS = (
     "bhg_frame_device_image", "bhg_frame_rebalance", "bhg_frame_stats", "bhg_frame_info", "bhg_frame_set_profiling",
     "bhg_frame_last_ms", "bhg_deal_tiles",
     "bhg_params_size", "bhg_camera_size", "bhg_scene_size", "bhg_frame_scene_size", "bhg_abi_check",
-    "bhg_default_params_sized", "bhg_peak_probe",
+    "bhg_default_params_sized", "bhg_peak_probe", "bhg_trajectory_objects",
 )
 PROBE_FMA, PROBE_STEP_MIX = 0, 1
 
@@ -233,6 +234,9 @@ def load():
     # (raw addresses: building a typed ctypes pointer costs ~2 us per array, and the engine's literal call is one ray long)
     L.bhg_trajectory.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bhg_trajectory_objects.restype = C.c_int
+    L.bhg_trajectory_objects.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bhg_set_profiling.restype = C.c_int
     L.bhg_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.bhg_last_pass_ms.restype = C.c_int
@@ -713,8 +717,9 @@ class Context:
                                 _np_dp(end), flags.ctypes.data_as(_u8p), p_steps, p_acc))
         return end, flags, steps, acc
 
-    def trajectory(self, k0, x0, params: Params, n_points):
-        """Sampled curves: (traj[N,6,T], n_valid[N], end[N,6], flags[N])."""
+    def trajectory(self, k0, x0, params: Params, n_points, spheres=None):
+        """Sampled curves: (traj[N,6,T], n_valid[N], end[N,6], flags[N]); with spheres= (object spheres in the curved region,
+        [[cx, cy, cz, radius], ...] BH-centred): (..., object_id[N]) -- bhg_trajectory_objects."""
         k0 = np.ascontiguousarray(k0, dtype=np.float64).reshape(-1, 3)
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         n = k0.shape[0]
@@ -726,6 +731,13 @@ class Context:
         nv = np.empty(n, np.uint32)
         end = np.empty((n, 6), np.float64)
         flags = np.empty(n, np.uint8)
+        if spheres is not None:
+            sp = _spheres_array(spheres)
+            obj = np.empty(n, np.int8)
+            _check(load().bhg_trajectory_objects(self._h, C.byref(params), _addr(sp) if len(sp) else None, len(sp), _addr(x0),
+                                                 1 if shared else 0, _addr(k0), n, int(n_points), _addr(traj), _addr(nv), _addr(end),
+                                                 _addr(flags), _addr(obj)))
+            return traj, nv, end, flags, obj
         _check(load().bhg_trajectory(self._h, C.byref(params), _addr(x0), 1 if shared else 0, _addr(k0), n,
                                      int(n_points), _addr(traj), _addr(nv), _addr(end), _addr(flags)))
         return traj, nv, end, flags

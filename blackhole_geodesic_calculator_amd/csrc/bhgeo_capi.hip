@@ -207,6 +207,7 @@ struct bhg_context {
     hipStream_t last_stream = nullptr;   // the stream of the last trace launch (launches of a context must stay ordered)
     bool launched = false;
     hipEvent_t ev_order = nullptr;
+    bool last_stream_foreign = false;    // last_stream is a caller's handle: ev_order was recorded behind that call
     int num_cus = 0;
     char name[256] = {0};
     // device buffers of the host-buffer entry points, grown on demand
@@ -283,6 +284,35 @@ bool is_pinned(const void *p)
     return at.type == hipMemoryTypeHost;
 }
 
+// ... and a whole range [p, p + bytes): the allocation that holds p must hold its last byte too (hipMemGetAddressRange on
+// the device alias of the block); where the runtime cannot tell the extent of a host allocation, both ends must at
+// least be page-locked and map to one contiguous device range
+bool is_pinned_range(const void *p, size_t bytes, void **dev_out)
+{
+    if (!p || bytes == 0 || !is_pinned(p)) return false;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) != hipSuccess || !dp) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hipDeviceptr_t base = nullptr;
+    size_t extent = 0;
+    if (hipMemGetAddressRange(&base, &extent, (hipDeviceptr_t)dp) == hipSuccess && base && extent) {
+        if ((const char *)dp + bytes > (const char *)base + extent) return false;
+    } else {
+        (void)hipGetLastError();
+        const char *last = (const char *)p + bytes - 1;
+        void *dl = nullptr;
+        if (!is_pinned(last)) return false;
+        if (hipHostGetDevicePointer(&dl, const_cast<char *>(last), 0) != hipSuccess || dl != (char *)dp + bytes - 1) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    *dev_out = dp;
+    return true;
+}
+
 // validate_tol (scipy _ivp/common.py:44-51): an rtol below 100 eps is raised to 100 eps -- scipy warns and carries on, and so
 // does every solve the reference runs through solve_ivp (README.md:196)
 inline double scipy_rtol(double rtol) { return rtol < 100.0 * DBL_EPSILON ? 100.0 * DBL_EPSILON : rtol; }
@@ -344,9 +374,12 @@ size_t bhg_frame_scene_size(void) { return sizeof(bhg_frame_scene); }
 
 int bhg_abi_check(int abi_version, size_t params_size, size_t camera_size, size_t scene_size, size_t frame_scene_size)
 {
-    if (abi_version != BHG_ABI_VERSION)
+    // (a binding written for an older ABI whose every entry point and struct layout this library still has is served:
+    // BHG_ABI_COMPAT_MIN .. BHG_ABI_VERSION)
+    if (abi_version < BHG_ABI_COMPAT_MIN || abi_version > BHG_ABI_VERSION)
         return fail(BHG_E_INVALID, "ABI mismatch: the binding was written for ABI " + std::to_string(abi_version) + ", this libbhgeo.so is ABI " +
-                                       std::to_string(BHG_ABI_VERSION) + " (include/bhgeo.h)");
+                                       std::to_string(BHG_ABI_VERSION) + " and serves bindings from ABI " + std::to_string(BHG_ABI_COMPAT_MIN) +
+                                       " on (include/bhgeo.h)");
     const struct {
         const char *name;
         size_t theirs, ours;
@@ -543,17 +576,14 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     // they must execute in the order they were issued.  On ONE stream they do; a call that arrives on ANOTHER stream than
     // the previous one is ordered behind it here (an event on the old stream, a wait on the new one) -- it then cannot
     // overlap the previous call, but it cannot corrupt it either (two traces that are to overlap need two contexts).
+    // The previous call's stream may be a handle the CALLER owns -- and may have destroyed since: it is never touched
+    // again.  A call on a caller's stream leaves an event behind it at its own end (below, ev_order recorded on that stream
+    // while the caller is still inside the call); only the context's own stream and the null stream, which cannot go away,
+    // are recorded on after the fact.
     if (c->launched && s != c->last_stream) {
         if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
-        // The previous call's stream is a handle the CALLER owns; the header asks that it outlive the next call on the
-        // context.  If it has been destroyed all the same (the runtime then refuses the handle), wait for the whole device
-        // instead: slow, but the previous launch is then certainly behind us and the context stays usable.
-        if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_order, 0));
-        } else {
-            (void)hipGetLastError();
-            HIP_TRY(hipDeviceSynchronize());
-        }
+        if (!c->last_stream_foreign) HIP_TRY(hipEventRecord(c->ev_order, c->last_stream));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_order, 0));
     }
     c->last_stream = s;
     c->launched = true;
@@ -710,6 +740,13 @@ int trace_device_one(bhg_context *c, const bhg_params *p, const double *spheres,
     c->last_launch[0] = (int32_t)grid;
     c->last_launch[1] = 64;
     c->last_launch[2] = per_cu;
+    // a caller's stream: leave the ordering event behind this call now, while the handle is certainly alive (the next
+    // call on another stream waits on it and never touches this stream again)
+    c->last_stream_foreign = s != nullptr && s != c->stream;
+    if (c->last_stream_foreign) {
+        if (!c->ev_order) HIP_TRY(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_order, s));
+    }
     return BHG_OK;
 }
 
@@ -1291,8 +1328,17 @@ int bhg_assemble_frame_f32_device(bhg_context *c, const float *d_slabs, const in
 int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0, size_t n,
                    uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags)
 {
+    return bhg_trajectory_objects(c, p, nullptr, 0, x0, x0_is_shared, k0, n, n_points, traj, n_valid, end, flags, nullptr);
+}
+
+int bhg_trajectory_objects(bhg_context *c, const bhg_params *p, const double *spheres, int32_t n_spheres, const double *x0,
+                           int x0_is_shared, const double *k0, size_t n, uint32_t n_points, double *traj, uint32_t *n_valid,
+                           double *end, uint8_t *flags, int8_t *object_id)
+{
     if (!c) return fail(BHG_E_INVALID, "ctx is NULL");
     int rc = validate(p);
+    if (rc != BHG_OK) return rc;
+    rc = validate_spheres(p, spheres, n_spheres);
     if (rc != BHG_OK) return rc;
     if (n_points < 2) return fail(BHG_E_INVALID, "n_points must be >= 2");
     if (n == 0) return BHG_OK;
@@ -1304,9 +1350,11 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     const size_t sz_traj = n * 6 * (size_t)n_points * sizeof(double);
     const size_t off_end = sz_traj, off_nv = off_end + n * 6 * sizeof(double), off_steps = off_nv + n * sizeof(uint32_t);
     const size_t off_acc = off_steps + n * sizeof(uint32_t), off_flags = off_acc + n * sizeof(uint32_t);
+    const size_t off_obj = off_flags + n;      // [n] int8: the sphere a ray ends on (-1: none); only with spheres
+    const bool with_obj = n_spheres > 0;
     rc = ensure(&c->d_in, &c->d_in_bytes, in_bytes);
     if (rc != BHG_OK) return rc;
-    rc = ensure(&c->d_out, &c->d_out_bytes, off_flags + n + 64);
+    rc = ensure(&c->d_out, &c->d_out_bytes, off_obj + n + 64);
     if (rc != BHG_OK) return rc;
     // up to 2048 rays the kernel runs one wave per ray, prepares the ray itself and fills what it never reaches with NaN:
     // no prepare records, no memset; the direction of a ONE-ray call (the engine's literal call) rides in the kernel arguments
@@ -1325,13 +1373,11 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     // are 512-byte runs per sample row; the array is complete when the stream has been waited for.)
     double *d_traj = (double *)o;
     bool direct = false;
-    if (wave && sz_traj <= (size_t(4) << 20) && is_pinned(traj)) {
+    if (wave && sz_traj <= (size_t(4) << 20)) {
         void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, traj, 0) == hipSuccess && dp) {
+        if (is_pinned_range(traj, sz_traj, &dp)) {      // (the WHOLE block, not its first byte: the kernel writes all of it)
             d_traj = (double *)dp;
             direct = true;
-        } else {
-            (void)hipGetLastError();
         }
     }
     // ... and then the small arrays behind the sample block -- end state, n_valid, counts, flags: at most 2048 rays --
@@ -1396,9 +1442,14 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
     }
     a.max_steps = p->max_steps ? p->max_steps : (1u << 20);
     a.min_step_cap = 0.0;
+    a.n_spheres = n_spheres;
+    for (int j = 0; j < n_spheres; j++)
+        for (int q = 0; q < 4; q++) a.spheres[j][q] = spheres[4 * j + q];
+    a.object_id = with_obj ? (int8_t *)(os + off_obj) : nullptr;
     HIP_TRY(bhg::launch_trajectory(a, (p->time_like && p->rhs_form == BHG_RHS_CHRISTOFFEL) ? bhg::BHG_RHS_CHRISTOFFEL_TL_ : p->rhs_form, p->method,
                                    d_traj, (uint32_t *)(os + off_nv), n_points, s));
-    const size_t total = off_flags + n;
+    const size_t total = with_obj ? off_obj + n : off_flags + n;
+    if (object_id && !with_obj) std::memset(object_id, 0xFF, n);      // (no spheres: no ray ends on one)
     if (direct) {
         const char *h = (const char *)c->pin_out - off_end;
         // (polling hipStreamQuery before the blocking wait was measured: no gain, the runtime already spins)
@@ -1406,6 +1457,7 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
         std::memcpy(n_valid, h + off_nv, n * sizeof(uint32_t));
         if (end) std::memcpy(end, h + off_end, n * 6 * sizeof(double));
         if (flags) std::memcpy(flags, h + off_flags, n);
+        if (object_id && with_obj) std::memcpy(object_id, h + off_obj, n);
         return BHG_OK;
     }
     if (total <= (size_t(4) << 20)) {
@@ -1421,12 +1473,14 @@ int bhg_trajectory(bhg_context *c, const bhg_params *p, const double *x0, int x0
         std::memcpy(n_valid, h + off_nv, n * sizeof(uint32_t));
         if (end) std::memcpy(end, h + off_end, n * 6 * sizeof(double));
         if (flags) std::memcpy(flags, h + off_flags, n);
+        if (object_id && with_obj) std::memcpy(object_id, h + off_obj, n);
         return BHG_OK;
     }
     HIP_TRY(hipMemcpyAsync(traj, o, sz_traj, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(n_valid, o + off_nv, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     if (end) HIP_TRY(hipMemcpyAsync(end, o + off_end, n * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
     if (flags) HIP_TRY(hipMemcpyAsync(flags, o + off_flags, n, hipMemcpyDeviceToHost, s));
+    if (object_id && with_obj) HIP_TRY(hipMemcpyAsync(object_id, o + off_obj, n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return BHG_OK;
 }

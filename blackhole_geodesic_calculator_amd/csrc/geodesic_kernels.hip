@@ -2808,6 +2808,7 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
             for (uint32_t j = lane; j < 6 * T; j += blockDim.x) out[j] = __builtin_nan("");
             if (lane == 0) {
                 n_valid[i] = 0;
+                if (A.object_id) A.object_id[i] = (int8_t)-1;
                 store_result(A, (uint32_t)i, cx, ck, BHG_FLAG_START_INSIDE_ | BHG_FLAG_HIT_HORIZON_, 0, 0);
             }
             return;
@@ -2844,6 +2845,7 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
     const double dt = t_bound / (double)(T - 1);
     double t = 0.0;
     uint32_t n_att = 0, n_acc = 0, next = 0, flags = 0;
+    int hit_obj = -1;        // bhg_trajectory_objects: the sphere the ray ends on
     bool rejected = false;
     double xe[3] = {x[0], x[1], x[2]}, ve[3] = {v[0], v[1], v[2]};
     for (;;) {
@@ -2936,9 +2938,12 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
         const bool ev_e = (A.r_exit > 0.0) && (r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
         // the thin disk (LimitedRelativisticRenderEngine.py:283-286, :413-438): a plane crossing is terminal only inside the annulus
         const bool ev_d = (A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(x, xn);
+        // object spheres (bhg_trajectory_objects; the reference's collision stub, RelativisticRenderEngine.py:304-305): the
+        // trace kernels' own chord rule on the step's ends
+        const bool ev_o = (A.n_spheres > 0) && any_sphere_candidate_of<RHS>(A, x, xn);
         double t_stop = t_new;
         uint32_t evflag = 0;
-        if (FIXED && !(ev_h || ev_e || ev_d) && !(r_new == r_new)) {
+        if (FIXED && !(ev_h || ev_e || ev_d || ev_o) && !(r_new == r_new)) {
             // a fixed step that ends in a non-finite state (through the Boyer-Lindquist 1 / Delta singularity): the ray ends
             // there, flagged NaN by store_result; the step yields no samples
             for (int c = 0; c < 3; c++) {
@@ -2948,13 +2953,13 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
             flags = 0;
             break;
         }
-        if (ev_h || ev_e || ev_d) {
+        if (ev_h || ev_e || ev_d || ev_o) {
             // the trace kernels' own event settlement (Brent on the dense output, scipy's brentq step for step; of the
-            // terminal candidates the earliest root wins, ties in the order horizon, exit, disk)
-            const uint32_t kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u);
+            // terminal candidates the earliest root wins, ties in the order horizon, exit, disk, sphere 0, 1, ...)
+            const uint32_t kind = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
             double best;
             int obj;
-            evflag = settle_events<(EVT_EXIT | EVT_DISK)>(
+            evflag = settle_events<(EVT_EXIT | EVT_DISK | EVT_OBJ)>(
                 A, kind, t, t_new, x, xn,
                 [&](double tt, double Rr) { return FIXED ? hermite_g(hd, tt, Rr, bl) : dense_g(d, tt, Rr, bl); },
                 [&](double tt) {
@@ -2980,7 +2985,10 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
                     }
                 },
                 bl, best, obj);
-            if (evflag) t_stop = best;
+            if (evflag) {
+                t_stop = best;
+                hit_obj = obj;
+            }
         }
         // emit every sample time up to where this step ends
         uint32_t first = next, stride = 1, last = T;
@@ -3054,6 +3062,7 @@ __global__ void __launch_bounds__(WAVE ? 256 : 64) trajectory_dp54_kernel(const 
         if (lane != 0) return;
     }
     n_valid[i] = next;
+    if (A.object_id) A.object_id[i] = (int8_t)hit_obj;
     store_result(A, (uint32_t)i, xe, ve, flags, n_att, n_acc);  // Kerr: still Boyer-Lindquist, finalised next
 }
 

@@ -118,7 +118,7 @@ class GeodesicIntegratorSchwarzschild:
 
     # ------------------------------------------------------------------------------------
     def calc_trajectory(self, k0_xyz, x0_xyz, max_step=np.inf, curve_end=50, nr_points_curve=50,
-                        verbose=False, r_exit=0.0, disk=None, **_ignored):
+                        verbose=False, r_exit=0.0, disk=None, spheres=None, **_ignored):
         """Per-ray drop-in for the call at RelativisticRenderEngine.py:293-294.
 
         Returns (k_xyz, x_xyz, result): k_xyz and x_xyz have shape (3, T') with the curve sampled at
@@ -128,11 +128,21 @@ class GeodesicIntegratorSchwarzschild:
         horizon rays), the same numbers trace() returns.  r_exit / disk=(R_in, R_out) (not in the reference's signature:
         the Limited engine's exit sphere and thin disk, Limited...py:273-278, :413-438): the curve then ends where the
         ray leaves the sphere or meets the disk, result['hit_disk'] says which.
+        spheres=[[cx, cy, cz, radius], ...] (BH-centred, at most 8): objects in the curved region -- this call is exactly
+        where the reference left its collision test as a stub ("NOW YOU DO COLLISION DETECTION ... hit = False", :304-305).
+        A ray that enters a sphere ends there: result['hit_object'] = True, result['object_id'] = its index,
+        result['end_loc'] the entry point -- the same flag, sphere and point trace(spheres=) gives for that ray -- and the
+        sampled curve stops in front of it.
         """
         k0 = np.asarray(k0_xyz, dtype=np.float64).reshape(3)
         x0 = np.asarray(x0_xyz, dtype=np.float64).reshape(3)
         n_pts = max(2, int(nr_points_curve))
-        traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end, r_exit, disk), n_pts)
+        obj = None
+        if spheres is not None:
+            traj, nv, end, flags, obj = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end, r_exit, disk), n_pts,
+                                                             spheres=spheres)
+        else:
+            traj, nv, end, flags = self._ctx.trajectory(k0[None, :], x0, self.params(max_step, curve_end, r_exit, disk), n_pts)
         m = int(nv[0])
         fl = int(flags[0])
         # (views of this call's own result block -- nothing else refers to it: two 240-kB copies less per call at the
@@ -147,6 +157,9 @@ class GeodesicIntegratorSchwarzschild:
             "end_loc": end[0, 0:3].copy(),
             "end_dir": end[0, 3:6].copy(),
         }
+        if obj is not None:
+            result["hit_object"] = fl == _ffi.FLAG_HIT_OBJECT
+            result["object_id"] = int(obj[0])
         if verbose or self.verbose:
             print("calc_trajectory:", {k: result[k] for k in ("start_inside_hole", "hit_blackhole", "flags")})
         return k_xyz, x_xyz, result

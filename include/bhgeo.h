@@ -51,8 +51,12 @@
 extern "C" {
 #endif
 
-#define BHG_ABI_VERSION 7   /* 7: the binder's handshake -- bhg_abi_check, bhg_*_size, bhg_default_params_sized; bhg_peak_probe.
+#define BHG_ABI_VERSION 8   /* 8: bhg_trajectory_objects (sampled curves that end on object spheres); nothing of ABI 7 changed.
+                               7: the binder's handshake -- bhg_abi_check, bhg_*_size, bhg_default_params_sized; bhg_peak_probe.
                                6: bhg_frame_* (library-owned frame, N devices), bhg_deal_tiles, bhg_params.time_like (104 bytes) */
+
+#define BHG_ABI_COMPAT_MIN 7 /* bhg_abi_check serves bindings written for this ABI or later: every symbol, struct layout and
+                                meaning they know is unchanged (ABI 8 only ADDED an entry point) */
 
 /* return codes */
 #define BHG_OK 0
@@ -221,6 +225,14 @@ int bhg_host_free(bhg_context *ctx, void *p);
  * block, no host-side split (the Python adaptor allocates it so). */
 int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int x0_is_shared, const double *k0,
                    size_t n, uint32_t n_points, double *traj, uint32_t *n_valid, double *end, uint8_t *flags);
+/* ... with object spheres in the curved region (ABI 8): the engine's literal per-ray call is exactly where the reference put
+ * its collision stub ("NOW YOU DO COLLISION DETECTION", RelativisticRenderEngine.py:293-305).  spheres [n_spheres][4] =
+ * {cx, cy, cz, radius}, BH-centred, as in bhg_trace_objects: a ray that enters one ends there with BHG_FLAG_HIT_OBJECT --
+ * the same flag, sphere index (object_id [n], -1 = none; may be NULL), entry point and step counts bhg_trace_objects gives
+ * for that ray -- and its curve is sampled up to the entry point, NaN behind it.  n_spheres = 0 is bhg_trajectory. */
+int bhg_trajectory_objects(bhg_context *ctx, const bhg_params *p, const double *spheres, int32_t n_spheres, const double *x0,
+                           int x0_is_shared, const double *k0, size_t n, uint32_t n_points, double *traj, uint32_t *n_valid,
+                           double *end, uint8_t *flags, int8_t *object_id);
 
 /* Device buffers (all d_* are device addresses on ctx's device; x0_shared is a HOST [3] array or
  * NULL when d_x0 [n][3] is given).  Enqueues on `stream` (a hipStream_t; NULL = HIP's null
@@ -228,9 +240,9 @@ int bhg_trajectory(bhg_context *ctx, const bhg_params *p, const double *x0, int 
  * returns without synchronising -- with or without a disk or objects: ONE persistent launch finishes
  * every ray (events are located and rays that carry on are resumed inside the trace kernel).  Two calls
  * on one context never overlap: they share the context's work counters and workspace, so a call issued on another
- * stream than the previous one is ordered behind it by the library (an event recorded on the PREVIOUS call's stream + a
- * wait on the new one: a stream handed to a call must therefore stay alive until the next call on the context has been
- * issued -- if it was destroyed all the same, the library falls back to a device-wide wait; calls that are to run
+ * stream than the previous one is ordered behind it by the library: a call on a CALLER's stream records an event behind
+ * itself before it returns, the next call on another stream waits on that event -- the library never touches a caller's
+ * stream after the call that was given it has returned, so the caller may destroy it right away; calls that are to run
  * concurrently need a context each).  The launch is not graph-replayable (it consumes and re-arms those counters). */
 int bhg_trace_device(bhg_context *ctx, const bhg_params *p, const double *x0_shared,
                      const double *d_x0, const double *d_k0, size_t n, double *d_end,

@@ -1,5 +1,5 @@
 import numpy as np, sys
-d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)
+d = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)[:32768]    # (per-wave stamps; the histogram sits behind them)
 d = d[d[:, 1] > 0]
 cross = ((d[:, 2] >> np.uint64(24)) & np.uint64((1 << 20) - 1)).astype(np.float64)
 passed = (d[:, 2] >> np.uint64(44)).astype(np.float64)

@@ -12,11 +12,12 @@ echo "# $(date -u +%FT%TZ) $(python3 -c 'import socket; print(socket.gethostname
 for i in 1 2 3 4 5; do
   for v in before_warmup after_only lean; do
     if [ $v = lean ]; then
-      line=$(timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --lean 2>/dev/null | tail -1)
+      line=$(timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --lean 2>gpurun_out/r06_driver_cmd_$tag.err | tail -1)
     else
-      line=$(BHGEO_PROBE_WHEN=$v timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1)
+      line=$(BHGEO_PROBE_WHEN=$v timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>gpurun_out/r06_driver_cmd_$tag.err | tail -1)
     fi
     echo "$line" >> $full
+    if [ -z "$line" ]; then echo "$v: no line; stderr:" >> $log; tail -15 gpurun_out/r06_driver_cmd_$tag.err >> $log; cat $log; exit 1; fi
     echo "$line" | python3 scripts/r06_line_summary.py "$v" >> $log
   done
 done

@@ -39,7 +39,8 @@ KERR_FUZZ_DIFFER = 0.04
 # The run repeated with these bounds: 1 499 Kerr draws, 1.85 M rays, 483 k of them horizon rays -- 102 draws have a ray that
 # differs, 618 rays in all: 614 horizon rays (worst draws 10.4 %, 9.9 %, 5.9 % of their horizon rays), 4 near-axis rays (worst
 # draw 0.075 % of its rays), none that is neither.
-KERR_FUZZ_DIFFER_HORIZON = 0.15
+# (asserted at 15 % in round 5; ADVICE r05: near the measured worst, 10.4 %, plus a margin)
+KERR_FUZZ_DIFFER_HORIZON = 0.125
 KERR_FUZZ_DIFFER_OTHER = 0.005
 LAST_COMPARE = {}   # filled by _compare: rays compared, rays further than TOL_END from the oracle, rays beyond the scaled bound
 COND = 500.0     # multiples of the oracle's own 1-ulp input sensitivity S_i (an estimate from three perturbations, not a
@@ -63,7 +64,11 @@ def _sensitivity(oracle, k0, x0, ref_end, **kw):
         return np.max([np.abs(oracle.trace(kp, x0, **kw)["end"] - ref_end).max(1) for kp in pats], axis=0)
 
 
-def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0, **kw):
+ROUNDING_FLIPS = {"draws": 0, "rays": 0, "flips": 0}    # over the whole run, fuzz draws only (see _compare)
+ROUNDING_FLIPS_MAX = 2     # measured: ONE such ray in 9 500 draws / 13 M rays (round 5); a suite run has ~100 draws
+
+
+def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0, rounding_flips=0, **kw):
     o = oracle.trace(k0, x0, **kw)
     spheres = kw.get("spheres")
     if spheres is not None:
@@ -91,11 +96,13 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0,
     else:
         assert np.array_equal(flags, o["flags"])
         sdiff = np.nonzero((steps != o["n_attempted"]) | (acc != o["n_accepted"]))[0]
-        # Identical accept / reject sequences on every ray -- or, for at most two rays of a draw, a sequence the CHECKER
-        # ITSELF produces when the ray's direction moves by an ulp or two: an error norm within rounding of 1.  (9 500 draws,
-        # 13 M rays, round 5, profiles/r05_fuzz6000.log: one such ray -- a horizon ray at rtol 1.5e-6, 29 / 16 steps on the GPU,
-        # 31 / 17 in the checker, 29 / 16 in the checker with k0 scaled by 1 - 1e-16.)
-        assert len(sdiff) <= 2, f"{len(sdiff)} rays differ in step count"
+        # Identical accept / reject sequences on EVERY ray: the default, and what every deterministic test asks.  Only the
+        # randomised draws pass rounding_flips = 2: at most that many rays of a draw may differ, each with a
+        # sequence the CHECKER ITSELF produces when the ray's direction moves by an ulp or two -- an error norm within rounding of
+        # 1.  (9 500 draws, 13 M rays, round 5, profiles/r05_fuzz6000.log: one such ray -- a horizon ray at rtol 1.5e-6, 29 / 16
+        # steps on the GPU, 31 / 17 in the checker, 29 / 16 in the checker with k0 scaled by 1 - 1e-16.)  The run's total is
+        # kept in ROUNDING_FLIPS and may not pass ROUNDING_FLIPS_MAX.
+        assert len(sdiff) <= rounding_flips, f"{len(sdiff)} rays differ in step count (allowed: {rounding_flips})"
         for i in sdiff:
             xi = x0 if np.ndim(x0) == 1 else np.asarray(x0)[i]
             seen = set()
@@ -103,6 +110,13 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0,
                 oo = oracle.trace(np.asarray(k0)[i:i + 1] * (1.0 + eps), xi, **kw)
                 seen.add((int(oo["n_attempted"][0]), int(oo["n_accepted"][0])))
             assert (int(steps[i]), int(acc[i])) in seen, f"ray {i}: GPU {steps[i]}/{acc[i]}, checker {o['n_attempted'][i]}/{o['n_accepted'][i]}, checker near by {seen}"
+        if rounding_flips:
+            ROUNDING_FLIPS["draws"] += 1
+            ROUNDING_FLIPS["rays"] += int(len(steps))
+            ROUNDING_FLIPS["flips"] += int(len(sdiff))
+            if len(sdiff):
+                print(f"rounding flips: {len(sdiff)} in this draw, {ROUNDING_FLIPS}")
+            assert ROUNDING_FLIPS["flips"] <= max(ROUNDING_FLIPS_MAX, 2e-6 * ROUNDING_FLIPS["rays"]), ROUNDING_FLIPS
         LAST_COMPARE["rounding_flips"] = int(len(sdiff))
     d = np.abs(end - o["end"]).max(1) if len(end) else np.zeros(0)
     if len(end):
@@ -115,16 +129,19 @@ def _compare(ctx, oracle, k0, x0, allow_flips=False, outliers=0.0, step_flips=0,
         # a disk-plane crossing is only as well located as the ray is steep: dt = dz / |k_z|
         dsk = o["flags"] == 128
         if dsk.any():
-            steep = np.abs(o["end"][:, 5]) / np.linalg.norm(o["end"][:, 3:6], axis=1)
-            tol = tol + np.where(dsk, 1e-11 / np.maximum(steep, 1e-12), 0.0)
+            # (over the disk rays only: other rows may hold the +-inf / NaN of an overflowed fixed-step state, and a reduction
+            # over inf - inf is an "invalid value" warning in the parity path)
+            kd = o["end"][dsk, 3:6]
+            steep = np.abs(kd[:, 2]) / np.linalg.norm(kd, axis=1)
+            tol[dsk] += 1e-11 / np.maximum(steep, 1e-12)
         # ... and so is the entry point into an object sphere: dt = dg / |n.k|, n the surface normal there
         hit = o["flags"] == 0x88
         if hit.any():
-            c = np.asarray(spheres, float).reshape(-1, 4)[np.maximum(o["object_id"], 0)]
-            nrm = (o["end"][:, 0:3] - c[:, 0:3]) / c[:, 3:4]
-            kk = o["end"][:, 3:6]
+            c = np.asarray(spheres, float).reshape(-1, 4)[o["object_id"][hit]]
+            nrm = (o["end"][hit, 0:3] - c[:, 0:3]) / c[:, 3:4]
+            kk = o["end"][hit, 3:6]
             steep = np.abs((nrm * kk).sum(1)) / np.linalg.norm(kk, axis=1)
-            tol = tol + np.where(hit, 1e-11 / np.maximum(steep, 1e-12), 0.0)
+            tol[hit] += 1e-11 / np.maximum(steep, 1e-12)
         over = d[fin] > tol[fin]
         # how much work the sensitivity-scaled part of the bound does: rays further than the absolute floor from the oracle
         # (rays cut off by the step budget end at a lambda that is the SUM of their step sizes: with tolerances near
@@ -595,7 +612,7 @@ def test_randomised_configurations(ctx, oracle, seed, record_property):
         kw["time_like"] = 1
         k = k * rng.uniform(0.05, 1.5, (n, 1))
     tight = kw.get("rtol", 1e-3) <= 1e-6 and kw["rhs_form"] == 0
-    _compare(ctx, oracle, k, x0, allow_flips=(0.02 if tight else False), outliers=2e-3, **kw)
+    _compare(ctx, oracle, k, x0, allow_flips=(0.02 if tight else False), outliers=2e-3, rounding_flips=2, **kw)
     # on record per draw (junit property / -rA): how many rays needed the sensitivity-scaled term at all, how many it let through
     for key, val in LAST_COMPARE.items():
         record_property(key, val)
@@ -750,7 +767,7 @@ def test_randomised_objects(ctx, oracle, seed):
         a = float(rng.uniform(1.5, 6.0)) * u
         kw.update(disk_r_in=a, disk_r_out=a * float(rng.uniform(1.1, 3.0)))
     tight = kw.get("rtol", 1e-3) <= 1e-6 and kw["rhs_form"] == 0
-    _compare(ctx, oracle, k, cam, allow_flips=(0.02 if tight else False), outliers=2e-3, **kw)
+    _compare(ctx, oracle, k, cam, allow_flips=(0.02 if tight else False), outliers=2e-3, rounding_flips=2, **kw)
 
 
 @pytest.mark.parametrize("seed", range(max(4, int(__import__("os").environ.get("BHG_FUZZ", "48")) // 4)))
@@ -1292,6 +1309,81 @@ def test_trajectories_with_the_thin_disk_event(ctx, oracle):
     assert np.array_equal(res["end_loc"], tr0[0][i, 0:3]) or np.abs(res["end_loc"] - tr0[0][i, 0:3]).max() < 1e-10
 
 
+def test_trajectories_with_object_spheres(ctx, oracle):
+    """bhg_trajectory_objects (ABI 8; VERDICT r05 missing #4): the engine's literal per-ray call is exactly where the reference
+    put its collision stub (RelativisticRenderEngine.py:293-305).  On the rays of the committed `objects` golden set and on
+    seeded frames (wave-per-ray and lane-per-ray shapes; Schwarzschild both forms, Kerr, fixed-step RK4): the flags, sphere
+    ids and entry points of the batch trace (bhg_trace_objects) and of the golden set; the oracle's samples; the curve
+    NaN behind the entry point, every sample in front of it outside every sphere, and bit for bit the samples of the same
+    call without spheres up to there; n_spheres = 0 is bhg_trajectory."""
+    from blackhole_geodesic_calculator_amd import GeodesicIntegratorSchwarzschild
+    g = load_golden("objects")
+    sph = np.asarray(g["spheres"], dtype=np.float64).reshape(-1, 4)
+    kw = dict(r_s=1.0, lambda_end=70.0, max_step=0.25, r_exit=35.0, disk_r_in=3.0, disk_r_out=7.0)
+    T = 128
+    traj, nv, end, flags, obj = ctx.trajectory(g["k0"], g["x0"], _params(**kw), T, spheres=sph)
+    assert np.array_equal(flags, g["flags"]) and np.array_equal(obj, g["object_id"]) and np.abs(end - g["end"]).max() <= 1e-8
+    e2, f2, s2, a2, o2 = ctx.trace(g["k0"], g["x0"], _params(**kw), spheres=sph)
+    assert np.array_equal(flags, f2) and np.array_equal(obj, o2) and np.abs(end - e2).max() < 1e-10
+    cam = np.array([4.0, -24.0, 13.0])
+    rng = np.random.default_rng(61)
+    spheres = np.array([[5.0, 0.0, 0.0, 1.5], [0.0, -6.0, 2.0, 1.2], [0.2, 0.1, 7.0, 1.0], [-4.0, 3.0, -3.0, 1.3]])
+    for n, kw in ((600, dict(r_s=1.0, lambda_end=60.0)),
+                  (2500, dict(r_s=1.0, lambda_end=60.0, rhs_form=1, r_exit=30.0, disk_r_in=2.0, disk_r_out=9.0)),
+                  (300, dict(r_s=1.0, lambda_end=60.0, rhs_form=2, spin=0.45)),
+                  (300, dict(r_s=1.0, lambda_end=40.0, method=1, h_fixed=0.1))):
+        k = (-cam / np.linalg.norm(cam))[None, :] + rng.normal(size=(n, 3)) * 0.2
+        k /= np.linalg.norm(k, axis=1)[:, None]
+        kerr, rk4 = kw.get("rhs_form") == 2, kw.get("method") == 1
+        T = 96
+        traj, nv, end, flags, obj = ctx.trajectory(k, cam, _params(**kw), T, spheres=spheres)
+        e2, f2, s2, a2, o2 = ctx.trace(k, cam, _params(**kw), spheres=spheres)
+        hit = flags == 0x88
+        assert np.array_equal(flags, f2) and np.array_equal(obj, o2)
+        assert hit.sum() > 0.03 * n and np.all(obj[hit] >= 0) and np.all(obj[~hit] == -1)
+        assert np.abs(end[hit] - e2[hit]).max() < (1e-10 if not kerr else 1e-8)
+        c = spheres[obj[hit]]
+        assert np.abs(np.linalg.norm(end[hit, 0:3] - c[:, 0:3], axis=1) - c[:, 3]).max() < 1e-9      # the ray ends ON its sphere
+        tr, onv, ofl = oracle.trajectory(k, cam, T, spheres=spheres, **kw)
+        assert np.array_equal(flags, ofl) and (nv == onv).mean() > 0.99
+        plain = ctx.trajectory(k, cam, _params(**kw), T)
+        for i in np.nonzero(hit & (nv == onv))[0][:120]:
+            m = nv[i]
+            assert 0 < m < T and np.isnan(traj[i, :, m:]).all()
+            assert np.abs(traj[i, :, :m] - tr[i, :, :m]).max() < (1e-8 if not (kerr or rk4) else 1e-4)
+            # the same steps as the call without spheres up to the entry point: the same samples, bit for bit
+            assert np.array_equal(traj[i, :, :m], plain[0][i, :, :m])
+            # ... all of them outside every sphere (the curve stops in front of the one it enters)
+            dist = np.linalg.norm(traj[i, 0:3, :m].T[:, None, :] - spheres[None, :, 0:3], axis=2) - spheres[None, :, 3]
+            assert dist.min() > -1e-9
+        # rays that meet no sphere: the plain call's results altogether
+        free = ~hit
+        assert np.array_equal(traj[free], plain[0][free], equal_nan=True) and np.array_equal(nv[free], plain[1][free])
+        assert np.array_equal(end[free], plain[2][free], equal_nan=True) and np.array_equal(flags[free], plain[3][free])
+    # n_spheres = 0 through the objects entry point is bhg_trajectory
+    k = frame_rays(200, seed=3)
+    t0 = ctx.trajectory(k, CAM, _params(r_s=1.0, lambda_end=50.0), 64)
+    t1 = ctx.trajectory(k, CAM, _params(r_s=1.0, lambda_end=50.0), 64, spheres=np.zeros((0, 4)))
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(t0, t1[:4])) and np.all(t1[4] == -1)
+    # the adaptor: calc_trajectory(spheres=) -- the engine's literal call with the collision test the reference left out
+    gi = GeodesicIntegratorSchwarzschild(mass=0.5, context=ctx)
+    kk = (-cam / np.linalg.norm(cam))[None, :] + np.random.default_rng(62).normal(size=(400, 3)) * 0.2
+    kk /= np.linalg.norm(kk, axis=1)[:, None]
+    tr0 = gi.trace(kk, cam, curve_end=60.0, spheres=spheres)
+    i = int(np.nonzero(tr0["flags"] == 0x88)[0][0])
+    k_xyz, x_xyz, res = gi.calc_trajectory(kk[i], cam, curve_end=60.0, nr_points_curve=10000, spheres=spheres)
+    assert res["hit_object"] and res["object_id"] == int(tr0["object_id"][i]) and not res["hit_blackhole"]
+    assert np.abs(res["end_loc"] - tr0["ray_end"][i, 0:3]).max() < 1e-10 and 0 < x_xyz.shape[1] < 10000
+    # the sampled curve runs up to the sphere: its last sample is within one sample spacing of the entry point
+    assert np.linalg.norm(x_xyz[:, -1] - res["end_loc"]) < 2.0 * 60.0 / 9999 * np.linalg.norm(k_xyz[:, -1]) + 1e-9
+    j = int(np.nonzero(tr0["flags"] != 0x88)[0][0])
+    _, _, res_j = gi.calc_trajectory(kk[j], cam, curve_end=60.0, nr_points_curve=100, spheres=spheres)
+    assert not res_j["hit_object"] and res_j["object_id"] == -1
+    # validation: the spheres are checked like bhg_trace_objects' (a radius <= 0 is refused)
+    with pytest.raises(Exception):
+        ctx.trajectory(k, CAM, _params(r_s=1.0, lambda_end=50.0), 64, spheres=[[1.0, 2.0, 3.0, -1.0]])
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # time_like=True (the solver object's other constructor value, RelativisticRenderEngine.py:134): massive particles
 # ------------------------------------------------------------------------------------------------------------------------
@@ -1375,6 +1467,7 @@ def test_timelike_adaptor_orbits(ctx, oracle):
     assert np.abs(pro[0, 0] - ret[0, 0]) > 1e-3 or np.abs(pro[0, 1] + ret[0, 1]) > 1e-3
 
 
+@pytest.mark.filterwarnings("error:invalid value encountered in reduce")     # (an unmasked NaN reduction in the parity path: VERDICT r05)
 def test_kerr_object_spheres_golden_and_oracle(ctx, oracle):
     """Object spheres with the Boyer-Lindquist form (round 4): the spheres live in the Cartesian frame, the chord rule runs on
     the images of a step's ends, the root search on the image of the dense output.  scipy golden (terminal events on the
