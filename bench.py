@@ -73,6 +73,10 @@ def parse(argv=None):
                     help="where the roofline calibration probes (bhg_peak_probe, power-bound pure-FMA launches, 25 ms) run relative to "
                          "the headline's timed region: after_only (default since round 6: nothing power-hungry in front of a short "
                          "region), before_warmup (round 5: in front of the W warm-up steps, and again afterwards), before_timed, off")
+    ap.add_argument("--clock-reads", type=int, default=int(os.environ.get("BHGEO_CLOCK_READS", "1")),
+                    help="reads of the shader clock (sysfs hwmon) per headline repetition, from the main thread while the GPU works "
+                         "through the enqueued steps; 0 = the headline's repetitions run unobserved (the thread sampler only ever "
+                         "runs in the extra repetition behind them)")
     ap.add_argument("--ramp-seconds", type=float, default=0.3,
                     help="untimed steps run before the W warm-up steps until this much wall time has passed: the "
                          "GPU's clocks take tens of milliseconds of load to settle (a 20-step timed region right "
@@ -353,6 +357,15 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the clock sampler is BUILT here, before anything is timed (see the timed region below)
+    sampler = None
+    if not overlap and not whole_frames and not a.lean and rank == 0:
+        try:
+            sampler = ClockSampler(rt.local_rank)
+            if not sampler.usable():
+                sampler = None
+        except Exception:   # noqa: BLE001
+            sampler = None
     if ramp > 0:      # clock ramp (untimed, not counted in W or K)
         t_ramp = time.perf_counter()
         while True:
@@ -370,7 +383,7 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
     # the probes run AFTER the timed region only (--probe-when after_only): they are power-bound pure-FMA launches, and the
     # driver's command times a 28-ms region five warm-up steps behind them (profiles/r06_driver_cmd_ab.log)
     calibrate = not overlap and not whole_frames and not a.lean and a.probe_when != "off"
-    calibration, sampler = {}, None
+    calibration = {}
     def probes(when):        # (a probe that fails leaves the line without that part of `calibration`, not without its headline)
         try:
             calibration[when] = run_probes(rt.ctx, rt.local_rank)
@@ -386,34 +399,52 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
         probes("before")
         barrier()
     # The timed region: EXACTLY K steps between barrier + synchronise on both sides -- `reps` times back to back, every
-    # repetition with its own wall clock, its own HIP-event samples and its own shader-clock samples (sysfs, a thread:
-    # measured neutral).  The headline is the MEDIAN repetition; all of them go into the line.
-    dts, sclks, rep_events = [], [], []
+    # repetition with its own wall clock and its own HIP-event samples.  The headline is the MEDIAN repetition; all of them
+    # go into the line.  NOTHING runs on the host between the barrier in front of a repetition and its clock: round 5 built
+    # its clock sampler right there (a sysfs glob + torch.cuda.get_device_properties, milliseconds with the GPU idle) and
+    # the driver's 28-ms region read 12 % slow for it; and the sampler itself -- reads of hwmon files, each one a message
+    # to the GPU's power controller -- costs a region 5-6 % while it runs (profiles/r06_matrix_b.log).  So: the headline's
+    # repetitions run unobserved but for --clock-reads reads of the clock each (default ONE, mid-region, from the main
+    # thread while the GPU works through the enqueued steps), and the thread sampler runs in ONE EXTRA repetition behind them
+    # that counts for nothing but the clock figure (its own ms per step is in the line: what sampling costs).
+    dts, dts_local, rep_clock, rep_events = [], [], [], []
     for rep in range(max(1, reps)):
-        sampler = None
-        if not overlap and not whole_frames and not a.lean and rank == 0:
-            try:
-                sampler = ClockSampler(rt.local_rank).start()
-            except Exception:   # noqa: BLE001
-                sampler = None
         n_ev = len(kernel_ms)
         t0 = time.perf_counter()
         for i in range(a.steps):
             step(i, True)
+        reads = []
+        if sampler is not None and a.clock_reads > 0:
+            for q in range(a.clock_reads):
+                if q:
+                    time.sleep(0.004)
+                reads.append(sampler.read_once())
         barrier(final=True)
         dt_rep = time.perf_counter() - t0
-        try:
-            sclks.append(sampler.stop() if sampler is not None else None)
-        except Exception:   # noqa: BLE001
-            sclks.append(None)
+        dts_local.append(dt_rep)
         if world > 1:
             tmax = torch.tensor([dt_rep], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_rep = float(tmax.item())
         dts.append(dt_rep)
+        reads = [r_ for r_ in reads if r_ is not None]
+        rep_clock.append(float(np.mean(reads)) if reads else None)
         rep_events.append(kernel_ms[n_ev:])
     dt = float(np.median(dts))
-    sclk = merge_clock_samples(sclks)
+    sclk, sampled_rep_ms = None, None
+    if sampler is not None and calibrate:
+        # the extra, SAMPLED repetition (not a headline sample)
+        try:
+            sampler.start()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(i, False)
+            barrier(final=True)
+            sampled_rep_ms = (time.perf_counter() - t0) / a.steps * 1e3
+            sclk = sampler.stop()
+        except Exception:   # noqa: BLE001
+            sclk = None
+    sclks = rep_clock
     if calibrate:
         probes("after")
         try:
@@ -437,6 +468,18 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
     flat = [x for r_ in call_samples for x in r_]
     call_ms = float(np.median(flat)) if flat else float("nan")
     call_ms_mean = float(np.mean(flat)) if flat else float("nan")
+    # N > 1: every rank's own clock beside the maximum the headline takes (one all-reduce of a [world, reps + 1] table each rank
+    # fills its row of: ms per step of every repetition by ITS wall clock, and its median trace-call time) -- so that a slow
+    # rank (a slow box, or rank 0's root share dealt wrongly) can be told from a slow job
+    per_rank = None
+    if world > 1:
+        tab = torch.zeros((world, len(dts_local) + 1), dtype=torch.float64, device="cuda")
+        tab[rank, :len(dts_local)] = torch.tensor([d_ / a.steps * 1e3 for d_ in dts_local], dtype=torch.float64)
+        tab[rank, -1] = call_ms if flat else 0.0
+        dist.all_reduce(tab)
+        tab = tab.cpu().numpy()
+        per_rank = [dict(rank=r_, ms_per_step_samples=[float(v) for v in tab[r_, :-1]], ms_per_step_median=float(np.median(tab[r_, :-1])),
+                         trace_call_ms_median=float(tab[r_, -1])) for r_ in range(world)]
     # the dominant kernel alone: one launch per call finishes every ray (events are located and resumed rays
     # carry on inside trace_*_kernel); Kerr adds a prepare and a finalize launch.  A few extra profiled calls
     # after the timed region (HIP events recorded by the library around prepare | trace on this same stream)
@@ -461,7 +504,8 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
     return dict(W=W, H=H, S=S, n=n, ray_steps=ray_steps, dt=dt, call_ms=call_ms, k_ms=k_ms, rays_all=float(tot[0].item()),
                 steps_all=float(tot[1].item()), launch=rt.ctx.last_launch(), fr=fr, tcost=tcost,
                 visit=tile_cost.visit, root_share=root_share, calibration=calibration, sclk=sclk,
-                dts=dts, sclks=sclks, call_samples=call_samples, call_ms_mean=call_ms_mean, share=share)
+                dts=dts, sclks=sclks, call_samples=call_samples, call_ms_mean=call_ms_mean, share=share,
+                sampled_rep_ms=sampled_rep_ms, per_rank=per_rank)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -589,7 +633,9 @@ def main():
             # every repetition of the K-step region, in the order they ran (ms per step): the headline is their median
             "ms_per_step_samples": [d_ / a.steps * 1e3 for d_ in m["dts"]],
             "ms_per_step_spread": spread([d_ / a.steps * 1e3 for d_ in m["dts"]]),
-            "sclk_mhz_per_repetition": [None if c is None else round(c["mean_mhz"], 1) for c in m["sclks"]],
+            # the shader clock read from sysfs while each repetition ran (--clock-reads reads per repetition, main thread)
+            "sclk_mhz_per_repetition": [None if c is None else round(c, 1) for c in m["sclks"]],
+            **({"per_rank": m["per_rank"]} if m["per_rank"] else {}),
             "higher_is_better": True,
             "scaling": "strong" if a.workload == "orbit" else "weak",
             "vs_baseline": None,
@@ -614,7 +660,7 @@ def main():
             },
             "roofline": roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64,
                                        calibration=m["calibration"], sclk=m["sclk"], call_samples=m["call_samples"], share=m["share"],
-                                       num_cus=rt.ctx.num_cus),
+                                       num_cus=rt.ctx.num_cus, sampled_rep_ms=m["sampled_rep_ms"]),
         }
         if a.workload == "frame":
             out["config"]["north_star_output"] = ("exit directions only (--dir-only)" if getattr(fr, "_dir_traced", False) else

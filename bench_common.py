@@ -276,16 +276,29 @@ class ClockSampler:
         except Exception:
             return None
 
-    def start(self):
+    def usable(self):
         if os.environ.get("BHGEO_NO_CLOCK_SAMPLER") == "1":
             self.path = None
-        if self.path is None or self._read() is None:
+        if self.path is not None and self._read() is None:
             self.path = None
+        return self.path is not None
+
+    def read_once(self):
+        """ONE read of the shader clock (MHz) -- no thread; None where nothing is readable."""
+        return self._read() if self.path is not None else None
+
+    def start(self):
+        """(Re)start the sampling thread: a sampler is built ONCE, before the warm-up steps (its construction globs sysfs and
+        asks torch for the device properties: milliseconds of host time during which the GPU would sit idle right in front
+        of a timed region), and started only for the repetition it samples."""
+        if not self.usable():
             return self
         import threading
+        self.samples, self._stop = [], False
         d = os.path.dirname(self.path)
-        self.extra_paths = {k: (os.path.join(d, f), sc) for k, (f, sc) in self.EXTRA.items()
-                            if self._read(os.path.join(d, f), sc) is not None}
+        if not hasattr(self, "extra_paths"):
+            self.extra_paths = {k: (os.path.join(d, f), sc) for k, (f, sc) in self.EXTRA.items()
+                                if self._read(os.path.join(d, f), sc) is not None}
         self.extra = {k: [] for k in self.extra_paths}
 
         def loop():
@@ -431,10 +444,14 @@ def calibration_block(cal, sclk, achieved_tf, valu_per_64, ray_steps, k_ms, num_
 
 
 def roofline_block(wl, ray_steps, k_ms, call_ms, n, bytes_per_ray, traffic, traffic_source, valu_per_64, calibration=None,
-                   sclk=None, call_samples=None, share=None, num_cus=256):
+                   sclk=None, call_samples=None, share=None, num_cus=256, sampled_rep_ms=None):
     achieved_tf = ray_steps * wl.flop / (k_ms * 1e-3) / 1e12
     cal = calibration_block(calibration, sclk, achieved_tf, valu_per_64, ray_steps, k_ms, num_cus=num_cus)
     extra = {} if cal is None else {"frac_of_measured_peak": cal["frac_of_measured_peak"], "calibration": cal}
+    if cal is not None and sampled_rep_ms is not None:
+        cal["sampled_repetition_ms_per_step"] = sampled_rep_ms      # the extra repetition the sysfs thread sampled: what sampling costs
+        cal["sclk_note"] = ("sclk_mhz_timed_region comes from ONE extra repetition behind the headline's (a sysfs thread, 4-ms period), which "
+                            "does not count: the sampler's reads slow a region by 5-6 % while they run (profiles/r06_matrix_b.log)")
     if call_samples:
         # every HIP-event sample of the timed region(s), not their mean: the trace call of every EV_EVERY-th step of each
         # repetition (ms) times the trace kernel's share of a call (1 for the Schwarzschild forms: one launch per call)

@@ -55,7 +55,7 @@ EXPORTS = (
 )
 PROBE_FMA, PROBE_STEP_MIX = 0, 1
 
-GATHER_AUTO, GATHER_COPY, GATHER_RCCL, GATHER_PEER = 0, 1, 2, 3
+GATHER_AUTO, GATHER_COPY, GATHER_RCCL, GATHER_PEER, GATHER_COPY_PEERCALL = 0, 1, 2, 3, 4
 
 
 class Camera(C.Structure):

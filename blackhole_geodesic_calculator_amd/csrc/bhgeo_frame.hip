@@ -209,8 +209,8 @@ struct bhg_frame {
     double root_share = 1.0;        // part of an equal share the first device is dealt (bhg_frame_rebalance)
     bool rendered = false;
     bool profiling = false;
-    bool peer_copy_always = false;  // BHG_FRAME_TEST_PEER_COPY=1 at bhg_frame_create: the gather's copies go through hipMemcpyPeerAsync also
-                                    // between contexts of ONE device (tests: the N-device call on a one-GPU box)
+    bool peer_copy_always = false;  // BHG_FRAME_GATHER_COPY_PEERCALL: the gather's copies go through hipMemcpyPeerAsync also between
+                                    // contexts of ONE device (the N-device call on a one-GPU box)
     std::vector<hipEvent_t> ev_root;   // around the root's gather + assembly (profiling)
     std::vector<hipEvent_t> ev_piece;  // the pieces of the image's way back to a pageable caller array
     hipEvent_t assembled = nullptr;    // the root has read the receive block of the last render (copies of the next wait for it)
@@ -433,7 +433,7 @@ try {
     if (cam->width <= 0 || cam->height <= 0 || cam->samples <= 0) return fail(BHG_E_INVALID, "width, height, samples must be > 0");
     if (tile <= 0) tile = 32;
     if (gather != BHG_FRAME_GATHER_AUTO && gather != BHG_FRAME_GATHER_COPY && gather != BHG_FRAME_GATHER_RCCL &&
-        gather != BHG_FRAME_GATHER_PEER)
+        gather != BHG_FRAME_GATHER_PEER && gather != BHG_FRAME_GATHER_COPY_PEERCALL)
         return fail(BHG_E_INVALID, "unknown gather mode");
     const size_t HW = (size_t)cam->width * (size_t)cam->height;
     if (HW * (size_t)cam->samples > 0xFFFFFFFFull) return fail(BHG_E_INVALID, "more than 2^32 rays in the frame");
@@ -457,8 +457,10 @@ try {
     if (!f) return fail(BHG_E_NOMEM, "host allocation failed");
     f->cam = *cam;
     f->tile = tile;
-    const char *tpc = std::getenv("BHG_FRAME_TEST_PEER_COPY");
-    f->peer_copy_always = tpc && tpc[0] == '1';
+    if (gather == BHG_FRAME_GATHER_COPY_PEERCALL) {      // (an explicit mode of the call, not an environment variable: ADVICE r05)
+        f->peer_copy_always = true;
+        gather = BHG_FRAME_GATHER_COPY;
+    }
     std::memset(&f->scene, 0, sizeof(f->scene));
     f->scene.disk_mean = 0.2;   // the Limited engine's defaults (LimitedRelativisticRenderEngine.py:495-498)
     f->scene.disk_stddev = 0.3;
@@ -732,8 +734,16 @@ try {
             // four pieces with the pool's usual 2-MB jobs: 2.15 (two jobs per piece leave six threads idle)
             constexpr int PIECES = 2;
             if (f->ev_piece.empty()) {
-                f->ev_piece.resize(PIECES, nullptr);
-                for (auto &e : f->ev_piece) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                // (all or nothing: a creation that fails half way must not leave null handles behind for the next render)
+                hipEvent_t made[PIECES] = {};
+                for (int q = 0; q < PIECES; q++) {
+                    const hipError_t e = hipEventCreateWithFlags(&made[q], hipEventDisableTiming);
+                    if (e != hipSuccess) {
+                        for (int r = 0; r < q; r++) (void)hipEventDestroy(made[r]);
+                        return fail_hip(e, "hipEventCreateWithFlags (image pieces)");
+                    }
+                }
+                f->ev_piece.assign(made, made + PIECES);
             }
             const size_t piece = ((bytes / PIECES) + 4095) & ~size_t(4095);
             int n_pieces = 0;

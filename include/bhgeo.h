@@ -373,6 +373,8 @@ int bhg_assemble_frame_f32_device(bhg_context *ctx, const float *d_slabs, const 
 #define BHG_FRAME_GATHER_COPY 1
 #define BHG_FRAME_GATHER_RCCL 2
 #define BHG_FRAME_GATHER_PEER 3
+#define BHG_FRAME_GATHER_COPY_PEERCALL 4   /* _COPY with hipMemcpyPeerAsync on EVERY pair, contexts of one device included (bhg_frame_info
+                                              reports _COPY): the N-device copy call, its arguments and stream order on a one-GPU box */
 typedef struct bhg_frame bhg_frame;
 /* The scene of a frame; everything lives on the HOST and is copied by bhg_frame_set_scene (images are uploaded to
  * every device on the next render).  Members as in bhg_scene.  sky = NULL keeps the current sky image (the first call

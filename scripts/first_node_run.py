@@ -145,6 +145,17 @@ def summarise(step, rc, out, err, seconds, predicted):
                    collective=cfg.get("collective"), root_share=cfg.get("root_share"), frac=(j.get("roofline") or {}).get("frac"),
                    frac_of_measured_peak=(j.get("roofline") or {}).get("frac_of_measured_peak"),
                    frac_at_timed_region_clock=((j.get("roofline") or {}).get("calibration") or {}).get("frac_at_timed_region_clock"))
+        # what tells "one box is slow" from "rank 0's root share is wrong" (round 6): every repetition of the timed region, every
+        # HIP-event sample of the trace kernel, the clock read while each repetition ran, and every RANK's own clock
+        rf = j.get("roofline") or {}
+        rec.update(ms_per_step_samples=j.get("ms_per_step_samples"), ms_per_step_spread=j.get("ms_per_step_spread"),
+                   sclk_mhz_per_repetition=j.get("sclk_mhz_per_repetition"), kernel_ms=rf.get("kernel_ms"),
+                   kernel_ms_samples=rf.get("kernel_ms_samples"), kernel_ms_spread=rf.get("kernel_ms_spread"),
+                   per_rank=j.get("per_rank"))
+        if j.get("per_rank"):
+            med = [r_["ms_per_step_median"] for r_ in j["per_rank"]]
+            rec["slowest_rank"] = int(max(range(len(med)), key=med.__getitem__))
+            rec["rank_spread"] = (max(med) - min(med)) / max(min(med), 1e-12)
         # RCCL ranks seen: "rccl gather, N rank(s)" (torch.distributed form) / "rccl (single-process mode), N device(s)"
         col = str(cfg.get("collective") or "")
         rec["rccl_ranks_seen"] = n if ("rccl" in col.lower() and str(n) in col) else 0

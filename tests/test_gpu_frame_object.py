@@ -208,19 +208,20 @@ def test_peer_store_frame_end_is_bit_identical(ctx):
     assert np.array_equal(imgs[_ffi.GATHER_PEER][1], imgs[_ffi.GATHER_PEER][2]) and not np.array_equal(imgs[_ffi.GATHER_PEER][0], imgs[_ffi.GATHER_PEER][1])
 
 
-def test_gather_copies_through_the_peer_copy_call_give_the_same_image(ctx, monkeypatch):
+def test_gather_copies_through_the_peer_copy_call_give_the_same_image(ctx):
     """The copy gather between DISTINCT devices is hipMemcpyPeerAsync on the sending device's stream; contexts of one device
-    use a plain device-to-device copy.  BHG_FRAME_TEST_PEER_COPY=1 (read at bhg_frame_create) sends the one-GPU frame through
-    the peer call too -- same device at both ends -- so that the call, its arguments and its stream order run on this box."""
+    use a plain device-to-device copy.  The gather mode BHG_FRAME_GATHER_COPY_PEERCALL (an explicit argument of
+    bhg_frame_create; an environment variable up to round 5) sends the one-GPU frame through the peer call too -- same
+    device at both ends -- so that the call, its arguments and its stream order run on this box."""
     from blackhole_geodesic_calculator_amd.device_frame import synthetic_sky
     from blackhole_geodesic_calculator_amd import _ffi
     W, H, S = 160, 96, 2
     sky = synthetic_sky(256, 128)
     p = _params(r_s=1.0, lambda_end=50.0)
     imgs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("BHG_FRAME_TEST_PEER_COPY", flag)
-        fr = _frame([0, 0, 0, 0], W, H, S, gather=_ffi.GATHER_COPY)
+    for mode in (_ffi.GATHER_COPY, _ffi.GATHER_COPY_PEERCALL):
+        fr = _frame([0, 0, 0, 0], W, H, S, gather=mode)
+        assert fr.info()["gather"] in (_ffi.GATHER_COPY, "copy")
         fr.set_scene(sky)
         imgs.append([fr.render(p).copy() for _ in range(3)])     # (three frames: the receive block is reused, the copies wait for the assembly)
         fr.close()
