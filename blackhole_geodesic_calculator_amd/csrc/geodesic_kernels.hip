@@ -1597,22 +1597,20 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // Outcome of a parked step
 constexpr int PARK_ENDED = 0, PARK_RESUME = 1, PARK_UNCERTIFIED = 2;
 
-// The SHORT way: one candidate event -- exit sphere or disk plane; a horizon crossing never comes here (short_kind()) --
-// whose event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything
-// when the certificate (or the iteration) fails: the step then goes to the long list.
+// The short search itself, on a step whose stages are at hand: x, v, a1, t = the step's start, h = its signed length, t_new its
+// end, a2..a7 / xn / vn / r_new its stages and end state, h_next the controller's |h| for the step after it.  Called by the
+// drain (which recomputes the stages from the parked record, bit for bit) and -- BHG_INPLACE_MIN builds -- by the step loop
+// itself with the stages still in registers.  PARK_ENDED: the ray's result is stored.  PARK_RESUME: no terminal event, the
+// ray carries on from the step's end (the caller takes xn, vn, a7, t_new, r_new).  PARK_UNCERTIFIED: nothing touched.
 template <int RHS, int EVT>
-__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
+__device__ __forceinline__ int dp54_short_core(const TraceArgs &A, const double x[3], const double v[3], const double a1[3], double t,
+                                               double t_new, double h, const double a2[3], const double a3[3], const double a4[3],
+                                               const double a5[3], const double a6[3], const double a7[3], const double xn[3],
+                                               const double vn[3], uint32_t kind, uint32_t idx, uint32_t n_att, uint32_t n_acc)
 {
     constexpr bool BL = RHS == BHG_RHS_KERR_BL_;
-    const double t = P.t, h_next = P.h_abs;
-    // the step as the integrate loop took it: same operations on the same bits
-    double t_new = t + P.r_cur;
-    if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
-    const double h = t_new - t;
-    double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
-    dp54_stages<RHS>(P.x, P.v, P.a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
     Dense d;
-    build_dense_pos(d, t, h, P.x, P.v, P.a1, a2, a3, a4, a5, a6, a7);
+    build_dense_pos(d, t, h, x, v, a1, a2, a3, a4, a5, a6, a7);
 
     const bool is_disk = (EVT & EVT_DISK) && kind == EV_DISK;
     double Ec[3], Dc[3];
@@ -1629,24 +1627,24 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
         comp = is_disk ? 1 : 0;
         if (is_disk) {
             // the plane theta* = pi/2 + k pi between the step ends (more than one: Brent decides)
-            const double k0 = floor((P.x[1] - 1.5707963267948966) * 0.3183098861837907);
+            const double k0 = floor((x[1] - 1.5707963267948966) * 0.3183098861837907);
             const double k1 = floor((xn[1] - 1.5707963267948966) * 0.3183098861837907);
             target = __builtin_fma(3.141592653589793, fmax(k0, k1), 1.5707963267948966);
-            mono = fabs(k1 - k0) == 1.0 && fabs(P.v[1]) > 1.0000001 * Dc[1];
+            mono = fabs(k1 - k0) == 1.0 && fabs(v[1]) > 1.0000001 * Dc[1];
         } else {
             target = A.r_exit;
-            mono = P.v[0] > 1.0000001 * Dc[0];
+            mono = v[0] > 1.0000001 * Dc[0];
         }
     } else if (is_disk) {
-        mono = fabs(P.v[2]) > 1.0000001 * Dc[2];
+        mono = fabs(v[2]) > 1.0000001 * Dc[2];
     } else {
         target = A.r_exit * A.r_exit;
         double xv = 0.0, S = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            xv = __builtin_fma(P.x[c], P.v[c], xv);
-            const double av = fabs(P.v[c]);
-            S = __builtin_fma(fabs(P.x[c]), Dc[c], S);
+            xv = __builtin_fma(x[c], v[c], xv);
+            const double av = fabs(v[c]);
+            S = __builtin_fma(fabs(x[c]), Dc[c], S);
             S = __builtin_fma(h, __builtin_fma(av, Ec[c] + Dc[c], Ec[c] * Dc[c]), S);
         }
         S *= 1.0000001;
@@ -1683,7 +1681,7 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
         if (is_disk) return xs_[2];
         return __builtin_fma(xs_[2], xs_[2], __builtin_fma(xs_[1], xs_[1], xs_[0] * xs_[0])) - target;
     };
-    const double g0 = gfun(P.x), g1 = gfun(xn);
+    const double g0 = gfun(x), g1 = gfun(xn);
     double dg, xs[3];
     // the step ends bracket the root (that is what parked the step); G is monotone between them
     double lo = 0.0, hi = 1.0;
@@ -1727,17 +1725,35 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
         terminal = Rc >= A.disk_r_in && Rc <= A.disk_r_out;
     }
     if (terminal) {
-        dense_dir_at(th, h, P.v, P.a1, a3, a4, a5, a6, a7, ve);
+        dense_dir_at(th, h, v, a1, a3, a4, a5, a6, a7, ve);
         const uint32_t fl = is_disk ? BHG_FLAG_HIT_DISK_ : BHG_FLAG_EXITED_SPHERE_;
-        store_result(A, P.idx, xe, ve, fl, P.n_att, P.n_acc);
+        store_result(A, idx, xe, ve, fl, n_att, n_acc);
         return PARK_ENDED;
     }
     // a disk-plane crossing outside the annulus: the ray is final if the step reached lambda_end (base.py:203-204),
     // otherwise it carries on from the step's end
     if (t_new - A.lambda_end >= 0.0) {
-        store_result(A, P.idx, xn, vn, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
+        store_result(A, idx, xn, vn, BHG_FLAG_REACHED_END_, n_att, n_acc);
         return PARK_ENDED;
     }
+    return PARK_RESUME;
+}
+
+// The SHORT way: one candidate event -- exit sphere or disk plane; a horizon crossing never comes here (short_kind()) --
+// whose event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything
+// when the certificate (or the iteration) fails: the step then goes to the long list.
+template <int RHS, int EVT>
+__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
+{
+    const double t = P.t, h_next = P.h_abs;
+    // the step as the integrate loop took it: same operations on the same bits
+    double t_new = t + P.r_cur;
+    if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
+    const double h = t_new - t;
+    double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
+    dp54_stages<RHS>(P.x, P.v, P.a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
+    const int outcome = dp54_short_core<RHS, EVT>(A, P.x, P.v, P.a1, t, t_new, h, a2, a3, a4, a5, a6, a7, xn, vn, kind, P.idx, P.n_att, P.n_acc);
+    if (outcome != PARK_RESUME) return outcome;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         R.x[c] = xn[c];
@@ -2475,7 +2491,37 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                             atomicAdd(A.diag + BHG_DIAG_HIST + 130, (unsigned long long)__builtin_popcountll(am_));   // all parked steps
                     }
 #endif
-                    if (ev_h || ev_e || ev_d || ev_o) {
+                    bool park = ev_h || ev_e || ev_d || ev_o, ended_here = false;
+#ifdef BHG_INPLACE_MIN
+                    // EXPERIMENT, measured and NOT KEPT (round 6, VERDICT r05 task 2b; off unless built with
+                    // -DBHG_INPLACE_MIN=K): when at least K lanes of the wave hold a step with ONE candidate event of a short
+                    // kind in this same iteration, those lanes resolve it HERE, with the stages still in registers -- the
+                    // drain's own certificate, Newton steps and direction at the root (dp54_short_core: the same bits, checked
+                    // on 37.7 M rays) -- instead of parking it: no slot, no recomputed stages.  A failed certificate parks as
+                    // before.  Same box, K = 20 / 32 / 48 (profiles/r06_inplace_ab.log): config 3 +0.0 / +0.1 / -0.1 %, Kerr +
+                    // disk +0.2 / -0.7 / -0.8 %, config 4 -0.5 / -0.4 / -0.4 %, headline 0.  Why: events are NOT wave-coherent
+                    // under lane refill -- a ray parks once per ~10 steps, so SOME lane parks in 54 % of the iterations, 8-12
+                    // lanes at a time; iterations with >= 32 such lanes hold 14-28 % of the events
+                    // (profiles/r06_event_coherence.md) -- and a resolution run for k lanes costs what one run for 64 does.
+                    if (HasShort<true, EVT>::value) {
+                        const bool one_short = (ev_e != ev_d) && !ev_h && !ev_o;
+                        if (__builtin_popcountll(__ballot(one_short)) >= BHG_INPLACE_MIN) {
+                            if (one_short) {
+                                const int outcome = dp54_short_core<RHS, EVT>(A, L.x, L.v, L.a1, L.t, t_new, h, a2, a3, a4, a5, a6, a7, xn, vn,
+                                                                              ev_e ? EV_EXIT : EV_DISK, L.idx, L.n_att, L.n_acc);
+                                if (outcome == PARK_ENDED) {
+                                    park = false;
+                                    ended_here = true;
+                                } else if (outcome == PARK_RESUME) {
+                                    park = false;        // (a plane crossing outside the annulus: the step is taken like any other)
+                                }
+                            }
+                        }
+                    }
+#endif
+                    if (ended_here) {
+                        L.active = 0u;
+                    } else if (park) {
                         // Park the step: x, v, a1, t still hold its START (the event drain recomputes it from there),
                         // h_abs is already the controller's choice for the next step, the radius register takes the
                         // |h| this step tried.  The record goes into the wave's LDS pool when the lane is next served.

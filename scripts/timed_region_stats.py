@@ -41,18 +41,23 @@ def main():
             if sub in r["Kernel_Name"]:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    n_timed = K * per_step
+    reps = max(1, len(b.get("ms_per_step_samples") or [1]))      # (round 6: the K-step region is repeated, every repetition timed)
+    n_timed = K * per_step * reps
     if len(rows) < n_timed + extra:
         raise SystemExit(f"only {len(rows)} launches of *{sub}* in the trace, need {n_timed} + {extra}")
     timed = rows[len(rows) - extra - n_timed: len(rows) - extra]
     dur = [e - s for s, e, _ in timed]
     every = [e - s for s, e, _ in rows]
     avg = sum(dur) / len(dur)
+    med = sorted(dur)[len(dur) // 2]
     rf = b["roofline"]
     frac_trace = rf["flop_per_ray_step"] * rf["ray_steps_per_launch"] / (avg * 1e-9) / 1e12 / rf["peak"]
+    frac_trace_median = rf["flop_per_ray_step"] * rf["ray_steps_per_launch"] / (med * 1e-9) / 1e12 / rf["peak"]
     res = {
         "kernel": timed[0][2], "box": box_id(),
-        "timed_region": {"launches": len(dur), "AverageNs": avg, "MinNs": min(dur), "MaxNs": max(dur)},
+        "timed_region": {"launches": len(dur), "repetitions": reps, "AverageNs": avg, "MedianNs": med, "MinNs": min(dur), "MaxNs": max(dur)},
+        "frac_from_kernel_trace_median": frac_trace_median,      # (the bench line's kernel_ms is the MEDIAN of its HIP-event samples since round 6)
+        "relative_difference_median": frac_trace_median / rf["frac"] - 1.0,
         "all_launches_of_the_run": {"launches": len(every), "AverageNs": sum(every) / len(every), "MinNs": min(every), "MaxNs": max(every)},
         "frac_from_kernel_trace": frac_trace,
         "frac_from_bench_line": rf["frac"], "kernel_ms_from_bench_line": rf["kernel_ms"],
