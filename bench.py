@@ -432,16 +432,29 @@ def measure(rt, wl, sky, nx, ny, ramp, overlap=False, whole_frames=False, reps=1
         rep_events.append(kernel_ms[n_ev:])
     dt = float(np.median(dts))
     sclk, sampled_rep_ms = None, None
-    if sampler is not None and calibrate:
-        # the extra, SAMPLED repetition (not a headline sample)
+    # the extra, SAMPLED repetition (not a headline sample).  Every step is a collective when N > 1: all ranks run it or none
+    # does -- rank 0, the only one that samples, says which
+    extra = torch.tensor([1.0 if (sampler is not None and calibrate) else 0.0], device="cuda")
+    if world > 1:
+        dist.broadcast(extra, src=0)
+    if float(extra.item()) != 0.0:
         try:
-            sampler.start()
-            t0 = time.perf_counter()
-            for i in range(a.steps):
-                step(i, False)
-            barrier(final=True)
-            sampled_rep_ms = (time.perf_counter() - t0) / a.steps * 1e3
-            sclk = sampler.stop()
+            if sampler is not None:
+                sampler.start()
+        except Exception:   # noqa: BLE001
+            pass
+        # (long enough for a clock mean worth the name: >= 0.12 s, i.e. >= 30 samples at the sampler's 4-ms period -- the
+        # driver's 20-step region is 28 ms, 7 samples: ADVICE r05)
+        n_extra = max(a.steps, int(0.12 / max(dt / a.steps, 1e-6)) + 1)
+        if whole_frames:
+            n_extra = a.steps
+        t0 = time.perf_counter()
+        for i in range(n_extra):
+            step(i, False)
+        barrier(final=True)
+        sampled_rep_ms = (time.perf_counter() - t0) / n_extra * 1e3
+        try:
+            sclk = sampler.stop() if sampler is not None else None
         except Exception:   # noqa: BLE001
             sclk = None
     sclks = rep_clock
