@@ -1052,10 +1052,18 @@ __device__ __forceinline__ void store_result(const TraceArgs &A, uint32_t idx, c
     store_end_state(A, idx, x, v);
     // (flags, n_steps, n_accepted are never null here: the C-ABI layer points them at its workspace when the caller
     // passes NULL -- three pointer tests less in a path that runs in nearly every iteration of the step loop)
+#ifdef BHG_EXPERIMENT_NO_NARROW_STORES
+    // MEASUREMENT ONLY (round 6, VERDICT r05 task 4 i): the upper bound of what packing flags and both counters into one
+    // wider store could save -- they are not stored at all (results are then incomplete: never a product build)
+    (void)flags;
+    (void)n_att;
+    (void)n_acc;
+#else
     *at_offset(A.flags, idx) = (uint8_t)flags;
     const uint32_t o4 = idx * 4u;
     *at_offset(A.n_steps, o4) = n_att;
     *at_offset(A.n_accepted, o4) = n_acc;
+#endif
 }
 
 
