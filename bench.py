@@ -633,6 +633,11 @@ def main():
     if rank == 0:
         traffic, traffic_source, valu_per_64 = counters_for(a, wl, live, ray_steps)
         bytes_per_ray = BYTES_PER_RAY_DIR if getattr(fr, "_dir_traced", False) else BYTES_PER_RAY
+        if a.workload == "disk":
+            # the five cameras' frames are ONE trace call with PER-RAY origins: 24 B/ray more read ("24 B in
+            # (k0; x0 shared) or 48 B (per-ray x0)") -- up to round 5 the line priced this call at the shared-origin figure
+            # and its traffic read 1.34 x the algorithmic bytes for it
+            bytes_per_ray += 24
         F = wl.flop
         out = {
             "metric": wl.metric(),
