@@ -1,6 +1,6 @@
 """Round 5: flags / attempted / accepted step counts of the device against the checker on EVERY ray of a sweep of full-size
 Schwarzschild frames (1024 x 1024 x 5 each) -- cameras near and far, on and off the axis, narrow and wide fields of view,
-other masses, tolerances, step caps, exit sphere, both right-hand-side forms -> gpurun_out/r05_every_ray_sweep.json"""
+other masses, tolerances, step caps, exit sphere, both right-hand-side forms -> gpurun_out/<tag>_every_ray_sweep.json (tag = argv[1], default r05)"""
 import json
 import sys
 import time
@@ -58,5 +58,5 @@ for c in cases:
     print(json.dumps(rec), flush=True)
     out.append(rec)
     del fr
-json.dump(out, open("gpurun_out/r05_every_ray_sweep.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/" + (sys.argv[1] if len(sys.argv) > 1 else "r05") + "_every_ray_sweep.json", "w"), indent=1)
 print("TOTAL rays", sum(r["rays"] for r in out), "flag diffs", sum(r["flag_diff"] for r in out), "attempted diffs", sum(r["attempted_diff"] for r in out))

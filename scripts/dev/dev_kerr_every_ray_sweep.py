@@ -1,6 +1,6 @@
 """Round 5: flags / attempted / accepted step counts of the device against the checker on EVERY ray of a sweep of full-size
 Kerr frames (1024 x 1024 x 5 each, Boyer-Lindquist) -- spins from -0.95 to 0.998 M, cameras from 5 to 85 degrees off the
-axis, near and far, with the thin disk, the exit sphere, other tolerances -> gpurun_out/r05_kerr_every_ray_sweep.json"""
+axis, near and far, with the thin disk, the exit sphere, other tolerances -> gpurun_out/<tag>_kerr_every_ray_sweep.json (tag = argv[1], default r05)"""
 import json
 import sys
 import time
@@ -61,6 +61,6 @@ for c in cases:
     print(json.dumps(rec), flush=True)
     out.append(rec)
     del fr
-json.dump(out, open("gpurun_out/r05_kerr_every_ray_sweep.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/" + (sys.argv[1] if len(sys.argv) > 1 else "r05") + "_kerr_every_ray_sweep.json", "w"), indent=1)
 print("TOTAL rays", sum(r["rays"] for r in out), "flag diffs", sum(r["flag_diff"] for r in out), "step diffs", sum(r["step_diff"] for r in out),
       "of them on rays that do not end on the horizon", sum(r["step_diff_other_rays"] for r in out))

@@ -530,3 +530,50 @@ def test_calls_of_one_context_on_different_streams_stay_ordered(ctx):
     torch.cuda.synchronize()
     for end, fl, st in outs:
         assert _same_bits(end, want[0]) and _same_bits(fl, want[1]) and _same_bits(st, want[2])
+
+
+def test_a_callers_stream_may_be_destroyed_right_after_its_call(ctx):
+    """the library must not touch a caller's stream after the call that was given it has returned.  Calls on raw HIP
+    streams (hipStreamCreate through ctypes: torch pools its streams and never destroys one) that are DESTROYED as soon as the
+    call has returned -- while their kernels may still be running -- each followed by a call on another stream: every call's
+    results equal the serial ones, no call fails (up to round 5 the next call recorded its ordering event on the dead handle)."""
+    import ctypes as C
+    import torch
+    from blackhole_geodesic_calculator_amd.device_frame import DeviceFrame
+    hip = None
+    # (by the soname libbhgeo.so itself is linked against, so that the loader hands back the runtime already in the process)
+    for name in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    if hip is None:
+        pytest.skip("libamdhip64 not loadable through ctypes")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    fr = DeviceFrame(ctx, 512, 512, 2, fov_x=0.6, fov_y=0.6)
+    fr.generate_rays()
+    n = fr.n
+    p = _params(r_s=1.0, lambda_end=50.0)
+    want = _trace_device(ctx, p, fr.d_k0, x0_shared=CAM)
+    outs = []
+    for rep in range(8):
+        end = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+        fl = torch.empty(n, dtype=torch.uint8, device="cuda")
+        st = torch.empty(n, dtype=torch.int32, device="cuda")
+        s = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s)) == 0
+        ctx.trace_device(p, n, fr.d_k0.data_ptr(), end.data_ptr(), x0_shared=CAM, d_flags=fl.data_ptr(), d_n_steps=st.data_ptr(),
+                         stream=s.value)
+        assert hip.hipStreamDestroy(s) == 0          # (the runtime lets the queued work finish; the HANDLE is dead from here on)
+        outs.append((end, fl, st))
+        if rep % 2 == 1:      # ... and every other time a call on the null stream in between
+            e2 = torch.empty((n, 6), dtype=torch.float64, device="cuda")
+            f2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+            s2 = torch.empty(n, dtype=torch.int32, device="cuda")
+            ctx.trace_device(p, n, fr.d_k0.data_ptr(), e2.data_ptr(), x0_shared=CAM, d_flags=f2.data_ptr(), d_n_steps=s2.data_ptr())
+            outs.append((e2, f2, s2))
+    torch.cuda.synchronize()
+    for end, fl, st in outs:
+        assert _same_bits(end, want[0]) and _same_bits(fl, want[1]) and _same_bits(st, want[2])
