@@ -18,6 +18,12 @@ for what in (sys.argv[1:] or ["frame", "disk", "diskkerr", "orbit", "exit"]):
     elif what == "exit":
         fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
         p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
+    elif what in ("kerr", "kerroff"):
+        # config 5 (on-axis camera) / the off-axis Kerr frame of the suite
+        inc = np.radians(60.0)
+        kwf = dict(origin=(30 * np.sin(inc), 0.0, 30 * np.cos(inc)), rotation_euler=(0.0, inc, 0.0)) if what == "kerroff" else {}
+        fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6, **kwf)
+        p = _ffi.make_params(r_s=1.0, lambda_end=50.0, rhs_form=2, spin=0.45)
     else:
         fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
         p = _ffi.make_params(r_s=1.0, lambda_end=50.0)
