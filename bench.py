@@ -10,9 +10,15 @@ per-pixel RGBA to rank 0 (asynchronous, overlapping the next frame's trace).  Th
 (exit position and direction, 48 B/ray: what spacetime_ray_cast returns, :307-308 -- the headline since round 5);
 --dir-only gives the sky frame's form (exit directions only), reported beside the headline as sky_frame_dir_only.
 
+The timed region -- EXACTLY --steps steps between barrier + synchronise -- is run --reps times (default 5); the headline is the
+MEDIAN repetition, every repetition is in the line (ms_per_step_samples) and so is every HIP-event sample of the trace kernel
+(roofline.kernel_ms_samples).  Nothing runs on the host between a repetition's barrier and its clock (round 5 built its clock
+sampler there and the driver's 28-ms region read 12 % slow: DESIGN.md section 6.1).
+
 roofline.calibration: bhg_peak_probe (a pure v_fma_f64 kernel and one with the step loop's instruction mix, in the trace
-kernels' launch geometry) before the warm-up steps and right after the timed region, and the shader clock sampled from
-sysfs while the region runs -> frac_of_measured_peak, frac_at_timed_region_clock beside frac (the vendor's 78.6 TFLOP/s).
+kernels' launch geometry) AFTER the timed region (--probe-when), one read of the shader clock per repetition from the main
+thread, and a sysfs sampler thread in ONE EXTRA repetition that does not count (its reads slow a region by 5-6 %)
+-> frac_of_measured_peak, frac_at_timed_region_clock beside frac (the vendor's 78.6 TFLOP/s).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the headline figures are WEAK scaling --
 the frame grows to (1024*nx) x (1024*ny), nx*ny = N, over the same window of directions, so every rank still
