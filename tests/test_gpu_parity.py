@@ -1325,6 +1325,12 @@ def test_trajectories_with_object_spheres(ctx, oracle):
     assert np.array_equal(flags, g["flags"]) and np.array_equal(obj, g["object_id"]) and np.abs(end - g["end"]).max() <= 1e-8
     e2, f2, s2, a2, o2 = ctx.trace(g["k0"], g["x0"], _params(**kw), spheres=sph)
     assert np.array_equal(flags, f2) and np.array_equal(obj, o2) and np.abs(end - e2).max() < 1e-10
+    # ... and the Boyer-Lindquist golden set (scipy terminal events on the Cartesian image of the Kerr solve)
+    gk = load_golden("kerr_objects")
+    kwk = dict(r_s=1.0, lambda_end=60.0, max_step=0.5, rhs_form=2, spin=float(gk["spin"]))
+    _, nvk, endk, flk, objk = ctx.trajectory(gk["k0"], gk["x0"], _params(**kwk), 64, spheres=gk["spheres"])
+    assert np.array_equal(flk, gk["flags"]) and np.array_equal(objk, gk["object_id"]) and np.abs(endk - gk["end"]).max() < 1e-6
+    assert np.all(nvk[flk == 0x88] < 64)
     cam = np.array([4.0, -24.0, 13.0])
     rng = np.random.default_rng(61)
     spheres = np.array([[5.0, 0.0, 0.0, 1.5], [0.0, -6.0, 2.0, 1.2], [0.2, 0.1, 7.0, 1.0], [-4.0, 3.0, -3.0, 1.3]])
