@@ -44,6 +44,10 @@
 
 // 1: the trace kernels work out the start records themselves (no prepare launch); 0: every form runs the prepare
 // pass (the code is then not compiled into the trace kernels at all).  The trajectory kernels always use the pass.
+// Steps run AHEAD of the step loop by the short drain (EV_AHEAD, RunsAhead below): on unless built with -DBHG_NO_AHEAD
+#if !defined(BHG_NO_AHEAD) && !defined(BHG_AHEAD)
+#define BHG_AHEAD 1
+#endif
 #ifndef BHG_INLINE_PREPARE
 #define BHG_INLINE_PREPARE 1
 #endif
@@ -649,7 +653,28 @@ __device__ __forceinline__ void entry_put(QEntry<RHS> &e, const double x[3], con
 
 // Kinds of event a parked step may hold (the `bits` word of its record; they never reach flags[]).
 constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
+// ... and (BHG_AHEAD builds) a step that has NOT been computed yet: the lane's last accepted step ended close enough to
+// the exit sphere that the next one is expected to leave it, so the lane hands the ray -- a queue-style record: the state at
+// the step's start, the |h| to try, the radius there -- to the short drain, which runs the WHOLE step (stages, error norm,
+// controller, event tests) and then locates the exit; the lane takes a fresh ray one iteration earlier and the step is
+// computed once instead of twice.  Where the step is computed never changes a result.
+constexpr uint32_t EV_AHEAD = 16u;
+// Which kernel variants do: the Schwarzschild forms with the exit sphere and WITHOUT the thin disk -- config 4's kernel <0,5>
+// and the exit-only frames <0,1>, <1,1>.  Measured, round 6 (profiles/r06_ahead_ab.log, bit-identical on eight workloads):
+// config 4 -2.4 % time, the exit frame -2.2 %.  Not with the disk: <0,3> sits at 167 VGPRs and no scratch, and the drain's
+// pass over such a step (error norm + the two-kind search; with or without the disk pre-filter in it -- both were built)
+// costs it 140 B of scratch per lane, part of it in blocks of the MAIN loop (result stores, deposit: seen in the ISA), which is
+// the trap section 4.1 of DESIGN.md describes.  Not the Boyer-Lindquist kernels: +3.1 % time on a Kerr exit frame (two waves per SIMD, 32 B of
+// scratch already).  BHG_NO_AHEAD builds without.
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
+template <int RHS, int EVT>
+struct RunsAhead {
+#ifdef BHG_AHEAD
+    static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 && (EVT & 2 /* EVT_DISK */) == 0 && RHS != BHG_RHS_KERR_BL_;
+#else
+    static constexpr bool value = false;
+#endif
+};
 
 // Boyer-Lindquist position (r, theta, phi) -> Cartesian: x = sqrt(r^2 + a^2) sin th cos ph, y = ... sin ph, z = r cos th.
 // Object spheres live in the Cartesian frame the boundary speaks; a Kerr ray meets them through this (the RHS's own sincos).
@@ -1747,21 +1772,121 @@ __device__ __forceinline__ int dp54_short_core(const TraceArgs &A, const double 
     return PARK_RESUME;
 }
 
+__device__ __forceinline__ void lane_state_copy(Lane &R, const Lane &P)
+{
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        R.x[c] = P.x[c];
+        R.v[c] = P.v[c];
+        R.a1[c] = P.a1[c];
+    }
+    R.t = P.t;
+    R.h_abs = P.h_abs;
+    R.r_cur = P.r_cur;
+}
+
 // The SHORT way: one candidate event -- exit sphere or disk plane; a horizon crossing never comes here (short_kind()) --
 // whose event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything
 // when the certificate (or the iteration) fails: the step then goes to the long list.
+//
+// BHG_AHEAD builds: the same function also runs steps AHEAD of the loop (kind == EV_AHEAD): P is then a queue-style record --
+// x, v, a1, t at the step's start, h_abs = the |h| the controller chose for it, r_cur = the radius there, the step counts
+// before it -- of a ray whose last step was ACCEPTED, and this is one whole pass of the step loop's body on it, operation
+// for operation: clamp, stages (the ONE stage computation both kinds of record share: a drain usually holds both), error
+// norm, factor, accept / reject, event tests, disk pre-filter -- and then the short search if the step holds one short event.
+//   PARK_ENDED        the ray's result is stored (exit / disk located, or lambda_end reached);
+//   PARK_RESUME       the ray carries on through the queue: from the step's end (accepted, no terminal event), or from its
+//                     start with the reduced step (rejected: r_bits = 1), or unchanged where one of the step prologue's rare
+//                     cases applies (step budget, step-size floor: the loop's own code deals with those);
+//   PARK_UNCERTIFIED  the step holds what the short search does not take (horizon, object spheres, several candidates, a
+//                     failed certificate): P has become the ordinary parked record of that step, kind its event bits.
 template <int RHS, int EVT>
-__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, const Lane &P, uint32_t kind, Lane &R)
+__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, Lane &P, uint32_t &kind, Lane &R, uint32_t &r_bits)
 {
-    const double t = P.t, h_next = P.h_abs;
-    // the step as the integrate loop took it: same operations on the same bits
-    double t_new = t + P.r_cur;
+    r_bits = 0u;
+    const double t = P.t;
+    double h_next = P.h_abs, h_try = P.r_cur;
+    bool ahead = false;
+#ifdef BHG_AHEAD
+    ahead = RunsAhead<RHS, EVT>::value && kind == EV_AHEAD;
+    if (ahead) {
+        // (the prologue's rare cases, trace_dp54_kernel: left to the loop -- the ray goes back as it came)
+        if (!(P.h_abs > A.min_step_cap) || P.n_att >= A.max_steps) {
+            lane_state_copy(R, P);
+            return PARK_RESUME;
+        }
+        h_try = P.h_abs;
+        if (h_try > A.max_step) h_try = A.max_step;    // rk.py:121-124, not after a rejection (this step follows an accepted one)
+    }
+#endif
+    // the step as the integrate loop took it (takes it): same operations on the same bits
+    double t_new = t + h_try;
     if (t_new - A.lambda_end > 0.0) t_new = A.lambda_end;
     const double h = t_new - t;
     double a2[3], a3[3], a4[3], a5[3], a6[3], a7[3], xn[3], vn[3], r_new;
     dp54_stages<RHS>(P.x, P.v, P.a1, h, m, a2, a3, a4, a5, a6, a7, xn, vn, r_new);
-    const int outcome = dp54_short_core<RHS, EVT>(A, P.x, P.v, P.a1, t, t_new, h, a2, a3, a4, a5, a6, a7, xn, vn, kind, P.idx, P.n_att, P.n_acc);
-    if (outcome != PARK_RESUME) return outcome;
+    uint32_t ck = kind;         // what the short search is asked to locate
+    bool search = true;
+#ifdef BHG_AHEAD
+    if (ahead) {
+        // (phase by phase, with scheduling barriers in between: left to itself the compiler overlaps the disk pre-filter, the
+        // error norm and the search's polynomial and spills 150 B per lane -- some of it on the paths INTO the step loop)
+        __builtin_amdgcn_sched_barrier(0);
+        // the loop's event tests (trace_dp54_kernel), on the same quantities -- evaluated before the error norm here (they
+        // only count if the step is accepted; their values do not depend on the order)
+        const bool ev_h = r_new <= A.r_hor;
+        const bool ev_e = (P.r_cur - A.r_exit <= 0.0) && (r_new - A.r_exit >= 0.0);
+        bool ev_d = (EVT & EVT_DISK) && (!(EVT & EVT_OBJ) || A.disk_r_out > 0.0) && crossed_disk_plane<RHS>(P.x, xn);
+        const bool ev_o = (EVT & EVT_OBJ) && any_sphere_candidate_of<RHS>(A, P.x, xn);
+        if ((EVT & EVT_DISK) && ev_d &&
+            !(RHS == BHG_RHS_KERR_BL_ ? disk_crossing_may_hit_bl<true>(A, P.x, P.v, xn, vn, h, P.a1, a2, a3, a4, a5, a6)
+                                      : disk_crossing_may_hit<true>(A, P.x, P.v, xn, vn, h, P.a1, a2, a3, a4, a5, a6)))
+            ev_d = false;
+#ifndef BHG_NO_SHARP_FILTER
+        if (RHS == BHG_RHS_KERR_BL_ && (EVT & EVT_DISK) && ev_d &&
+            !disk_crossing_may_hit_sharp<RHS>(A, P.x, P.v, xn, vn, h, P.a1, a2, a3, a4, a5, a6))
+            ev_d = false;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const double h_abs = fabs(h);
+        P.n_att++;
+        const double errsq = dp54_errsq(P.x, P.v, xn, vn, P.a1, a2, a3, a4, a5, a6, a7, h, A.rtol, A.atol);
+        double fac = dp54_factor(errsq);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(errsq < 1.0)) {
+            lane_state_copy(R, P);                      // (the start state, the radius there)
+            R.h_abs = h_abs * fmax(0.2, fac);
+            r_bits = 1u;
+            return PARK_RESUME;
+        }
+        fac = fmin(fac, 10.0);
+        h_next = h_abs * fac;
+        P.n_acc++;
+        ck = (ev_h ? EV_HORIZON : 0u) | (ev_e ? EV_EXIT : 0u) | (ev_d ? EV_DISK : 0u) | (ev_o ? EV_OBJ : 0u);
+        if (ck == 0u) {
+            if (t_new - A.lambda_end >= 0.0) {           // base.py:203-204
+                store_result<false>(A, P.idx, xn, vn, BHG_FLAG_REACHED_END_, P.n_att, P.n_acc);
+                return PARK_ENDED;
+            }
+            search = false;                             // no event: the ray carries on from the step's end
+        } else if (!(ck == EV_EXIT || ((EVT & EVT_DISK) && ck == EV_DISK))) {
+            // the ordinary parked record of this step: start state, |h| for the NEXT step, the |h| this one tried (Lane::pend)
+            P.h_abs = h_next;
+            P.r_cur = h_try;
+            kind = ck;
+            return PARK_UNCERTIFIED;
+        }
+    }
+#endif
+    if (search) {
+        const int outcome = dp54_short_core<RHS, EVT>(A, P.x, P.v, P.a1, t, t_new, h, a2, a3, a4, a5, a6, a7, xn, vn, ck, P.idx, P.n_att, P.n_acc);
+        if (outcome == PARK_UNCERTIFIED && ahead) {
+            P.h_abs = h_next;
+            P.r_cur = h_try;
+            kind = ck;
+        }
+        if (outcome != PARK_RESUME) return outcome;
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         R.x[c] = xn[c];
@@ -1986,6 +2111,7 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
 
     int outcome = PARK_ENDED;
     Lane R;
+    uint32_t r_bits = 0u;     // bits of the queue entry of a ray that carries on (BHG_AHEAD: 1 = its last attempt was rejected)
     if (mine) {
         Metric met;
         met.r_s = A.r_s;
@@ -1994,7 +2120,7 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
         met.E = P.E;
         met.L = P.Lz;
         if (ADAPTIVE)
-            outcome = dp54_resolve_short<RHS, EVT>(A, met, P, kind, R);
+            outcome = dp54_resolve_short<RHS, EVT>(A, met, P, kind, R, r_bits);
         else
             outcome = rk4_resolve_parked<RHS, EVT>(A, met, P, kind, R);
     }
@@ -2006,7 +2132,7 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
     const uint64_t rm = __ballot(resumed), am = __ballot(again), fm = __ballot(mine && !resumed && !again);
     if (resumed) {
         SLOT_CHECK(Q, s, 4, 1, "drain_short resume");
-        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, 0u);
+        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, r_bits);
         Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)] = (uint8_t)s;
     } else if (again) {
         SLOT_CHECK(Q, s, 4, 3, "drain_short again");
@@ -2074,11 +2200,11 @@ __device__ __forceinline__ void drain_long(const TraceArgs &A, LDS &Q, Wave &W, 
 }
 
 // Which list does a parked step of these kinds go on?
-template <bool ADAPTIVE, int EVT>
+template <int RHS, bool ADAPTIVE, int EVT>
 __device__ __forceinline__ bool short_kind(uint32_t kind)
 {
     if (!ADAPTIVE) return true;
-    return ((EVT & EVT_EXIT) && kind == EV_EXIT) || ((EVT & EVT_DISK) && kind == EV_DISK);
+    return ((EVT & EVT_EXIT) && (kind == EV_EXIT || (RunsAhead<RHS, EVT>::value && kind == EV_AHEAD))) || ((EVT & EVT_DISK) && kind == EV_DISK);
 }
 // Does this kernel variant have a short list at all?  The adaptive kernel without optional events (the headline frame)
 // parks horizon crossings only, all of them long: its short drain -- 650 instructions -- is not compiled in.
@@ -2099,7 +2225,7 @@ __device__ __forceinline__ void deposit_parked(LDS &Q, Wave &W, Lane &L, uint32_
     const int can = n < W.n_free ? n : W.n_free;
     const uint32_t rk = lane_rank(pm);
     const bool dep = L.pend != 0u && (int)rk < can;
-    const bool shrt = short_kind<ADAPTIVE, EVT>(L.pend);
+    const bool shrt = short_kind<RHS, ADAPTIVE, EVT>(L.pend);
     const uint64_t ma = __ballot(dep && shrt), mb = __ballot(dep && !shrt);
     if (dep) {
         const uint32_t s = Q.free_list[W.n_free - 1 - (int)rk];
@@ -2130,9 +2256,14 @@ __device__ __forceinline__ void pop_rays(LDS &Q, Wave &W, Lane &L, uint32_t lane
     if (!L.active && L.pend == 0u && (int)rk < take) {
         const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
         SLOT_CHECK(Q, s, 1, 0, "pop");
+#ifdef BHG_AHEAD
+        // (a queue entry's bits: 1 = the ray's last attempt was rejected -- only a step the drain ran ahead and rejected)
+        L.rejected = slot_get<RHS>(Q.slot[s], L) & 1u;
+#else
         (void)slot_get<RHS>(Q.slot[s], L);
-        Q.free_list[W.n_free + (int)rk] = (uint8_t)s;
         L.rejected = 0u;
+#endif
+        Q.free_list[W.n_free + (int)rk] = (uint8_t)s;
         L.active = 1u;
     }
     wave_lds_sync();
@@ -2154,21 +2285,26 @@ __device__ __forceinline__ void swap_parked(LDS &Q, Wave &W, Lane &L, uint32_t l
     const int take = n < W.q_count ? n : W.q_count;
     const uint32_t rk = lane_rank(pm);
     const bool dep = L.pend != 0u && (int)rk < take;
-    const bool shrt = short_kind<ADAPTIVE, EVT>(L.pend);
+    const bool shrt = short_kind<RHS, ADAPTIVE, EVT>(L.pend);
     const uint64_t ma = __ballot(dep && shrt), mb = __ballot(dep && !shrt);
     if (dep) {
         const uint32_t s = Q.q_list[(W.q_head + (int)rk) & (QRING - 1)];
         Lane T;
         T.E = T.Lz = 0.0;
         SLOT_CHECK(Q, s, 1, shrt ? 2 : 3, "swap");
-        (void)slot_get<RHS>(Q.slot[s], T);
+        const uint32_t tbits = slot_get<RHS>(Q.slot[s], T);
         slot_put<RHS>(Q.slot[s], L, L.pend);
         if (shrt)
             Q.ev_list[W.n_evA + (int)lane_rank(ma)] = (uint8_t)s;
         else
             Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(mb)] = (uint8_t)s;
         L = T;
+#ifdef BHG_AHEAD
+        L.rejected = tbits & 1u;
+#else
+        (void)tbits;
         L.rejected = 0u;
+#endif
         L.pend = 0u;
         L.active = 1u;
     }
@@ -2551,6 +2687,28 @@ __global__ void __launch_bounds__(64, (RHS == BHG_RHS_KERR_BL_ ? BHG_KERR_WAVES_
                             store_result<false>(A, L.idx, L.x, L.v, BHG_FLAG_REACHED_END_, L.n_att, L.n_acc);
                             L.active = 0u;
                         }
+#ifdef BHG_AHEAD
+                        else if (RunsAhead<RHS, EVT>::value) {
+                            // Is the NEXT step expected to leave the exit sphere?  Radial extrapolation from the state just
+                            // accepted: r + h (x.k) / r >= R_exit, written r (r - R_exit) + h x.k >= 0 (Boyer-Lindquist: r and
+                            // dr/dlambda are coordinates).  A GUESS, not a bound: it decides where the step is computed --
+                            // here, or by the short drain (EV_AHEAD), once instead of twice -- never what comes out of it.
+                            double hp = t_bound - t_new;
+                            hp = L.h_abs < hp ? L.h_abs : hp;
+                            const double dr = r_new - A.r_exit;
+                            bool ahead;
+                            if (RHS == BHG_RHS_KERR_BL_) {
+                                ahead = dr < 0.0 && __builtin_fma(hp, vn[0], dr) >= 0.0;
+                            } else {
+                                const double xk = __builtin_fma(xn[2], vn[2], __builtin_fma(xn[1], vn[1], xn[0] * vn[0]));
+                                ahead = dr < 0.0 && __builtin_fma(r_new, dr, hp * xk) >= 0.0;
+                            }
+                            if (ahead) {
+                                L.pend = EV_AHEAD;      // (x, v, a1, t, h_abs, r_cur: the next step's start -- a queue-style record)
+                                L.active = 0u;
+                            }
+                        }
+#endif
                     }
                 } else {
                     L.h_abs *= fmax(0.2, fac);

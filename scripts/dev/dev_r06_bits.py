@@ -15,6 +15,13 @@ for what in (sys.argv[1:] or ["frame", "disk", "diskkerr", "orbit", "exit"]):
         fr = DeviceFrame(ctx, 2048, 2048, 4, fov_x=0.6, fov_y=0.6)
         fr.set_objects([[8.0, 0.0, 0.0, 1.5]])
         p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
+    elif what == "exitkerr":
+        fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
+        p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0, rhs_form=2, spin=0.45)
+    elif what == "orbitkerr":
+        fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
+        fr.set_objects([[8.0, 0.0, 0.0, 1.5]])
+        p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0, rhs_form=2, spin=0.45)
     elif what == "exit":
         fr = DeviceFrame(ctx, 1024, 1024, 5, fov_x=0.6, fov_y=0.6)
         p = _ffi.make_params(r_s=1.0, lambda_end=80.0, r_exit=40.0)
