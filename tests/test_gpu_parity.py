@@ -1309,6 +1309,39 @@ def test_trajectories_with_the_thin_disk_event(ctx, oracle):
     assert np.array_equal(res["end_loc"], tr0[0][i, 0:3]) or np.abs(res["end_loc"] - tr0[0][i, 0:3]).max() < 1e-10
 
 
+def test_steps_run_ahead_edge_cases(ctx, oracle):
+    """Round 6: in the exit-sphere kernels without the disk a ray whose NEXT step is expected to leave the sphere is handed to the
+    short drain before that step is computed (EV_AHEAD, csrc/geodesic_kernels.hip): the drain runs the whole step -- clamp, error
+    norm, accept / reject, event tests.  Where a step is computed must never show: every ray against the checker -- flags and both
+    step counts identical -- where the drain's copy of the loop's logic is exercised hardest: a step budget that runs out at the
+    handed-over step, tolerances at which it is rejected, a step cap, lambda_end inside it, the camera close to the sphere (the
+    FIRST step leaves: never predicted), object spheres in its way, a sphere so small that nearly every step is a last step."""
+    k = frame_rays(6000, seed=71, fov=1.2)
+    cam = np.array([0.5, -1.0, 26.0])
+    for kw in (dict(r_s=1.0, lambda_end=90.0, r_exit=35.0),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, rhs_form=1),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, max_steps=6),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, max_steps=9),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, max_step=3.0),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, rtol=1e-7, atol=1e-10, rhs_form=1),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, rtol=3e-2, atol=1e-4),
+               dict(r_s=1.0, lambda_end=57.0, r_exit=35.0),              # lambda_end is reached near the sphere: either may end the ray
+               dict(r_s=1.0, lambda_end=90.0, r_exit=26.5),              # the camera sits just inside: the first step leaves
+               dict(r_s=1.0, lambda_end=90.0, r_exit=27.5, max_step=0.4),
+               dict(r_s=1.0, lambda_end=90.0, r_exit=35.0, spheres=[[0.0, 0.0, -30.0, 6.0], [3.0, 2.0, 10.0, 1.5]]),
+               dict(r_s=0.0, lambda_end=90.0, r_exit=35.0)):
+        end, flags, steps, d = _compare(ctx, oracle, k[:3000] if kw.get("max_step") == 0.4 else k, cam, **kw)
+        assert (flags == 8).sum() > 0.3 * len(flags) or kw.get("max_steps") or kw.get("lambda_end") == 57.0, kw
+    # per-ray origins on the sphere's inside, rays in all directions
+    rng = np.random.default_rng(72)
+    x0 = rng.normal(size=(4000, 3))
+    x0 *= (rng.uniform(4.0, 19.5, 4000) / np.linalg.norm(x0, axis=1))[:, None]
+    kk = rng.normal(size=(4000, 3))
+    kk /= np.linalg.norm(kk, axis=1)[:, None]
+    _compare(ctx, oracle, kk, x0, r_s=1.0, lambda_end=60.0, r_exit=20.0)
+    _compare(ctx, oracle, kk, x0, r_s=1.0, lambda_end=60.0, r_exit=20.0, time_like=1)   # (the time-like unit: one run-time event variant, no ahead steps)
+
+
 def test_trajectories_with_object_spheres(ctx, oracle):
     """bhg_trajectory_objects (ABI 8; VERDICT r05 missing #4): the engine's literal per-ray call is exactly where the reference
     put its collision stub (RelativisticRenderEngine.py:293-305).  On the rays of the committed `objects` golden set and on
