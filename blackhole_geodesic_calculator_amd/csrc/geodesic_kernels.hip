@@ -659,6 +659,7 @@ constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
 // controller, event tests) and then locates the exit; the lane takes a fresh ray one iteration earlier and the step is
 // computed once instead of twice.  Where the step is computed never changes a result.
 constexpr uint32_t EV_AHEAD = 16u;
+constexpr uint32_t EV_REQUEUE = 32u;     // (marks the bits of a queue entry written back by the short drain; bit 0 = rejected)
 // Which kernel variants do: the Schwarzschild forms with the exit sphere and WITHOUT the thin disk -- config 4's kernel <0,5>
 // and the exit-only frames <0,1>, <1,1>.  Measured, round 6 (profiles/r06_ahead_ab.log, bit-identical on eight workloads):
 // config 4 -2.4 % time, the exit frame -2.2 %.  Not with the disk: <0,3> sits at 167 VGPRs and no scratch, and the drain's
@@ -670,7 +671,13 @@ constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 template <int RHS, int EVT>
 struct RunsAhead {
 #ifdef BHG_AHEAD
+#ifdef BHG_AHEAD_NO_DISK
     static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 && (EVT & 2 /* EVT_DISK */) == 0 && RHS != BHG_RHS_KERR_BL_;
+#else
+    // (with the disk: the Christoffel form only -- the reduced form's <1,3> spills into its main loop with it, seen in the ISA)
+    static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 && RHS != BHG_RHS_KERR_BL_ &&
+                                  ((EVT & 2 /* EVT_DISK */) == 0 || RHS == BHG_RHS_CHRISTOFFEL_);
+#endif
 #else
     static constexpr bool value = false;
 #endif
@@ -1628,7 +1635,7 @@ __device__ __forceinline__ void dense_dir_at(double th, double h, const double v
 // which one brentq lands on is part of the contract) -- goes through Brent, step for step as before.
 // ------------------------------------------------------------------------------------------
 // Outcome of a parked step
-constexpr int PARK_ENDED = 0, PARK_RESUME = 1, PARK_UNCERTIFIED = 2;
+constexpr int PARK_ENDED = 0, PARK_RESUME = 1, PARK_UNCERTIFIED = 2, PARK_REQUEUE = 3;
 
 // The short search itself, on a step whose stages are at hand: x, v, a1, t = the step's start, h = its signed length, t_new its
 // end, a2..a7 / xn / vn / r_new its stages and end state, h_next the controller's |h| for the step after it.  Called by the
@@ -1772,19 +1779,6 @@ __device__ __forceinline__ int dp54_short_core(const TraceArgs &A, const double 
     return PARK_RESUME;
 }
 
-__device__ __forceinline__ void lane_state_copy(Lane &R, const Lane &P)
-{
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        R.x[c] = P.x[c];
-        R.v[c] = P.v[c];
-        R.a1[c] = P.a1[c];
-    }
-    R.t = P.t;
-    R.h_abs = P.h_abs;
-    R.r_cur = P.r_cur;
-}
-
 // The SHORT way: one candidate event -- exit sphere or disk plane; a horizon crossing never comes here (short_kind()) --
 // whose event function is certified monotone over the step.  Returns PARK_UNCERTIFIED without having touched anything
 // when the certificate (or the iteration) fails: the step then goes to the long list.
@@ -1795,15 +1789,16 @@ __device__ __forceinline__ void lane_state_copy(Lane &R, const Lane &P)
 // for operation: clamp, stages (the ONE stage computation both kinds of record share: a drain usually holds both), error
 // norm, factor, accept / reject, event tests, disk pre-filter -- and then the short search if the step holds one short event.
 //   PARK_ENDED        the ray's result is stored (exit / disk located, or lambda_end reached);
-//   PARK_RESUME       the ray carries on through the queue: from the step's end (accepted, no terminal event), or from its
-//                     start with the reduced step (rejected: r_bits = 1), or unchanged where one of the step prologue's rare
-//                     cases applies (step budget, step-size floor: the loop's own code deals with those);
+//   PARK_RESUME       the ray carries on through the queue from the step's end (accepted, no terminal event): R;
+//   PARK_REQUEUE      the ray goes back into the queue from the step's START -- P itself is the queue entry, kind its bits
+//                     (EV_REQUEUE | rejected): with the reduced step after a rejection, or unchanged where one of the step prologue's rare cases applies
+//                     (step budget, step-size floor: the loop's own code deals with those).  (From P, not through R: a second
+//                     source for R behind the stages costs the disk variants 100 B of scratch per lane -- measured, round 6);
 //   PARK_UNCERTIFIED  the step holds what the short search does not take (horizon, object spheres, several candidates, a
 //                     failed certificate): P has become the ordinary parked record of that step, kind its event bits.
 template <int RHS, int EVT>
-__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, Lane &P, uint32_t &kind, Lane &R, uint32_t &r_bits)
+__device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metric &m, Lane &P, uint32_t &kind, Lane &R)
 {
-    r_bits = 0u;
     const double t = P.t;
     double h_next = P.h_abs, h_try = P.r_cur;
     bool ahead = false;
@@ -1812,8 +1807,8 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
     if (ahead) {
         // (the prologue's rare cases, trace_dp54_kernel: left to the loop -- the ray goes back as it came)
         if (!(P.h_abs > A.min_step_cap) || P.n_att >= A.max_steps) {
-            lane_state_copy(R, P);
-            return PARK_RESUME;
+            kind = EV_REQUEUE;
+            return PARK_REQUEUE;
         }
         h_try = P.h_abs;
         if (h_try > A.max_step) h_try = A.max_step;    // rk.py:121-124, not after a rejection (this step follows an accepted one)
@@ -1854,10 +1849,9 @@ __device__ __forceinline__ int dp54_resolve_short(const TraceArgs &A, const Metr
         double fac = dp54_factor(errsq);
         __builtin_amdgcn_sched_barrier(0);
         if (!(errsq < 1.0)) {
-            lane_state_copy(R, P);                      // (the start state, the radius there)
-            R.h_abs = h_abs * fmax(0.2, fac);
-            r_bits = 1u;
-            return PARK_RESUME;
+            P.h_abs = h_abs * fmax(0.2, fac);           // (P: the start state, the radius there, the counts with this attempt)
+            kind = EV_REQUEUE | 1u;                     // (the queue entry's bits: bit 0 = the last attempt was rejected)
+            return PARK_REQUEUE;
         }
         fac = fmin(fac, 10.0);
         h_next = h_abs * fac;
@@ -2111,7 +2105,6 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
 
     int outcome = PARK_ENDED;
     Lane R;
-    uint32_t r_bits = 0u;     // bits of the queue entry of a ray that carries on (BHG_AHEAD: 1 = its last attempt was rejected)
     if (mine) {
         Metric met;
         met.r_s = A.r_s;
@@ -2120,7 +2113,7 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
         met.E = P.E;
         met.L = P.Lz;
         if (ADAPTIVE)
-            outcome = dp54_resolve_short<RHS, EVT>(A, met, P, kind, R, r_bits);
+            outcome = dp54_resolve_short<RHS, EVT>(A, met, P, kind, R);
         else
             outcome = rk4_resolve_parked<RHS, EVT>(A, met, P, kind, R);
     }
@@ -2128,16 +2121,21 @@ __device__ __forceinline__ void drain_short(const TraceArgs &A, LDS &Q, Wave &W,
     // (on its way to the long list), or is free
     const uint32_t bits = slot_get<RHS>(Q.slot[s], L);
     lane_set_bits(L, bits);
-    const bool resumed = outcome == PARK_RESUME, again = outcome == PARK_UNCERTIFIED;
-    const uint64_t rm = __ballot(resumed), am = __ballot(again), fm = __ballot(mine && !resumed && !again);
+    // (PARK_REQUEUE: P goes back as the queue entry it is -- through the site that writes P back for the long list: two sources
+    // for one slot write are two live copies of a ray.  Its bits are EV_REQUEUE | rejected; the pop reads bit 0.)
+    const bool requeued = outcome == PARK_REQUEUE;
+    const bool resumed = outcome == PARK_RESUME, again = outcome == PARK_UNCERTIFIED || requeued;
+    const uint64_t rm = __ballot(resumed || requeued), am = __ballot(again && !requeued), fm = __ballot(mine && !resumed && !again);
     if (resumed) {
         SLOT_CHECK(Q, s, 4, 1, "drain_short resume");
-        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, r_bits);
+        entry_put<RHS>(Q.slot[s], R.x, R.v, R.a1, R.h_abs, R.r_cur, R.t, P.E, P.Lz, P.idx, P.n_att, P.n_acc, 0u);
         Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)] = (uint8_t)s;
     } else if (again) {
-        SLOT_CHECK(Q, s, 4, 3, "drain_short again");
+        SLOT_CHECK(Q, s, 4, requeued ? 1 : 3, "drain_short again");
         slot_put<RHS>(Q.slot[s], P, kind);
-        Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(am)] = (uint8_t)s;
+        uint8_t *list = requeued ? &Q.q_list[(W.q_head + W.q_count + (int)lane_rank(rm)) & (QRING - 1)]
+                                 : &Q.ev_list[NSLOT - 1 - W.n_evB - (int)lane_rank(am)];
+        *list = (uint8_t)s;
     } else if (mine) {
         // (the slots borrowed by the idle lanes of a partial drain sit below n_free and are not touched)
         SLOT_CHECK(Q, s, 4, 0, "drain_short free");
