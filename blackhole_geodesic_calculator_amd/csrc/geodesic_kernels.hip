@@ -660,13 +660,14 @@ constexpr uint32_t EV_HORIZON = 1u, EV_EXIT = 2u, EV_DISK = 4u, EV_OBJ = 8u;
 // computed once instead of twice.  Where the step is computed never changes a result.
 constexpr uint32_t EV_AHEAD = 16u;
 constexpr uint32_t EV_REQUEUE = 32u;     // (marks the bits of a queue entry written back by the short drain; bit 0 = rejected)
-// Which kernel variants do: the Schwarzschild forms with the exit sphere and WITHOUT the thin disk -- config 4's kernel <0,5>
-// and the exit-only frames <0,1>, <1,1>.  Measured, round 6 (profiles/r06_ahead_ab.log, bit-identical on eight workloads):
-// config 4 -2.4 % time, the exit frame -2.2 %.  Not with the disk: <0,3> sits at 167 VGPRs and no scratch, and the drain's
-// pass over such a step (error norm + the two-kind search; with or without the disk pre-filter in it -- both were built)
-// costs it 140 B of scratch per lane, part of it in blocks of the MAIN loop (result stores, deposit: seen in the ISA), which is
-// the trap section 4.1 of DESIGN.md describes.  Not the Boyer-Lindquist kernels: +3.1 % time on a Kerr exit frame (two waves per SIMD, 32 B of
-// scratch already).  BHG_NO_AHEAD builds without.
+// Which kernel variants do: the Schwarzschild forms with the exit sphere -- config 4's <0,5>, config 3's <0,3>, the exit-only
+// frames <0,1>, <1,1>.  Measured, round 6, bit-identical on eight full-size workloads, same-box A/Bs (profiles/r06_ahead_ab.log,
+// r06_ahead_disk_ab.log): config 4 -2.4 % time, the exit frame -2.5 %, config 3 -1.1 %.  With the disk the registers are the
+// whole story: <0,3> sits at 167 VGPRs, and the first three builds of it (a rejected step handed back through R, i.e. a second
+// source for R behind the stages) spilled 140-156 B per lane, part of it in the MAIN loop: +32 % time.  Handing a rejected
+// step back from P, its bits in `kind` (not even one more live word), leaves 52 B in the drains and nothing in the main loop.
+// Not the reduced form with the disk (<1,3> spills into its main loop with it).  Not the Boyer-Lindquist kernels: +3.1 % time
+// on a Kerr exit frame.  BHG_NO_AHEAD builds without; BHG_AHEAD_NO_DISK keeps the disk variants out.
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 template <int RHS, int EVT>
 struct RunsAhead {
