@@ -666,8 +666,9 @@ constexpr uint32_t EV_REQUEUE = 32u;     // (marks the bits of a queue entry wri
 // whole story: <0,3> sits at 167 VGPRs, and the first three builds of it (a rejected step handed back through R, i.e. a second
 // source for R behind the stages) spilled 140-156 B per lane, part of it in the MAIN loop: +32 % time.  Handing a rejected
 // step back from P, its bits in `kind` (not even one more live word), leaves 52 B in the drains and nothing in the main loop.
-// Not the reduced form with the disk (<1,3> spills into its main loop with it).  Not the Boyer-Lindquist kernels: +3.1 % time
-// on a Kerr exit frame.  BHG_NO_AHEAD builds without; BHG_AHEAD_NO_DISK keeps the disk variants out.
+// Not the reduced form with the disk (<1,3> spills into its main loop with it).  The Boyer-Lindquist kernels: with the disk
+// (Kerr + disk -1.5 % time), not without (a Kerr exit-only frame +2.6 %).  BHG_NO_AHEAD builds without; BHG_AHEAD_NO_DISK
+// keeps the disk variants out.
 constexpr int EVT_EXIT = 1, EVT_DISK = 2, EVT_OBJ = 4;
 template <int RHS, int EVT>
 struct RunsAhead {
@@ -675,9 +676,12 @@ struct RunsAhead {
 #ifdef BHG_AHEAD_NO_DISK
     static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 && (EVT & 2 /* EVT_DISK */) == 0 && RHS != BHG_RHS_KERR_BL_;
 #else
-    // (with the disk: the Christoffel form only -- the reduced form's <1,3> spills into its main loop with it, seen in the ISA)
-    static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 && RHS != BHG_RHS_KERR_BL_ &&
-                                  ((EVT & 2 /* EVT_DISK */) == 0 || RHS == BHG_RHS_CHRISTOFFEL_);
+    // Schwarzschild forms: every exit-sphere variant, with the disk the Christoffel form only (the reduced form's <1,3> spills into
+    // its main loop with it, seen in the ISA).  Boyer-Lindquist: WITH the disk only -- Kerr + disk -1.5 % time, a Kerr exit-only
+    // frame +2.6 % (profiles/r06_ahead_kerr_ab.log).
+    static constexpr bool value = (EVT & 1 /* EVT_EXIT */) != 0 &&
+                                  (RHS == BHG_RHS_KERR_BL_ ? (EVT & 2 /* EVT_DISK */) != 0
+                                                           : ((EVT & 2 /* EVT_DISK */) == 0 || RHS == BHG_RHS_CHRISTOFFEL_));
 #endif
 #else
     static constexpr bool value = false;
